@@ -1,0 +1,133 @@
+"""Oracle (test infrastructure): restatement of /root/reference/src/transcribe.rs.
+
+Windowing, the decode driver (`mels_to_text` with the live beam search,
+transcribe.rs:148-312) and the token-overlap stitch. The tokenizer is out of
+scope: the caller supplies the special-token ids and the `is_special` mask the
+reference derives from `tokenizer.json` (transcribe.rs:179-185, :243-251), and
+token ids are returned instead of text.
+
+The algorithm is restated AS WRITTEN: no KV cache, the whole decoder re-run over
+the whole prefix for every beam at every step, cross-attention K/V recomputed
+per layer per call (transcribe.rs:270, mod.rs:482-490), logits for all positions.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import beam as obeam
+from .mel import max_waveform_samples, prep_audio
+from .model import OracleWhisper, log_softmax
+
+
+@dataclass
+class SpecialTokens:
+    """Ids the reference looks up by name (transcribe.rs:179-185) + the vocab mask."""
+    start_of_transcript: int
+    language: int
+    transcribe: int
+    no_timestamps: int
+    end_of_text: int
+    is_special: np.ndarray          # bool [V], transcribe.rs:243-244
+
+
+def find_chunk_overlap(prev_tokens: Sequence[int], curr_tokens: Sequence[int],
+                       max_n_offsets: int, min_n_overlaps: int) -> Optional[Tuple[int, int]]:
+    """transcribe.rs:76-110."""
+    max_overlap = 0
+    max_overlap_indices = (0, 0)
+    n_offsets = min(len(prev_tokens), len(curr_tokens), max_n_offsets)
+    for offset in range(n_offsets):
+        prev_start_index = len(prev_tokens) - 1 - offset
+        matches = [i for i, (old, new) in enumerate(zip(prev_tokens[prev_start_index:], curr_tokens))
+                   if old == new]
+        n_overlap = len(matches)
+        if n_overlap > max_overlap:
+            max_overlap = n_overlap
+            curr_overlap_index = matches[0]
+            max_overlap_indices = (prev_start_index + curr_overlap_index, curr_overlap_index)
+    return max_overlap_indices if max_overlap >= min_n_overlaps else None
+
+
+def window_extents(n_samples: int, sample_rate: int, window_length_samples: int) -> List[Tuple[int, int]]:
+    """transcribe.rs:120-128: [start, end) of every window."""
+    chunk_overlap = sample_rate * 3
+    shift = max(max(window_length_samples - chunk_overlap, 0), 1)
+    iter_len = max(n_samples - 1, 0) // shift + 1
+    return [(i * shift, min(i * shift + window_length_samples, n_samples)) for i in range(iter_len)]
+
+
+def mels_to_tokens(whisper: OracleWhisper, st: SpecialTokens, mels: torch.Tensor, padding: int = 10,
+                   beam_size: int = 5, max_depth: int = 100) -> List[int]:
+    """transcribe.rs:148-312 (token ids instead of text). mels: [1, 80, T]."""
+    n_ctx_max_encoder = whisper.encoder_ctx_size()
+    _, n_mel, n_ctx = mels.shape
+    mels = torch.cat([mels[0:1, :, 0:min(n_ctx, n_ctx_max_encoder - padding)],
+                      torch.zeros(1, n_mel, padding, dtype=mels.dtype)], 2)      # :171-177
+    initial = obeam.BeamNode(
+        seq=[(t, 0.0) for t in (st.start_of_transcript, st.language, st.transcribe, st.no_timestamps)],
+        log_prob=0.0)                                                            # :203-220
+    encoder_output = whisper.forward_encoder(mels)                               # :222
+    neg_inf = float("-inf")
+    maskout = torch.tensor(np.where(st.is_special, neg_inf, 0.0), dtype=torch.float32)  # :244
+
+    def is_finished(seq) -> bool:                                                # :235-241
+        return bool(seq) and seq[-1][0] == st.end_of_text
+
+    def next_lp(beams):
+        """transcribe.rs:253-284: per beam the f32 log-prob row at its last token."""
+        max_seq_len = max((len(b.seq) for b in beams), default=0)
+        toks = [[t for t, _ in b.seq] + [0] * (max_seq_len - len(b.seq)) for b in beams]
+        logits = whisper.forward_decoder(torch.tensor(toks, dtype=torch.long),
+                                         encoder_output.repeat(len(beams), 1, 1))
+        if not max_seq_len > 5:
+            logits = logits + maskout[None, None]
+        log_probs = log_softmax(logits, 2)
+        return [log_probs[i, len(b.seq) - 1].numpy().astype(np.float64) for i, b in enumerate(beams)]
+
+    def step(beams, _next, is_fin, k):
+        """beam.rs:39-79 with the V-wide scans done by `top_indices_fast`."""
+        rows = next_lp(beams)
+        finished, new_beams = [], []
+        for node, lp in zip(beams, rows):
+            if is_fin(node.seq):
+                finished.append(node)
+            else:
+                scores = node.log_prob + lp                                      # :299
+                for tok in obeam.top_indices_fast(scores, k):
+                    new_beams.append(obeam.BeamNode(seq=node.seq + [(int(tok), float(lp[tok]))],
+                                                    log_prob=float(scores[tok])))
+        return obeam.get_top_elements(new_beams, lambda b: b.log_prob, k) + \
+            obeam.get_top_elements(finished, lambda b: b.log_prob, k)
+
+    seq = obeam.beam_search([initial], None, is_finished, beam_size, max_depth, step_fn=step)  # :309
+    return [t for t, _ in seq]
+
+
+def waveform_to_tokens(whisper: OracleWhisper, st: SpecialTokens, waveform: np.ndarray,
+                       sample_rate: int = 16000, beam_size: int = 5, max_depth: int = 100,
+                       return_windows: bool = False):
+    """transcribe.rs:23-74 without the tokenizer: returns the stitched token ids."""
+    padding = 10
+    n_per_window = max_waveform_samples(whisper.encoder_ctx_size() - padding)     # :32-34
+    tokens: List[int] = []
+    per_window = []
+    wav = torch.as_tensor(np.asarray(waveform, dtype=np.float32))
+    for start, end in window_extents(len(wav), sample_rate, n_per_window):
+        mel = prep_audio(wav[start:end][None], float(sample_rate))                # :134
+        new_tokens = mels_to_tokens(whisper, st, mel, padding, beam_size, max_depth)
+        per_window.append(list(new_tokens))
+        tokens = stitch(tokens, new_tokens)
+    return (tokens, per_window) if return_windows else tokens
+
+
+def stitch(tokens: List[int], new_tokens: List[int]) -> List[int]:
+    """transcribe.rs:56-63."""
+    ov = find_chunk_overlap(tokens, new_tokens, 40, 3)
+    if ov is not None:
+        prev_index, curr_index = ov
+        return tokens[:prev_index] + list(new_tokens[curr_index:])
+    return tokens + list(new_tokens)
