@@ -1,0 +1,199 @@
+/* whisper_hip.h -- C ABI of libwhisper_hip.so, the MI355X (gfx950) drop-in for the
+ * tensor seams of Gadersd/whisper-burn.
+ *
+ * The reference has no FFI: its only seam is the `B: Backend` type parameter.  The
+ * boundary is therefore cut at the three tensor call sites of src/transcribe.rs
+ * (prep_audio :134, Whisper::forward_encoder :222, Whisper::forward_decoder :270) plus
+ * the public Whisper::forward / waveform_to_text, and a Rust `extern "C"` shim keeps
+ * the reference's signatures on top of these entry points.
+ *
+ * Conventions
+ *  - every function returns WB_OK (0) or a negative wb_status; nothing aborts or
+ *    throws across the boundary (the reference's assert!/panic sites are mapped to
+ *    WB_ERR_SHAPE); wb_last_error() gives a thread-local message.
+ *  - the caller owns every host buffer it passes; the library owns device memory
+ *    behind opaque handles.  All pointers below are HOST pointers unless the
+ *    parameter name ends in `_dev`.
+ *  - all floating point data is IEEE f32 (the reference runs TchBackend<f32>,
+ *    src/bin/transcribe/main.rs:80); token ids are int32.
+ *  - a wb_model is immutable after load and may be shared by threads; a wb_session is
+ *    not thread-safe.
+ */
+#ifndef WHISPER_HIP_H
+#define WHISPER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum wb_status {
+  WB_OK = 0,
+  WB_ERR_ARG = -1,     /* null pointer / bad enum / bad handle                     */
+  WB_ERR_SHAPE = -2,   /* a shape contract the reference assert!s on was violated  */
+  WB_ERR_IO = -3,      /* dump-dir / npy read error (load.rs:29-45 Box<dyn Error>) */
+  WB_ERR_HIP = -4,     /* HIP runtime error (message carries hipGetErrorString)    */
+  WB_ERR_OOM = -5,
+  WB_ERR_STATE = -6    /* call sequence error on a session                         */
+} wb_status;
+
+/* compute_dtype for wb_model_load_*: the arithmetic the GEMMs run in. */
+enum { WB_F32 = 0,     /* exact-f32 MFMA (v_mfma_f32_32x32x2_f32): the parity path */
+       WB_BF16 = 1 };  /* bf16 MFMA, f32 accumulate: the speed path               */
+
+typedef struct wb_model wb_model;     /* Whisper<B>            src/model/mod.rs:41-45   */
+typedef struct wb_session wb_session; /* per window-batch decode state (new: the
+                                         reference has no KV cache, transcribe.rs:270) */
+
+/* WhisperConfig = AudioEncoderConfig + TextDecoderConfig, src/model/mod.rs:16-20,
+ * :73-80, :164-171 */
+typedef struct wb_dims {
+  int32_t n_mels, n_audio_ctx, n_audio_state, n_audio_head, n_audio_layer;
+  int32_t n_vocab, n_text_ctx, n_text_state, n_text_head, n_text_layer;
+} wb_dims;
+
+/* ---- model ---------------------------------------------------------------------- */
+
+/* load_whisper(path), src/model/load.rs:295-310: reads the dump directory written by
+ * python/dump.py (1-D f32 .npy files, shape stored as leading floats). */
+int wb_model_load_dump_dir(const char* dir, int device, int compute_dtype, wb_model** out);
+
+/* Same model from tensors already in host memory, named by their dump-dir relative
+ * path without ".npy" (e.g. "encoder/block_0/attn/query/weight"); lets a Rust caller
+ * hand over the tensors of a Burn record (src/bin/transcribe/main.rs:63-70).
+ * shapes[i] points at ranks[i] dims.  Scalars (n_head, n_layer, eps ...) have rank 1. */
+int wb_model_load_tensors(const char* const* names, const float* const* data,
+                          const int64_t* const* shapes, const int32_t* ranks, int n,
+                          int device, int compute_dtype, wb_model** out);
+
+/* Whisper::encoder_ctx_size / decoder_ctx_size (mod.rs:64-70) and the rest of the config. */
+int wb_model_dims(const wb_model* m, wb_dims* out);
+void wb_model_free(wb_model* m);
+
+/* LayerNorm epsilon placement: 0 = (x-mu)/(sqrt(var)+eps)  [Burn 0.9.0 @ fb2a71bb, default]
+ *                              1 = (x-mu)/sqrt(var+eps)    [later Burn releases, HF]      */
+int wb_model_set_ln_variant(wb_model* m, int eps_inside_sqrt);
+
+/* ---- stateless, reference-shaped entry points (the parity surface) -------------- */
+
+/* max_waveform_samples(n_frame_max), src/audio.rs:12-17 */
+int64_t wb_max_waveform_samples(int64_t n_frame_max);
+
+/* prep_audio(waveform [1,n], sample_rate) -> [1,80,n/160], src/audio.rs:34-56.
+ * mel must hold 80*(n/160) floats; *n_frames receives n/160.  n < 400 -> WB_ERR_SHAPE
+ * (audio.rs:292 assert). */
+int wb_prep_audio(int device, const float* pcm, int64_t n, double sample_rate, float* mel,
+                  int64_t* n_frames);
+
+/* Whisper::forward_encoder(mel [B,80,T]) -> [B,C,d], C=(T-1)/2+1, src/model/mod.rs:52-54,
+ * :228-260.  T > n_audio_ctx -> WB_ERR_SHAPE (mod.rs:236-241). */
+int wb_forward_encoder(wb_model* m, const float* mel, int B, int T, float* out);
+
+/* Whisper::forward_decoder(tokens [n,L], encoder_output [n,C,d]) -> logits [n,L,V],
+ * src/model/mod.rs:56-62, :131-157.  Stateless: cross-attention K/V are re-projected
+ * (mod.rs:482-490).  L > n_text_ctx -> WB_ERR_SHAPE (mod.rs:134-139). */
+int wb_forward_decoder(wb_model* m, const int32_t* tokens, int n, int L, const float* enc, int C,
+                       float* logits);
+
+/* Whisper::forward(mel [B,80,T], tokens [B,L]) -> logits [B,L,V], src/model/mod.rs:48-50 */
+int wb_forward(wb_model* m, const float* mel, int B, int T, const int32_t* tokens, int L,
+               float* logits);
+
+/* ---- stateful fast path (result-equivalent to transcribe.rs:148-312) ------------ */
+
+/* Decode constants the reference hard-codes; wb_decode_params_default() fills them in. */
+typedef struct wb_decode_params {
+  int32_t beam_size;            /* transcribe.rs:232 (5).  1 == greedy */
+  int32_t max_depth;            /* transcribe.rs:233 (100)                            */
+  int32_t padding;              /* transcribe.rs:33  (10 zero mel frames)             */
+  int32_t overlap_seconds;      /* transcribe.rs:120 (3)                              */
+  int32_t max_n_offsets;        /* transcribe.rs:57  (40)                             */
+  int32_t min_n_overlaps;       /* transcribe.rs:57  (3)                              */
+  int32_t mask_until_len;       /* transcribe.rs:271 (5): special mask while len <= 5 */
+  int32_t max_batch_windows;    /* engine knob: windows encoded/decoded together (0 = all) */
+  /* special tokens by id (transcribe.rs:179-185; looked up by name in tokenizer.json
+   * by the reference -- the tokenizer stays on the caller's side of the boundary) */
+  int32_t tok_start_of_transcript, tok_language, tok_transcribe, tok_no_timestamps,
+      tok_end_of_text;
+} wb_decode_params;
+void wb_decode_params_default(wb_decode_params* p);
+
+/* mel (+clip, +`padding` zero frames) -> encoder -> cross-attention K/V once, for
+ * n_windows windows cut from `pcm` at [starts[i], starts[i]+lens[i]).
+ * transcribe.rs:134, :171-177, :222.  max_beams = live beams per window. */
+int wb_session_begin(wb_model* m, const float* pcm, int64_t n_pcm, const int64_t* starts,
+                     const int64_t* lens, int n_windows, int max_beams, int padding,
+                     wb_session** out);
+/* Same, from already-prepared mel windows mel[i] = [80, T[i]] packed back to back. */
+int wb_session_begin_mel(wb_model* m, const float* mel, const int32_t* T, int n_windows,
+                         int max_beams, int padding, wb_session** out);
+
+/* is_special[V] != 0 where bpe.is_special(id); transcribe.rs:243-251 */
+int wb_session_set_special_mask(wb_session* s, const uint8_t* is_special);
+
+/* One decode step for n live beams (KV-cached equivalent of the closure
+ * `beamsearch_next`, transcribe.rs:253-307).  Beam i of this step continues the beam
+ * that occupied slot parent[i] in the previous step (-1: a fresh, empty beam) of window
+ * window[i], and appends new_tokens[i].  If k > 0 the k best continuations of each beam
+ * by (log-prob descending, token id ascending) are returned: log_softmax over the
+ * (optionally special-masked, transcribe.rs:271-275) logits of the last position. */
+int wb_session_step(wb_session* s, const int32_t* new_tokens, const int32_t* parent,
+                    const int32_t* window, int n, int apply_special_mask, int k, int32_t* top_ids,
+                    float* top_logprobs);
+
+/* Debug/parity: full log-prob row [V] of beam slot i after the last step. */
+int wb_session_last_logprobs(wb_session* s, int slot, float* out);
+/* Debug/parity: encoder output of window w, [C_w, d]; *C receives C_w. */
+int wb_session_encoder_output(wb_session* s, int w, float* out, int32_t* C);
+void wb_session_free(wb_session* s);
+
+/* mels_to_text (transcribe.rs:148-383) without the tokenizer, for a batch of windows:
+ * beam search (src/beam.rs:9-110) driven by wb_session_step.  out_tokens holds
+ * n_windows rows of `row_stride` ints; out_lens[i] = sequence length of window i
+ * (prompt included, transcribe.rs:309-312). */
+int wb_session_decode(wb_session* s, const wb_decode_params* p, int32_t* out_tokens,
+                      int32_t row_stride, int32_t* out_lens);
+
+/* waveform_to_text (transcribe.rs:23-74) without the tokenizer: windows
+ * (transcribe.rs:114-128), per-window decode, token-overlap stitch
+ * (find_chunk_overlap, transcribe.rs:76-110).  Only windows [win_begin, win_end) are
+ * decoded (multi-GPU sharding: SURVEY 8e); pass 0, -1 for all.  Per-window token rows go
+ * to win_tokens [n_local, row_stride] / win_lens; when stitched != NULL the stitched
+ * stream of the local windows is written there (capacity stitched_cap, length *n_stitched). */
+int wb_waveform_to_tokens(wb_model* m, const float* pcm, int64_t n, int sample_rate,
+                          const wb_decode_params* p, const uint8_t* is_special, int win_begin,
+                          int win_end, int32_t* win_tokens, int32_t row_stride, int32_t* win_lens,
+                          int32_t* stitched, int64_t stitched_cap, int64_t* n_stitched);
+
+/* Window extents of waveform_to_mel_tensor (transcribe.rs:114-128).  Returns the window
+ * count; fills starts/lens when non-NULL (capacity cap). */
+int64_t wb_window_extents(int64_t n_samples, int sample_rate, int64_t window_len, int overlap_seconds,
+                          int64_t* starts, int64_t* lens, int64_t cap);
+
+/* find_chunk_overlap(prev, curr, max_n_offsets, min_n_overlaps), transcribe.rs:76-110.
+ * Returns 1 and sets the indices if an overlap >= min_n_overlaps was found, else 0. */
+int wb_find_chunk_overlap(const int32_t* prev, int64_t n_prev, const int32_t* curr, int64_t n_curr,
+                          int max_n_offsets, int min_n_overlaps, int64_t* prev_index,
+                          int64_t* curr_index);
+
+/* Fold the stitch (transcribe.rs:56-63) over per-window token rows in window order. */
+int wb_stitch_windows(const int32_t* win_tokens, int32_t row_stride, const int32_t* win_lens,
+                      int n_windows, int max_n_offsets, int min_n_overlaps, int32_t* out,
+                      int64_t cap, int64_t* n_out);
+
+/* ---- measurement hooks ----------------------------------------------------------- */
+
+/* Per-stage device time (ms, HIP events on the engine's stream) accumulated since the
+ * last reset: [0]=mel [1]=encoder [2]=cross-KV [3]=decode steps [4]=number of decode
+ * steps [5]=mel kernel launches [6]=logits kernel ms [7]=logits kernel launches. */
+int wb_profile_enable(int on);
+int wb_profile_read(double* out8, int reset);
+
+const char* wb_last_error(void);
+const char* wb_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WHISPER_HIP_H */

@@ -1,0 +1,181 @@
+// K5: flash-style attention in exact f32 on MFMA, head size 64.
+//
+// Replaces qkv_attention (/root/reference/src/model/mod.rs:493-533), which materialises the
+// [B,H,Lq,Lk] score tensor through >= 9 launches: scores never leave registers here.
+//
+// "Swapped" formulation so that softmax rows are lane-local and P never round-trips LDS:
+//   S^T[kv][q]  = K_tile * Q^T          (A = K from LDS, B = Q fragment held in registers)
+//   O^T[dh][q] += V_tile^T * P^T        (A = V from LDS, B = P^T = the S^T accumulator itself)
+// With v_mfma_f32_32x32x2_f32, the accumulator register r of lane (j, h) holds element
+// (row = (r&3) + 8(r>>2) + 4h, col = j); as the B operand of the PV product the same lane must
+// supply P^T[kv(step, h)][q = j] -- exactly its own accumulator r = step when the V operand is
+// gathered with the matching kv permutation.  Row max / sum are per lane (+ one xor-32 exchange).
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace wb {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int KV_TILE = 32;
+constexpr int KS_LD = 65;   // padded K rows: lanes walk rows -> conflict-free ds_read_b32
+constexpr int VS_LD = 64;
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attention_f32_kernel(const float* __restrict__ Q, int ldq,
+                                                                  const float* __restrict__ K,
+                                                                  const float* __restrict__ V, int ldkv,
+                                                                  float* __restrict__ O, int ldo,
+                                                                  const AttnSeg* __restrict__ segs, float scale,
+                                                                  int causal) {
+  __shared__ __attribute__((aligned(16))) float Ks[2][KV_TILE][KS_LD];
+  __shared__ __attribute__((aligned(16))) float Vs[2][KV_TILE][VS_LD];
+  constexpr int NTHR = NW * 64;
+  constexpr int LD_PER_T = (KV_TILE * 16) / NTHR;   // float4 loads per thread per operand per tile
+  static_assert((KV_TILE * 16) % NTHR == 0, "tile must divide over the block");
+
+  const AttnSeg seg = segs[blockIdx.z];
+  const int head = blockIdx.y;
+  const int q_base = blockIdx.x * 32 * NW;
+  if (q_base >= seg.q_len) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, hh = lane >> 5;
+  const int q0 = q_base + wave * 32;
+  const int qi = q0 + li;                         // this lane's query position (may be >= q_len)
+  const int qrow = min(qi, seg.q_len - 1);
+
+  // Q fragment: Q[q][head*64 + hh*32 + s], s = 0..31, pre-scaled (mod.rs:506-509)
+  float qreg[32];
+  {
+    const float4* qp = reinterpret_cast<const float4*>(Q + (int64_t)(seg.q_row0 + qrow) * ldq + head * 64 + hh * 32);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      float4 v = qp[i];
+      qreg[4 * i + 0] = v.x * scale; qreg[4 * i + 1] = v.y * scale;
+      qreg[4 * i + 2] = v.z * scale; qreg[4 * i + 3] = v.w * scale;
+    }
+  }
+
+  int kv_end = seg.kv_len;
+  if (causal) kv_end = min(kv_end, q_base + 32 * NW);   // keys beyond the block's last query are masked
+  const int n_tiles = (kv_end + KV_TILE - 1) / KV_TILE;
+
+  const float* Kb = K + (int64_t)seg.kv_row0 * ldkv + head * 64;
+  const float* Vb = V + (int64_t)seg.kv_row0 * ldkv + head * 64;
+  float4 rk[LD_PER_T], rv[LD_PER_T];
+  auto load_tile = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < LD_PER_T; i++) {
+      int idx = tid + i * NTHR, r = idx >> 4, c4 = (idx & 15) * 4;
+      int kv = t * KV_TILE + r;
+      if (kv < seg.kv_len) {
+        rk[i] = *reinterpret_cast<const float4*>(Kb + (int64_t)kv * ldkv + c4);
+        rv[i] = *reinterpret_cast<const float4*>(Vb + (int64_t)kv * ldkv + c4);
+      } else {
+        rk[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        rv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < LD_PER_T; i++) {
+      int idx = tid + i * NTHR, r = idx >> 4, c4 = (idx & 15) * 4;
+      Ks[buf][r][c4 + 0] = rk[i].x * scale; Ks[buf][r][c4 + 1] = rk[i].y * scale;   // mod.rs:510-514
+      Ks[buf][r][c4 + 2] = rk[i].z * scale; Ks[buf][r][c4 + 3] = rk[i].w * scale;
+      *reinterpret_cast<float4*>(&Vs[buf][r][c4]) = rv[i];
+    }
+  };
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int t = 0; t < 2; t++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) oacc[t][r] = 0.f;
+  float m_run = -1.0e30f, l_run = 0.f;
+
+  if (n_tiles > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int t = 0; t < n_tiles; t++) {
+    const int buf = t & 1;
+    if (t + 1 < n_tiles) load_tile(t + 1);
+    // ---- S^T = K_tile * Q^T ----
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) sacc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 32; s++)
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[buf][li][hh * 32 + s], qreg[s], sacc, 0, 0, 0);
+    // ---- mask + online softmax (rows = this lane's query) ----
+    const int kv0 = t * KV_TILE + 4 * hh;
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int kv = kv0 + (r & 3) + 8 * (r >> 2);
+      const bool ok = kv < seg.kv_len && (!causal || kv <= qi);
+      sacc[r] = ok ? sacc[r] : -INFINITY;
+      tmax = fmaxf(tmax, sacc[r]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      sacc[r] = expf(sacc[r] - m_new);
+      psum += sacc[r];
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) oacc[tt][r] *= alpha;
+    // ---- O^T += V_tile^T * P^T ----
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+      for (int s = 0; s < 16; s++)
+        oacc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[buf][(s & 3) + 8 * (s >> 2) + 4 * hh][32 * tt + li],
+                                                         sacc[s], oacc[tt], 0, 0, 0);
+    if (t + 1 < n_tiles) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  if (qi < seg.q_len) {
+    float* op = O + (int64_t)(seg.q_row0 + qi) * ldo + head * 64;
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        float4 v = make_float4(oacc[tt][4 * g + 0] / l_tot, oacc[tt][4 * g + 1] / l_tot,
+                               oacc[tt][4 * g + 2] / l_tot, oacc[tt][4 * g + 3] / l_tot);
+        *reinterpret_cast<float4*>(op + 32 * tt + 8 * g + 4 * hh) = v;
+      }
+  }
+}
+
+}  // namespace
+
+void launch_attention_f32(hipStream_t st, const float* Q, int ldq, const float* K, const float* V, int ldkv,
+                          float* O, int ldo, const AttnSeg* segs_dev, int n_segs, int max_q_len, int n_head,
+                          float scale, int causal) {
+  if (n_segs <= 0 || max_q_len <= 0) return;
+  if (max_q_len <= 64) {
+    dim3 grid((max_q_len + 63) / 64, n_head, n_segs);
+    hipLaunchKernelGGL((attention_f32_kernel<2>), grid, dim3(128), 0, st, Q, ldq, K, V, ldkv, O, ldo, segs_dev,
+                       scale, causal);
+  } else {
+    dim3 grid((max_q_len + 127) / 128, n_head, n_segs);
+    hipLaunchKernelGGL((attention_f32_kernel<4>), grid, dim3(256), 0, st, Q, ldq, K, V, ldkv, O, ldo, segs_dev,
+                       scale, causal);
+  }
+}
+
+}  // namespace wb

@@ -1,0 +1,205 @@
+// Encoder / decoder forward passes: the reference's module graph (src/model/mod.rs) expressed as a
+// short sequence of fused gfx950 launches over packed, ragged window batches.
+#include "engine.h"
+
+#include <map>
+#include <mutex>
+
+namespace wb {
+
+int get_mel_tables(int device, double sample_rate, const MelTables** out_dev) {
+  static std::mutex mu;
+  static std::map<std::pair<int, double>, MelTables*> cache;
+  std::lock_guard<std::mutex> lk(mu);
+  auto key = std::make_pair(device, sample_rate);
+  auto it = cache.find(key);
+  if (it != cache.end()) { *out_dev = it->second; return WB_OK; }
+  auto host = std::make_unique<MelTables>();
+  WB_REQUIRE(mel_tables_build(sample_rate, host.get()) == 0, WB_ERR_SHAPE,
+             "mel filterbank for sample_rate %g has a row wider than %d taps", sample_rate, MEL_MAX_TAPS);
+  MelTables* dev = nullptr;
+  WB_HIP(hipSetDevice(device));
+  WB_HIP(hipMalloc(&dev, sizeof(MelTables)));
+  WB_HIP(hipMemcpy(dev, host.get(), sizeof(MelTables), hipMemcpyHostToDevice));
+  cache[key] = dev;
+  *out_dev = dev;
+  return WB_OK;
+}
+
+static int upload(hipStream_t st, DevMem& dst, const void* src, size_t bytes) {
+  WB_TRY(dst.ensure(bytes));
+  WB_HIP(hipMemcpyAsync(dst.p, src, bytes, hipMemcpyHostToDevice, st));
+  return WB_OK;
+}
+
+static int gemm(hipStream_t st, const GemmArgs& a) {
+  WB_REQUIRE(launch_gemm_f32(st, a) == 0, WB_ERR_SHAPE, "gemm: unsupported shape M=%d N=%d K=%d ldb=%d", a.M,
+             a.N, a.K, a.ldb);
+  return WB_OK;
+}
+
+static GemmArgs linear_args(const float* A, int M, const LinearW& w, float* C) {
+  GemmArgs g;
+  g.A = A; g.lda = w.k; g.B = w.w; g.ldb = w.n; g.C = C; g.ldc = w.n; g.bias = w.b;
+  g.M = M; g.N = w.n; g.K = w.k;
+  return g;
+}
+
+int run_encoder(wb_model* m, hipStream_t st, Workspace& ws, const MelBatch& mb, float* out_dev, EncoderOut* eo) {
+  const wb_dims& D = m->dims;
+  const int d = D.n_audio_state, H = D.n_audio_head, nw = (int)mb.T.size();
+  WB_REQUIRE(nw > 0, WB_ERR_ARG, "encoder: empty batch");
+  eo->C.resize(nw); eo->row0.resize(nw);
+  int rows1 = 0, rows2 = 0, maxC = 0;
+  std::vector<int> x1row0(nw);
+  for (int w = 0; w < nw; w++) {
+    // mod.rs:236-241 (the reference bounds MEL FRAMES by n_audio_ctx)
+    WB_REQUIRE(mb.T[w] >= 1 && mb.T[w] <= D.n_audio_ctx, WB_ERR_SHAPE, "Audio length %d cannot exceed %d.",
+               mb.T[w], D.n_audio_ctx);
+    x1row0[w] = rows1; rows1 += mb.T[w];
+    eo->C[w] = (mb.T[w] - 1) / 2 + 1;
+    eo->row0[w] = rows2; rows2 += eo->C[w];
+    maxC = std::max(maxC, eo->C[w]);
+  }
+  eo->rows = rows2;
+  // ---- per-row descriptors of the two implicit-GEMM convolutions ----
+  std::vector<RowDesc> d1(rows1), d2(rows2);
+  std::vector<int32_t> aidx(rows2);
+  std::vector<AttnSeg> segs(nw);
+  for (int w = 0; w < nw; w++) {
+    const int T = mb.T[w], C = eo->C[w];
+    for (int t = 0; t < T; t++) {
+      RowDesc& r = d1[x1row0[w] + t];
+      r.off = (int32_t)(w * mb.win_stride + t); r.klo = (t == 0); r.khi = (t == T - 1);
+    }
+    for (int c = 0; c < C; c++) {
+      RowDesc& r = d2[eo->row0[w] + c];
+      r.off = (int32_t)(((int64_t)x1row0[w] + 2 * c - 1) * d);   // rows 2c-1, 2c, 2c+1 of x1 are contiguous
+      r.klo = (int16_t)(c == 0 ? d : 0);                         // zero padding left of the window
+      r.khi = (int16_t)(2 * c + 1 >= T ? 2 * d : 3 * d);         // ... and right of it
+      aidx[eo->row0[w] + c] = c;                                 // positional_embedding[0..C] (mod.rs:247-252)
+    }
+    segs[w] = AttnSeg{eo->row0[w], C, eo->row0[w], C};
+  }
+  WB_REQUIRE((int64_t)nw * mb.win_stride < (int64_t)1 << 31 && (int64_t)rows1 * d < (int64_t)1 << 31, WB_ERR_SHAPE,
+             "encoder batch too large for 32-bit row offsets");
+  WB_TRY(upload(st, ws.desc1, d1.data(), d1.size() * sizeof(RowDesc)));
+  WB_TRY(upload(st, ws.desc2, d2.data(), d2.size() * sizeof(RowDesc)));
+  WB_TRY(upload(st, ws.auxidx, aidx.data(), aidx.size() * sizeof(int32_t)));
+  WB_TRY(upload(st, ws.segs, segs.data(), segs.size() * sizeof(AttnSeg)));
+  WB_HIP(hipStreamSynchronize(st));   // host vectors die at scope exit
+  WB_TRY(ws.x1.ensure((size_t)rows1 * d * 4));
+  WB_TRY(ws.x.ensure((size_t)rows2 * d * 4));
+  WB_TRY(ws.h.ensure((size_t)rows2 * d * 4));
+  WB_TRY(ws.qkv.ensure((size_t)rows2 * 3 * d * 4));
+  WB_TRY(ws.att.ensure((size_t)rows2 * d * 4));
+  WB_TRY(ws.hm.ensure((size_t)rows2 * 4 * d * 4));
+  float *x1 = ws.x1.as<float>(), *x = ws.x.as<float>(), *h = ws.h.as<float>(), *qkv = ws.qkv.as<float>(),
+        *att = ws.att.as<float>(), *hm = ws.hm.as<float>();
+
+  // conv1 + GELU (mod.rs:243): implicit GEMM over [T, 240] x [240, d], output position-major [T, d]
+  {
+    GemmArgs g;
+    g.A = mb.mel; g.a_desc = ws.desc1.as<RowDesc>(); g.conv1_tstride = mb.row_stride;
+    g.B = m->conv1.w; g.ldb = d; g.C = x1; g.ldc = d; g.bias = m->conv1.b;
+    g.M = rows1; g.N = d; g.K = 240; g.act = ACT_GELU;
+    WB_TRY(gemm(st, g));
+  }
+  // conv2 (stride 2) + GELU + transpose + positional add (mod.rs:244-252): rows 2c-1..2c+1 of x1 form one A row
+  {
+    GemmArgs g;
+    g.A = x1; g.a_desc = ws.desc2.as<RowDesc>();
+    g.B = m->conv2.w; g.ldb = d; g.C = x; g.ldc = d; g.bias = m->conv2.b;
+    g.M = rows2; g.N = d; g.K = 3 * d; g.act = ACT_GELU;
+    g.aux = m->enc_pos; g.aux_idx = ws.auxidx.as<int32_t>(); g.ld_aux = d;
+    WB_TRY(gemm(st, g));
+  }
+  for (int i = 0; i < D.n_audio_layer; i++) {   // ResidualEncoderAttentionBlock::forward, mod.rs:299-303
+    const EncBlockW& b = m->enc[i];
+    launch_layernorm(st, x, h, rows2, d, b.ln1.g, b.ln1.b, b.ln1.eps, m->ln_eps_inside_sqrt);
+    GemmArgs g = linear_args(h, rows2, b.qkv, qkv);
+    g.col_scale = m->qk_scale; g.col_scale_period = 3 * d; g.col_scale_width = 2 * d;   // q*s, k*s (mod.rs:506-514)
+    WB_TRY(gemm(st, g));
+    launch_attention_f32(st, qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, att, d, ws.segs.as<AttnSeg>(), nw, maxC, H,
+                         1.0f, 0);
+    g = linear_args(att, rows2, b.out, x);
+    g.residual = x; g.ldr = d;
+    WB_TRY(gemm(st, g));
+    launch_layernorm(st, x, h, rows2, d, b.ln2.g, b.ln2.b, b.ln2.eps, m->ln_eps_inside_sqrt);
+    g = linear_args(h, rows2, b.mlp1, hm);
+    g.act = ACT_GELU;
+    WB_TRY(gemm(st, g));
+    g = linear_args(hm, rows2, b.mlp2, x);
+    g.residual = x; g.ldr = d;
+    WB_TRY(gemm(st, g));
+  }
+  launch_layernorm(st, x, out_dev, rows2, d, m->ln_post.g, m->ln_post.b, m->ln_post.eps, m->ln_eps_inside_sqrt);
+  WB_HIP(hipGetLastError());
+  return WB_OK;
+}
+
+int run_decoder_stateless(wb_model* m, hipStream_t st, Workspace& ws, const int32_t* tokens_dev, int n, int L,
+                          const float* enc_dev, int C, float* logits_dev) {
+  const wb_dims& D = m->dims;
+  const int d = D.n_text_state, H = D.n_text_head, NL = D.n_text_layer, V = D.n_vocab;
+  const int rows = n * L, krows = n * C, ldkv = NL * 2 * d;
+  std::vector<AttnSeg> segs(2 * n);
+  for (int i = 0; i < n; i++) {
+    segs[i] = AttnSeg{i * L, L, i * L, L};          // masked self-attention
+    segs[n + i] = AttnSeg{i * L, L, i * C, C};      // cross-attention
+  }
+  WB_TRY(upload(st, ws.segs, segs.data(), segs.size() * sizeof(AttnSeg)));
+  WB_HIP(hipStreamSynchronize(st));
+  WB_TRY(ws.x.ensure((size_t)rows * d * 4));
+  WB_TRY(ws.h.ensure((size_t)rows * d * 4));
+  WB_TRY(ws.qkv.ensure((size_t)rows * 3 * d * 4));
+  WB_TRY(ws.att.ensure((size_t)rows * d * 4));
+  WB_TRY(ws.hm.ensure((size_t)rows * 4 * d * 4));
+  WB_TRY(ws.x1.ensure((size_t)krows * ldkv * 4));   // cross K|V of every layer
+  float *x = ws.x.as<float>(), *h = ws.h.as<float>(), *qkv = ws.qkv.as<float>(), *att = ws.att.as<float>(),
+        *hm = ws.hm.as<float>(), *ckv = ws.x1.as<float>();
+  const AttnSeg* sg = ws.segs.as<AttnSeg>();
+
+  launch_embed(st, tokens_dev, rows, L, d, m->tok_emb, m->dec_pos, x);   // mod.rs:141-146
+  // cross-attention K/V (mod.rs:484-485) for all layers in one GEMM; K columns pre-scaled (mod.rs:510-514)
+  GemmArgs g = linear_args(enc_dev, krows, m->ckv_all, ckv);
+  g.col_scale = m->qk_scale; g.col_scale_period = 2 * d; g.col_scale_width = d;
+  WB_TRY(gemm(st, g));
+  for (int i = 0; i < NL; i++) {   // ResidualDecoderAttentionBlock::forward, mod.rs:345-350
+    const DecBlockW& b = m->dec[i];
+    launch_layernorm(st, x, h, rows, d, b.ln1.g, b.ln1.b, b.ln1.eps, m->ln_eps_inside_sqrt);
+    g = linear_args(h, rows, b.qkv, qkv);
+    g.col_scale = m->qk_scale; g.col_scale_period = 3 * d; g.col_scale_width = 2 * d;
+    WB_TRY(gemm(st, g));
+    launch_attention_f32(st, qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, att, d, sg, n, L, H, 1.0f, 1);
+    g = linear_args(att, rows, b.out, x);
+    g.residual = x; g.ldr = d;
+    WB_TRY(gemm(st, g));
+    launch_layernorm(st, x, h, rows, d, b.ln2.g, b.ln2.b, b.ln2.eps, m->ln_eps_inside_sqrt);
+    g = linear_args(h, rows, b.cq, qkv);
+    g.col_scale = m->qk_scale; g.col_scale_period = d; g.col_scale_width = d;
+    WB_TRY(gemm(st, g));
+    launch_attention_f32(st, qkv, d, ckv + (size_t)i * 2 * d, ckv + (size_t)i * 2 * d + d, ldkv, att, d, sg + n, n,
+                         L, H, 1.0f, 0);
+    g = linear_args(att, rows, b.cout, x);
+    g.residual = x; g.ldr = d;
+    WB_TRY(gemm(st, g));
+    launch_layernorm(st, x, h, rows, d, b.ln3.g, b.ln3.b, b.ln3.eps, m->ln_eps_inside_sqrt);
+    g = linear_args(h, rows, b.mlp1, hm);
+    g.act = ACT_GELU;
+    WB_TRY(gemm(st, g));
+    g = linear_args(hm, rows, b.mlp2, x);
+    g.residual = x; g.ldr = d;
+    WB_TRY(gemm(st, g));
+  }
+  launch_layernorm(st, x, h, rows, d, m->ln_dec.g, m->ln_dec.b, m->ln_dec.eps, m->ln_eps_inside_sqrt);
+  // logits = x . token_embedding^T (mod.rs:156), streamed from the [d][Vp] transposed copy
+  GemmArgs lg;
+  lg.A = h; lg.lda = d; lg.B = m->tok_emb_t; lg.ldb = m->vocab_ld; lg.C = logits_dev; lg.ldc = V;
+  lg.M = rows; lg.N = V; lg.K = d;
+  WB_TRY(gemm(st, lg));
+  WB_HIP(hipGetLastError());
+  return WB_OK;
+}
+
+}  // namespace wb

@@ -1,0 +1,34 @@
+// Encoder / decoder orchestration over the gfx950 kernels (host side).
+#pragma once
+#include <vector>
+
+#include "kernels.h"
+#include "wb_internal.h"
+
+namespace wb {
+
+// Geometry of a batch of mel windows laid out [n_windows][80][row_stride]; T[w] = frames incl. padding.
+struct MelBatch {
+  const float* mel = nullptr;      // device
+  int64_t win_stride = 0;          // floats between windows
+  int row_stride = 0;              // floats between mel rows
+  std::vector<int> T;              // frames per window (<= n_audio_ctx)
+};
+
+struct EncoderOut {
+  std::vector<int> C;              // encoder positions per window: (T-1)/2+1  (mod.rs:244 stride-2 conv)
+  std::vector<int> row0;           // first packed row of each window
+  int rows = 0;                    // sum C
+};
+
+// AudioEncoder::forward (mod.rs:228-260) for a packed batch of ragged windows -> out[rows][d].
+int run_encoder(wb_model* m, hipStream_t st, Workspace& ws, const MelBatch& mb, float* out_dev, EncoderOut* eo);
+
+// TextDecoder::forward (mod.rs:131-157), stateless: tokens_dev [n*L], enc_dev [n*C][d] -> logits_dev [n*L][V].
+int run_decoder_stateless(wb_model* m, hipStream_t st, Workspace& ws, const int32_t* tokens_dev, int n, int L,
+                          const float* enc_dev, int C, float* logits_dev);
+
+// Process-wide mel constant tables for (device, sample_rate).
+int get_mel_tables(int device, double sample_rate, const MelTables** out_dev);
+
+}  // namespace wb

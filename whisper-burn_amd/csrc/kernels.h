@@ -1,0 +1,74 @@
+// Host-callable launchers of the gfx950 kernels (defined in the .hip files).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wb {
+
+// ---- mel frontend (mel.hip) ---------------------------------------------------------
+constexpr int MEL_N_FFT = 400, MEL_HOP = 160, MEL_N_MELS = 80, MEL_N_BINS = 201, MEL_MAX_TAPS = 16;
+
+struct MelTables {            // device-resident constants, built once per (device, sample_rate)
+  float hann[400];            // audio.rs:272-278
+  float2 tw[400];             // W_400^{n2*k1}, index n2*20+k1
+  int tap_start[80];          // sparse Slaney filterbank rows (audio.rs:67-143)
+  int tap_len[80];
+  float tap_w[80 * MEL_MAX_TAPS];
+};
+// Host-side construction (f32 op order of the reference); returns 0 / -1 if a row has > MAX_TAPS taps.
+int mel_tables_build(double sample_rate, MelTables* host_out);
+
+struct MelWindow {            // one window of PCM
+  int64_t pcm_off;            // offset (samples) of the window start in the PCM buffer
+  int32_t n_samples;          // window length in samples (>= 400)
+  int32_t n_frames;           // frames to emit: min(n_samples/160, clip)
+};
+
+// log10(max(mel,1e-10)) for every (window, mel row, frame) + per-window max (pass 1).
+// out[w][m][t] at out + w*win_stride + m*row_stride + t.  gmax[w] must be pre-set to -inf.
+void launch_mel_spectrogram(hipStream_t st, const float* pcm, const MelWindow* wins_dev, int n_windows,
+                            int max_frames, const MelTables* tabs_dev, float* out, int64_t win_stride,
+                            int row_stride, float* gmax_dev);
+// pass 2: max(x, gmax-8), (x+4)/4 ; frames [n_frames, n_frames+pad) := 0   (audio.rs:52-53, transcribe.rs:171-177)
+void launch_mel_finalize(hipStream_t st, const MelWindow* wins_dev, int n_windows, int max_frames_padded,
+                         int pad, float* out, int64_t win_stride, int row_stride, const float* gmax_dev);
+void launch_fill_f32(hipStream_t st, float* p, int64_t n, float v);
+
+// ---- GEMM (gemm.hip): C = act(A*B + bias) (+ residual) (+ aux[aux_idx[m]]) --------------
+enum { ACT_NONE = 0, ACT_GELU = 1 };
+struct RowDesc {             // optional per-row A addressing (implicit-GEMM conv, packed windows)
+  int32_t off;               // element offset of the row start (may be negative: masked k never read)
+  int16_t klo, khi;          // A[m][k] := 0 for k outside [klo, khi)   (ROWS mode)
+                             // CONV1 mode: klo = 1 if first frame of its window, khi = 1 if last
+};
+struct GemmArgs {
+  const float* A = nullptr; int64_t lda = 0;     // ROWS: A[m][k] = A[m*lda + k] (or A[desc[m].off + k])
+  const RowDesc* a_desc = nullptr;               // per-row descriptors (device), or null
+  int conv1_tstride = 0;                         // >0 selects CONV1 gather: A[m][ci*3+kk] = A[off + ci*tstride + kk - 1]
+  const float* B = nullptr; int ldb = 0;         // [K][N] row-major
+  float* C = nullptr; int ldc = 0;
+  const float* bias = nullptr;                   // [N]
+  const float* residual = nullptr; int ldr = 0;  // [M][N], added after activation (may alias C)
+  const float* aux = nullptr; const int32_t* aux_idx = nullptr; int ld_aux = 0;  // + aux[aux_idx[m]][n]
+  float col_scale = 1.f; int col_scale_period = 0, col_scale_width = 0;  // out *= col_scale where (n % period) < width
+  int M = 0, N = 0, K = 0;                       // K % 16 == 0
+  int act = ACT_NONE;
+};
+int launch_gemm_f32(hipStream_t st, const GemmArgs& a);   // exact-f32 MFMA (v_mfma_f32_32x32x2_f32)
+
+// ---- elementwise / normalisation (ops.hip) ----------------------------------------
+// y[m] = LN(x[m]) * g + b, biased variance; eps placement per variant (see whisper_hip.h)
+void launch_layernorm(hipStream_t st, const float* x, float* y, int M, int d, const float* g, const float* b,
+                      float eps, int eps_inside_sqrt);
+// x[r] = E[tok[r]] + pos[r % L]    (mod.rs:141-146)
+void launch_embed(hipStream_t st, const int32_t* tok, int n_rows, int L, int d, const float* E, const float* pos,
+                  float* x);
+
+// ---- attention (attention.hip) ---------------------------------------------------
+struct AttnSeg { int32_t q_row0, q_len, kv_row0, kv_len; };   // one (batch) segment of packed rows
+// O[q][h*64..] = softmax((Q*s)(K*s)^T [+causal]) V per segment and head, head size 64 (mod.rs:493-533)
+void launch_attention_f32(hipStream_t st, const float* Q, int ldq, const float* K, const float* V, int ldkv,
+                          float* O, int ldo, const AttnSeg* segs_dev, int n_segs, int max_q_len, int n_head,
+                          float scale, int causal);
+
+}  // namespace wb

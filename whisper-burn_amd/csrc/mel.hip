@@ -1,0 +1,322 @@
+// K1: fused log-mel frontend for gfx950.
+//
+// Replaces /root/reference/src/audio.rs:34-56 (prep_audio) + :284-367 (stfft: dense DFT by
+// two [201x400]x[400xT] f32 matmuls, ~60 tiny launches and 3 blocking D2H reads per window)
+// with one launch per batch of windows plus a tiny finalize pass:
+//   reflect-padded frame loads (no materialised padded copy, audio.rs:297-306)
+//   -> Hann (audio.rs:272-278) -> 400-point DFT as an LDS-staged 20x20 Cooley-Tukey FFT,
+//   two real frames packed into one complex transform -> |X|^2 for bins 0..200
+//   -> sparse Slaney filterbank (<= 14 taps per row, audio.rs:67-143)
+//   -> relu(x-1e-10)+1e-10, ln(x)/ln10 (helper.rs:8-10, :24-27) -> per-window max (audio.rs:50).
+// Bound: HBM (640 B PCM in + 320 B mel out per frame); ~11 kFLOP per frame of f32 VALU.
+//
+// Geometry: block = 320 threads = 16 pairs x 20 lanes; a pair transforms frames (2p, 2p+1)
+// of the block's 32 consecutive frames.  Lane q of a pair runs one 20-point complex DFT per
+// stage in registers (stage 1: over n1 for n2 = q; stage 2: over n2 for k1 = q).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+
+#include "kernels.h"
+
+namespace wb {
+
+namespace {
+
+constexpr int FPB = 32;          // frames per block
+constexpr int PAIRS = FPB / 2;   // 16
+constexpr int MEL_THREADS = PAIRS * 20;   // 320
+constexpr int FROW = 426;        // LDS floats per frame row: 2*FROW = 852 >= 840 (U) and 852 % 32 == 20
+constexpr int UROW = 21;         // padded row (float2) of the 20x20 intermediate
+constexpr int OT_LD = FPB + 1;   // out tile leading dim
+
+struct cpx { float re, im; };
+
+__device__ __forceinline__ cpx cmul(cpx a, float wr, float wi) {
+  return {a.re * wr - a.im * wi, a.re * wi + a.im * wr};
+}
+
+// 20-point forward DFT (e^{-i...}) in registers: 5 radix-4 butterflies, twiddles W20^{bc},
+// 4 radix-5 butterflies.  n = 5a+b, k = c+4e.
+__device__ __forceinline__ void dft20(cpx (&x)[20]) {
+  constexpr float C1 = 0.30901699437494742f;    // cos(2pi/5)
+  constexpr float C2 = -0.80901699437494742f;   // cos(4pi/5)
+  constexpr float S1 = 0.95105651629515357f;    // sin(2pi/5)
+  constexpr float S2 = 0.58778525229247313f;    // sin(4pi/5)
+  // W20^j = cos(2pi j/20) - i sin(2pi j/20), j = 0..9
+  constexpr float WR[10] = {1.f, 0.95105651629515357f, 0.80901699437494742f, 0.58778525229247313f,
+                            0.30901699437494742f, 0.f, -0.30901699437494742f, -0.58778525229247313f,
+                            -0.80901699437494742f, -0.95105651629515357f};
+  constexpr float WI[10] = {0.f, -0.30901699437494742f, -0.58778525229247313f, -0.80901699437494742f,
+                            -0.95105651629515357f, -1.f, -0.95105651629515357f, -0.80901699437494742f,
+                            -0.58778525229247313f, -0.30901699437494742f};
+  cpx u[5][4];
+#pragma unroll
+  for (int b = 0; b < 5; b++) {
+    cpx x0 = x[b], x1 = x[5 + b], x2 = x[10 + b], x3 = x[15 + b];
+    cpx s02 = {x0.re + x2.re, x0.im + x2.im}, d02 = {x0.re - x2.re, x0.im - x2.im};
+    cpx s13 = {x1.re + x3.re, x1.im + x3.im}, d13 = {x1.re - x3.re, x1.im - x3.im};
+    cpx t0 = {s02.re + s13.re, s02.im + s13.im};
+    cpx t2 = {s02.re - s13.re, s02.im - s13.im};
+    // t1 = d02 - i*d13 ; t3 = d02 + i*d13
+    cpx t1 = {d02.re + d13.im, d02.im - d13.re};
+    cpx t3 = {d02.re - d13.im, d02.im + d13.re};
+    u[b][0] = t0;
+    if (b == 0) {
+      u[b][1] = t1; u[b][2] = t2; u[b][3] = t3;
+    } else {
+      u[b][1] = cmul(t1, WR[b], WI[b]);
+      u[b][2] = cmul(t2, WR[2 * b], WI[2 * b]);
+      // W20^{3b}, 3b up to 12: W20^{j+10} = -W20^j
+      int j = 3 * b;
+      float wr = j < 10 ? WR[j] : -WR[j - 10], wi = j < 10 ? WI[j] : -WI[j - 10];
+      u[b][3] = cmul(t3, wr, wi);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    cpx u0 = u[0][c], u1 = u[1][c], u2 = u[2][c], u3 = u[3][c], u4 = u[4][c];
+    cpx a1 = {u1.re + u4.re, u1.im + u4.im}, a2 = {u2.re + u3.re, u2.im + u3.im};
+    cpx b1 = {u1.re - u4.re, u1.im - u4.im}, b2 = {u2.re - u3.re, u2.im - u3.im};
+    cpx p1 = {u0.re + C1 * a1.re + C2 * a2.re, u0.im + C1 * a1.im + C2 * a2.im};
+    cpx p2 = {u0.re + C2 * a1.re + C1 * a2.re, u0.im + C2 * a1.im + C1 * a2.im};
+    cpx q1 = {S1 * b1.re + S2 * b2.re, S1 * b1.im + S2 * b2.im};
+    cpx q2 = {S2 * b1.re - S1 * b2.re, S2 * b1.im - S1 * b2.im};
+    x[c] = {u0.re + a1.re + a2.re, u0.im + a1.im + a2.im};
+    x[c + 4] = {p1.re + q1.im, p1.im - q1.re};     // p1 - i q1
+    x[c + 16] = {p1.re - q1.im, p1.im + q1.re};    // p1 + i q1
+    x[c + 8] = {p2.re + q2.im, p2.im - q2.re};
+    x[c + 12] = {p2.re - q2.im, p2.im + q2.re};
+  }
+}
+
+__device__ __forceinline__ void atomic_max_float(float* addr, float v) {
+  // monotone int punning: non-negative floats order as ints, negative ones reversed as uints
+  if (v >= 0.f)
+    atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else
+    atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+
+__global__ __launch_bounds__(MEL_THREADS) void mel_spectrogram_kernel(
+    const float* __restrict__ pcm, const MelWindow* __restrict__ wins, const MelTables* __restrict__ tabs,
+    float* __restrict__ out, int64_t win_stride, int row_stride, float* __restrict__ gmax) {
+  __shared__ __attribute__((aligned(16))) float lds[PAIRS * 2 * FROW + MEL_N_MELS * OT_LD];
+  float* otile = lds + PAIRS * 2 * FROW;
+
+  const MelWindow w = wins[blockIdx.y];
+  const int f0 = blockIdx.x * FPB;
+  if (f0 >= w.n_frames) return;
+  const int tid = threadIdx.x;
+  const int N = w.n_samples;
+  const float* x = pcm + w.pcm_off;
+
+  // ---- stage 0: frames -> LDS rows, reflect indexing (audio.rs:297-306), Hann applied ----
+  for (int e = tid; e < FPB * MEL_N_FFT; e += MEL_THREADS) {
+    int fr = e / MEL_N_FFT, n = e - fr * MEL_N_FFT;
+    int j = (f0 + fr) * MEL_HOP + n - MEL_N_FFT / 2;
+    if (j < 0) j = -j;
+    if (j >= N) j = 2 * (N - 1) - j;
+    j = max(0, min(j, N - 1));   // frames past the window's last frame are never emitted
+    lds[fr * FROW + n] = x[j] * tabs->hann[n];
+  }
+  __syncthreads();
+
+  const int p = tid / 20, q = tid - p * 20;
+  float* reg = lds + p * 2 * FROW;   // this pair's private region
+  cpx z[20];
+  // ---- stage 1: 20-point DFT over n1 of z[n1] = xa[20 n1 + q] + i xb[20 n1 + q] ----
+#pragma unroll
+  for (int n1 = 0; n1 < 20; n1++) z[n1] = {reg[20 * n1 + q], reg[FROW + 20 * n1 + q]};
+  dft20(z);
+  __syncthreads();   // everyone has consumed the frame rows; region becomes U[k1][n2]
+  float2* U = reinterpret_cast<float2*>(reg);
+#pragma unroll
+  for (int k1 = 0; k1 < 20; k1++) {
+    float2 t = tabs->tw[q * 20 + k1];
+    cpx v = cmul(z[k1], t.x, t.y);
+    U[k1 * UROW + q] = make_float2(v.re, v.im);
+  }
+  __syncthreads();
+  // ---- stage 2: 20-point DFT over n2 for k1 = q: Z[q + 20 k2] ----
+#pragma unroll
+  for (int n2 = 0; n2 < 20; n2++) {
+    float2 v = U[q * UROW + n2];
+    z[n2] = {v.x, v.y};
+  }
+  dft20(z);
+  __syncthreads();
+  float2* Z = reinterpret_cast<float2*>(reg);   // Z[k], k = 0..399
+#pragma unroll
+  for (int k2 = 0; k2 < 20; k2++) Z[q + 20 * k2] = make_float2(z[k2].re, z[k2].im);
+  __syncthreads();
+  // ---- stage 3: split the packed transform, power spectrum of both frames ----
+  // A[k] = (Z[k] + conj Z[400-k]) / 2,  B[k] = (Z[k] - conj Z[400-k]) / (2i)
+  float pa[11], pb[11];
+#pragma unroll
+  for (int i = 0; i < 11; i++) {
+    int k = q + 20 * i;
+    if (k <= 200) {
+      float2 zk = Z[k], zn = Z[k == 0 ? 0 : 400 - k];
+      float ar = zk.x + zn.x, ai = zk.y - zn.y;
+      float br = zk.y + zn.y, bi = zn.x - zk.x;
+      pa[i] = 0.25f * (ar * ar + ai * ai);
+      pb[i] = 0.25f * (br * br + bi * bi);
+    }
+  }
+  __syncthreads();
+  float* P = reg;   // P[0..207] frame a, P[208..415] frame b
+#pragma unroll
+  for (int i = 0; i < 11; i++) {
+    int k = q + 20 * i;
+    if (k <= 200) { P[k] = pa[i]; P[208 + k] = pb[i]; }
+  }
+  __syncthreads();
+  // ---- stage 4: sparse mel filterbank, log10, local max ----
+  const float LN10 = 2.30258509299404568402f;   // (f32) ln 10, helper.rs:25
+  float lmax = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    int m = q + 20 * r;
+    int s = tabs->tap_start[m], len = tabs->tap_len[m];
+    float sa = 0.f, sb = 0.f;
+    for (int t = 0; t < len; t++) {
+      float wv = tabs->tap_w[m * MEL_MAX_TAPS + t];
+      sa += wv * P[s + t];
+      sb += wv * P[208 + s + t];
+    }
+    // tensor_max_scalar(x, 1e-10) = relu(x - 1e-10) + 1e-10 (helper.rs:8-10); log10 = ln/ln10 (:24-27)
+    float va = logf(fmaxf(sa - 1.0e-10f, 0.f) + 1.0e-10f) / LN10;
+    float vb = logf(fmaxf(sb - 1.0e-10f, 0.f) + 1.0e-10f) / LN10;
+    otile[m * OT_LD + 2 * p] = va;
+    otile[m * OT_LD + 2 * p + 1] = vb;
+    if (f0 + 2 * p < w.n_frames) lmax = fmaxf(lmax, va);
+    if (f0 + 2 * p + 1 < w.n_frames) lmax = fmaxf(lmax, vb);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+  if ((tid & 63) == 0 && lmax > -INFINITY) atomic_max_float(&gmax[blockIdx.y], lmax);
+  __syncthreads();
+  // ---- stage 5: coalesced store of the [80][32] tile ----
+  float* o = out + (int64_t)blockIdx.y * win_stride + f0;
+  const int nf = min(FPB, w.n_frames - f0);
+  for (int e = tid; e < MEL_N_MELS * FPB; e += MEL_THREADS) {
+    int m = e / FPB, f = e - m * FPB;
+    if (f < nf) o[(int64_t)m * row_stride + f] = otile[m * OT_LD + f];
+  }
+}
+
+__global__ void mel_finalize_kernel(const MelWindow* __restrict__ wins, int max_frames_padded, int pad,
+                                    float* __restrict__ out, int64_t win_stride, int row_stride,
+                                    const float* __restrict__ gmax) {
+  const int w = blockIdx.z, m = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= max_frames_padded) return;
+  const int nf = wins[w].n_frames;
+  float* p = out + (int64_t)w * win_stride + (int64_t)m * row_stride + t;
+  if (t < nf) {
+    // audio.rs:50-53: max computed as f64 from the f32 max, (max - 8.0) handed back as f32
+    const float m8 = (float)((double)gmax[w] - 8.0);
+    float v = fmaxf(*p - m8, 0.f) + m8;
+    *p = (v + 4.0f) / 4.0f;
+  } else if (t < nf + pad) {
+    *p = 0.f;   // transcribe.rs:171-177: zero frames in normalised log-mel space
+  }
+}
+
+__global__ void fill_f32_kernel(float* p, int64_t n, float v) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+}  // namespace
+
+void launch_mel_spectrogram(hipStream_t st, const float* pcm, const MelWindow* wins_dev, int n_windows,
+                            int max_frames, const MelTables* tabs_dev, float* out, int64_t win_stride,
+                            int row_stride, float* gmax_dev) {
+  dim3 grid((max_frames + FPB - 1) / FPB, n_windows);
+  hipLaunchKernelGGL(mel_spectrogram_kernel, grid, dim3(MEL_THREADS), 0, st, pcm, wins_dev, tabs_dev, out,
+                     win_stride, row_stride, gmax_dev);
+}
+
+void launch_mel_finalize(hipStream_t st, const MelWindow* wins_dev, int n_windows, int max_frames_padded,
+                         int pad, float* out, int64_t win_stride, int row_stride, const float* gmax_dev) {
+  dim3 grid((max_frames_padded + 255) / 256, MEL_N_MELS, n_windows);
+  hipLaunchKernelGGL(mel_finalize_kernel, grid, dim3(256), 0, st, wins_dev, max_frames_padded, pad, out,
+                     win_stride, row_stride, gmax_dev);
+}
+
+void launch_fill_f32(hipStream_t st, float* p, int64_t n, float v) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, v);
+}
+
+// ---- host: constant tables ------------------------------------------------------------
+// The filterbank follows the f32 op order of audio.rs:67-143 / :178-266 (scalars are cast to
+// f32 before each tensor op, as burn-tch does), so it matches what the reference builds on
+// device for every window -- here once per process.
+int mel_tables_build(double sample_rate, MelTables* t) {
+  memset(t, 0, sizeof(*t));
+  // Hann: sin(n * f32(pi/400))^2 in f32 (audio.rs:272-278)
+  const float step = (float)(M_PI / 400.0);
+  for (int n = 0; n < 400; n++) {
+    float s = sinf((float)n * step);
+    t->hann[n] = s * s;
+  }
+  for (int n2 = 0; n2 < 20; n2++)
+    for (int k1 = 0; k1 < 20; k1++) {
+      double a = -2.0 * M_PI * (double)(n2 * k1) / 400.0;
+      t->tw[n2 * 20 + k1] = make_float2((float)cos(a), (float)sin(a));
+    }
+  // mel_frequencies_device (audio.rs:178-196) with hz_to_mel (:198-230) in f64 on the host
+  auto hz_to_mel = [](double f) {
+    const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp;
+    const double logstep = log(6.4) / 27.0;
+    return f >= min_log_hz ? min_log_mel + log(f / min_log_hz) / logstep : f / f_sp;
+  };
+  const int n_mels = 80, n_f = n_mels + 2;
+  const double fmin = 0.0, fmax = sample_rate * 0.5;
+  const double min_mel = hz_to_mel(fmin), max_mel = hz_to_mel(fmax);
+  const float mstep = (float)((max_mel - min_mel) / (double)(n_f - 1)), mmin = (float)min_mel;
+  const float f_sp = (float)(200.0 / 3.0), min_log_mel = (float)(1000.0 / (200.0 / 3.0));
+  const float logstep = (float)(log(6.4) / 27.0), min_log_hz = 1000.0f;
+  float mel_f[82];
+  for (int i = 0; i < n_f; i++) {
+    float mel = (float)i * mstep + mmin;
+    // mel_to_hz_tensor (audio.rs:232-266): log_t * (exp((mel - mlm) * logstep) * 1000) + (1 - log_t) * (mel * f_sp + 0)
+    float log_t = mel >= min_log_mel ? 1.0f : 0.0f;
+    float a = log_t * (expf((mel - min_log_mel) * logstep) * min_log_hz);
+    float b = (-log_t + 1.0f) * (mel * f_sp + 0.0f);
+    mel_f[i] = a + b;
+  }
+  const float fstep = (float)(sample_rate / 400.0);
+  float W[80][201];
+  for (int i = 0; i < n_mels; i++) {
+    float fd0 = mel_f[i + 1] - mel_f[i], fd1 = mel_f[i + 2] - mel_f[i + 1];
+    float enorm = powf(mel_f[i + 2] - mel_f[i], -1.0f) * 2.0f;
+    for (int j = 0; j < 201; j++) {
+      float ff = (float)j * fstep;
+      float lower = -(mel_f[i] - ff) / fd0;
+      float upper = (mel_f[i + 2] - ff) / fd1;
+      // tensor_min(lower, upper) = -(relu(-lower - (-upper)) + (-upper))  (helper.rs:16-22)
+      float nx = -lower, nm = -upper;
+      float tmin = -(fmaxf(nx - nm, 0.f) + nm);
+      W[i][j] = fmaxf(tmin, 0.f) * enorm;
+    }
+  }
+  for (int i = 0; i < n_mels; i++) {
+    int s = -1, e = -1;
+    for (int j = 0; j < 201; j++)
+      if (W[i][j] != 0.f) { if (s < 0) s = j; e = j; }
+    if (s < 0) { s = 0; e = -1; }
+    int len = e - s + 1;
+    if (len > MEL_MAX_TAPS) return -1;
+    t->tap_start[i] = s;
+    t->tap_len[i] = len;
+    for (int k = 0; k < len; k++) t->tap_w[i * MEL_MAX_TAPS + k] = W[i][s + k];
+  }
+  return 0;
+}
+
+}  // namespace wb

@@ -1,0 +1,131 @@
+// Internal declarations shared by the host side of libwhisper_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/whisper_hip.h"
+
+namespace wb {
+
+// ---- errors -------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+#define WB_HIP(expr)                                                                   \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess) {                                                            \
+      wb::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,   \
+                    __LINE__);                                                         \
+      return (_e == hipErrorOutOfMemory) ? WB_ERR_OOM : WB_ERR_HIP;                    \
+    }                                                                                  \
+  } while (0)
+
+#define WB_TRY(expr)              \
+  do {                            \
+    int _s = (expr);              \
+    if (_s != WB_OK) return _s;   \
+  } while (0)
+
+#define WB_REQUIRE(cond, status, ...) \
+  do {                                \
+    if (!(cond)) {                    \
+      wb::set_error(__VA_ARGS__);     \
+      return (status);                \
+    }                                 \
+  } while (0)
+
+// ---- device memory ------------------------------------------------------------
+// Owning device allocation; freed with the owner (model / session / scratch arena).
+struct DevMem {
+  void* p = nullptr;
+  size_t bytes = 0;
+  DevMem() = default;
+  DevMem(const DevMem&) = delete;
+  DevMem& operator=(const DevMem&) = delete;
+  DevMem(DevMem&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+  DevMem& operator=(DevMem&& o) noexcept {
+    if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+    return *this;
+  }
+  ~DevMem() { release(); }
+  int alloc(size_t n);           // returns wb_status
+  int ensure(size_t n);          // grow-only
+  void release();
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// ---- host tensors (loader input) ------------------------------------------------
+struct HostTensor {
+  std::vector<int64_t> shape;
+  const float* data = nullptr;          // borrowed or -> owned
+  std::vector<float> owned;
+  int64_t numel() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
+};
+using TensorMap = std::unordered_map<std::string, HostTensor>;
+
+int read_dump_dir(const char* dir, TensorMap* out);   // model_load.cpp
+}  // namespace wb
+struct wb_model;
+namespace wb {
+int build_model(TensorMap& tm, int device, int compute_dtype, wb_model** out);
+
+// ---- model ----------------------------------------------------------------------
+struct LayerNormW { float* g = nullptr; float* b = nullptr; float eps = 1e-5f; };
+struct LinearW { float* w = nullptr; float* b = nullptr; int k = 0, n = 0; };  // w: [k][n] row-major
+
+struct EncBlockW {
+  LayerNormW ln1, ln2;
+  LinearW qkv;   // [d][3d], bias [3d] (key part zero: mod.rs:402-404)
+  LinearW out;   // [d][d]
+  LinearW mlp1;  // [d][4d]
+  LinearW mlp2;  // [4d][d]
+};
+struct DecBlockW {
+  LayerNormW ln1, ln2, ln3;
+  LinearW qkv, out;        // masked self-attention
+  LinearW cq, cout;        // cross-attention query / out
+  LinearW mlp1, mlp2;
+};
+
+// Grow-only device workspace shared by the forward passes of one owner (model scratch or session).
+struct Workspace {
+  DevMem x1, x, h, qkv, att, hm, desc1, desc2, auxidx, segs, misc;
+};
+
+}  // namespace wb
+
+struct wb_model {
+  wb_dims dims{};
+  int device = 0;
+  int compute_dtype = WB_F32;
+  int ln_eps_inside_sqrt = 0;
+  // all weights live in one arena allocation
+  wb::DevMem arena;
+  // encoder
+  wb::LinearW conv1;   // repacked [240 = ci*3+kk][d]
+  wb::LinearW conv2;   // repacked [3d = kk*d+ci][d]
+  float* enc_pos = nullptr;   // [n_audio_ctx][d]
+  std::vector<wb::EncBlockW> enc;
+  wb::LayerNormW ln_post;
+  // decoder
+  float* tok_emb = nullptr;    // E   [V][d]
+  float* tok_emb_t = nullptr;  // E^T [d][vocab_ld]  (logits GEMM/GEMV streams V contiguously)
+  int vocab_ld = 0;            // V rounded up to 64
+  float* dec_pos = nullptr;    // [n_text_ctx][d]
+  std::vector<wb::DecBlockW> dec;
+  wb::LinearW ckv_all;         // cross K|V projections of ALL layers: [d][n_layer*2d]
+  wb::LayerNormW ln_dec;
+  float qk_scale = 0.f;        // (d/H)^-0.25 as f32, mod.rs:503
+  hipStream_t stream = nullptr;
+  // scratch of the stateless entry points (grow-only; serialised by a process-wide lock in api.cpp)
+  wb::Workspace ws;
+  wb::DevMem io_a, io_b, io_c;
+};

@@ -1,0 +1,227 @@
+"""Host-side mirror of the reference interface for the hot path, over the C ABI.
+
+Same names, argument meaning and error behaviour as the reference seams
+(/root/reference/src/audio.rs:34 prep_audio, src/model/mod.rs:47-71 Whisper::{forward,
+forward_encoder, forward_decoder, encoder_ctx_size, decoder_ctx_size},
+src/transcribe.rs:23-29 waveform_to_text), so the parity tests read like tests of the
+reference would.  Shape-contract violations the reference `assert!`s on raise
+`ShapeError` (a WbError with status WB_ERR_SHAPE).  All arithmetic happens in
+libwhisper_hip.so; this file only marshals NumPy arrays.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import WbDecodeParams, WbDims, WbError, check
+from .tokens import SpecialTokens
+
+WB_F32, WB_BF16 = 0, 1
+WB_ERR_SHAPE = -2
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _fp(a: np.ndarray):
+    return a.ctypes.data_as(_lib.c_float_p)
+
+
+def _ip(a: np.ndarray):
+    return a.ctypes.data_as(_lib.c_int32_p)
+
+
+def max_waveform_samples(n_frame_max: int) -> int:
+    """audio.rs:12-17."""
+    return int(_lib.load().wb_max_waveform_samples(int(n_frame_max)))
+
+
+def prep_audio(waveform, sample_rate: float = 16000.0, device: int = 0) -> np.ndarray:
+    """audio.rs:34: waveform [n_batch, n_samples] -> log-mel [n_batch, 80, n_samples // 160]."""
+    lib = _lib.load()
+    w = _f32(waveform)
+    if w.ndim == 1:
+        w = w[None]
+    out = []
+    for row in w:
+        n = row.shape[0]
+        mel = np.empty((80, max(n // 160, 0)), dtype=np.float32)
+        nf = C.c_int64(0)
+        check(lib.wb_prep_audio(device, _fp(row), n, float(sample_rate), _fp(mel), C.byref(nf)))
+        out.append(mel)
+    return np.stack(out)
+
+
+class Whisper:
+    """mod.rs:41-71 `Whisper<B>` on one MI355X."""
+
+    def __init__(self, handle, device: int):
+        self._h = handle
+        self.device = device
+        d = WbDims()
+        check(_lib.load().wb_model_dims(self._h, C.byref(d)))
+        self.dims = {k: int(getattr(d, k)) for k, _ in WbDims._fields_}
+
+    # -- construction -----------------------------------------------------------------
+    @staticmethod
+    def load_dump_dir(path: str, device: int = 0, compute_dtype: int = WB_F32) -> "Whisper":
+        """load_whisper(path), load.rs:295-310."""
+        h = C.c_void_p()
+        check(_lib.load().wb_model_load_dump_dir(path.encode(), device, compute_dtype, C.byref(h)))
+        return Whisper(h, device)
+
+    @staticmethod
+    def from_tensors(weights: Dict[str, np.ndarray], device: int = 0, compute_dtype: int = WB_F32) -> "Whisper":
+        names = list(weights)
+        arrs = [_f32(weights[k]) for k in names]
+        n = len(names)
+        c_names = (C.c_char_p * n)(*[k.encode() for k in names])
+        c_data = (_lib.c_float_p * n)(*[_fp(a) for a in arrs])
+        shp = [np.asarray(a.shape if a.ndim else (1,), dtype=np.int64) for a in arrs]
+        c_shapes = (_lib.c_int64_p * n)(*[s.ctypes.data_as(_lib.c_int64_p) for s in shp])
+        c_ranks = (C.c_int32 * n)(*[len(s) for s in shp])
+        h = C.c_void_p()
+        check(_lib.load().wb_model_load_tensors(c_names, c_data, c_shapes, c_ranks, n, device, compute_dtype,
+                                                C.byref(h)))
+        return Whisper(h, device)
+
+    def close(self):
+        if self._h:
+            _lib.load().wb_model_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_layernorm_variant(self, eps_inside_sqrt: bool):
+        check(_lib.load().wb_model_set_ln_variant(self._h, int(eps_inside_sqrt)))
+
+    # -- mod.rs:47-71 -------------------------------------------------------------------
+    def encoder_ctx_size(self) -> int:
+        return self.dims["n_audio_ctx"]
+
+    def decoder_ctx_size(self) -> int:
+        return self.dims["n_text_ctx"]
+
+    def forward_encoder(self, mel) -> np.ndarray:
+        """[B, 80, T] -> [B, C, d]."""
+        mel = _f32(mel)
+        B, n_mels, T = mel.shape
+        if n_mels != self.dims["n_mels"]:     # mod.rs:231-235
+            raise WbError(WB_ERR_SHAPE, f"Audio mel spectrum size must be {self.dims['n_mels']}.")
+        out = np.empty((B, (T - 1) // 2 + 1 if T > 0 else 0, self.dims["n_audio_state"]), dtype=np.float32)
+        check(_lib.load().wb_forward_encoder(self._h, _fp(mel), B, T, _fp(out)))
+        return out
+
+    def forward_decoder(self, tokens, encoder_output) -> np.ndarray:
+        """tokens [n, L] int, encoder_output [n, C, d] -> logits [n, L, V]."""
+        tokens = _i32(tokens)
+        enc = _f32(encoder_output)
+        n, L = tokens.shape
+        assert enc.shape[0] == n and enc.shape[2] == self.dims["n_text_state"]
+        logits = np.empty((n, L, self.dims["n_vocab"]), dtype=np.float32)
+        check(_lib.load().wb_forward_decoder(self._h, _ip(tokens), n, L, _fp(enc), enc.shape[1], _fp(logits)))
+        return logits
+
+    def forward(self, mel, tokens) -> np.ndarray:
+        mel = _f32(mel)
+        tokens = _i32(tokens)
+        B, _, T = mel.shape
+        logits = np.empty((B, tokens.shape[1], self.dims["n_vocab"]), dtype=np.float32)
+        check(_lib.load().wb_forward(self._h, _fp(mel), B, T, _ip(tokens), tokens.shape[1], _fp(logits)))
+        return logits
+
+
+def decode_params(st: SpecialTokens, beam_size: int = 5, max_depth: int = 100, **kw) -> WbDecodeParams:
+    """The constants transcribe.rs hard-codes (beam 5 x depth 100, padding 10, 3 s overlap, (40, 3) stitch)."""
+    p = WbDecodeParams()
+    _lib.load().wb_decode_params_default(C.byref(p))
+    p.beam_size, p.max_depth = beam_size, max_depth
+    p.tok_start_of_transcript, p.tok_language = st.start_of_transcript, st.language
+    p.tok_transcribe, p.tok_no_timestamps, p.tok_end_of_text = st.transcribe, st.no_timestamps, st.end_of_text
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def window_extents(n_samples: int, sample_rate: int, window_len: int, overlap_seconds: int = 3):
+    """transcribe.rs:120-128."""
+    lib = _lib.load()
+    n = int(lib.wb_window_extents(n_samples, sample_rate, window_len, overlap_seconds, None, None, 0))
+    starts = np.zeros(n, dtype=np.int64)
+    lens = np.zeros(n, dtype=np.int64)
+    lib.wb_window_extents(n_samples, sample_rate, window_len, overlap_seconds,
+                          starts.ctypes.data_as(_lib.c_int64_p), lens.ctypes.data_as(_lib.c_int64_p), n)
+    return starts, lens
+
+
+def find_chunk_overlap(prev_tokens: Sequence[int], curr_tokens: Sequence[int], max_n_offsets: int,
+                       min_n_overlaps: int) -> Optional[Tuple[int, int]]:
+    """transcribe.rs:76-110."""
+    p, c = _i32(list(prev_tokens)), _i32(list(curr_tokens))
+    pi, ci = C.c_int64(0), C.c_int64(0)
+    r = _lib.load().wb_find_chunk_overlap(_ip(p), len(p), _ip(c), len(c), max_n_offsets, min_n_overlaps,
+                                          C.byref(pi), C.byref(ci))
+    return (int(pi.value), int(ci.value)) if r == 1 else None
+
+
+def stitch_windows(win_tokens: np.ndarray, win_lens: np.ndarray, max_n_offsets: int = 40,
+                   min_n_overlaps: int = 3) -> List[int]:
+    """Fold transcribe.rs:56-63 over per-window token rows in window order."""
+    wt, wl = _i32(win_tokens), _i32(win_lens)
+    cap = int(wl.sum()) + 1
+    out = np.zeros(cap, dtype=np.int32)
+    n_out = C.c_int64(0)
+    check(_lib.load().wb_stitch_windows(_ip(wt), wt.shape[1] if wt.ndim == 2 else 0, _ip(wl), len(wl),
+                                        max_n_offsets, min_n_overlaps, _ip(out), cap, C.byref(n_out)))
+    return out[:n_out.value].tolist()
+
+
+def waveform_to_tokens(whisper: Whisper, st: SpecialTokens, waveform, sample_rate: int = 16000,
+                       beam_size: int = 5, max_depth: int = 100, win_begin: int = 0, win_end: int = -1,
+                       params: Optional[WbDecodeParams] = None):
+    """waveform_to_text (transcribe.rs:23-74) without the tokenizer.
+
+    Returns (stitched token ids of the local windows, per-window token lists).  [win_begin, win_end)
+    selects the windows this process decodes (multi-GPU sharding); default all."""
+    lib = _lib.load()
+    wav = _f32(waveform).reshape(-1)
+    p = params or decode_params(st, beam_size, max_depth)
+    wlen = max_waveform_samples(whisper.encoder_ctx_size() - p.padding)
+    starts, _ = window_extents(len(wav), sample_rate, wlen, p.overlap_seconds)
+    n_win = len(starts)
+    if win_end < 0:
+        win_end = n_win
+    n_local = max(0, win_end - win_begin)
+    stride = 4 + p.max_depth + 4
+    win_tokens = np.zeros((max(n_local, 1), stride), dtype=np.int32)
+    win_lens = np.zeros(max(n_local, 1), dtype=np.int32)
+    cap = max(n_local, 1) * stride
+    stitched = np.zeros(cap, dtype=np.int32)
+    n_st = C.c_int64(0)
+    mask = np.ascontiguousarray(st.is_special, dtype=np.uint8)
+    check(lib.wb_waveform_to_tokens(whisper._h, _fp(wav), len(wav), sample_rate, C.byref(p),
+                                    mask.ctypes.data_as(_lib.c_uint8_p), win_begin, win_end, _ip(win_tokens),
+                                    stride, _ip(win_lens), _ip(stitched), cap, C.byref(n_st)))
+    per_window = [win_tokens[i, :win_lens[i]].tolist() for i in range(n_local)]
+    return stitched[:n_st.value].tolist(), per_window
+
+
+def waveform_to_text(whisper: Whisper, bpe, lang, waveform, sample_rate: int = 16000):
+    """transcribe.rs:23-29 shape: returns (text, tokens).  `bpe` must offer
+    `special_tokens(lang) -> SpecialTokens` and `decode(tokens, skip_special) -> str`
+    (the tokenizer stays outside the engine; none ships in this environment)."""
+    st = bpe.special_tokens(lang)
+    tokens, _ = waveform_to_tokens(whisper, st, waveform, sample_rate)
+    return bpe.decode(tokens, True), tokens
