@@ -111,7 +111,7 @@ int wb_prep_audio(int device, const float* pcm, int64_t n, double sample_rate, f
   WB_TRY(d_out.alloc((size_t)80 * T * 4));
   WB_TRY(d_win.alloc(sizeof(MelWindow)));
   WB_TRY(d_max.alloc(4));
-  MelWindow w{0, (int32_t)n, T};
+  MelWindow w{0, (int32_t)n, T, T, 0};
   hipStream_t st = nullptr;
   WB_HIP(hipMemcpyAsync(d_pcm.p, pcm, (size_t)n * 4, hipMemcpyHostToDevice, st));
   WB_HIP(hipMemcpyAsync(d_win.p, &w, sizeof(w), hipMemcpyHostToDevice, st));

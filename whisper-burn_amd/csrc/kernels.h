@@ -21,7 +21,9 @@ int mel_tables_build(double sample_rate, MelTables* host_out);
 struct MelWindow {            // one window of PCM
   int64_t pcm_off;            // offset (samples) of the window start in the PCM buffer
   int32_t n_samples;          // window length in samples (>= 400)
-  int32_t n_frames;           // frames to emit: min(n_samples/160, clip)
+  int32_t n_frames;           // n_samples / 160: frames that enter the max (audio.rs:41-42, :50)
+  int32_t n_emit;             // frames written: min(n_frames, clip)  (transcribe.rs:171-177 clips AFTER prep_audio)
+  int32_t reserved;
 };
 
 // log10(max(mel,1e-10)) for every (window, mel row, frame) + per-window max (pass 1).

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(MEL_THREADS) void mel_spectrogram_kernel(
   __syncthreads();
   // ---- stage 5: coalesced store of the [80][32] tile ----
   float* o = out + (int64_t)blockIdx.y * win_stride + f0;
-  const int nf = min(FPB, w.n_frames - f0);
+  const int nf = min(FPB, w.n_emit - f0);
   for (int e = tid; e < MEL_N_MELS * FPB; e += MEL_THREADS) {
     int m = e / FPB, f = e - m * FPB;
     if (f < nf) o[(int64_t)m * row_stride + f] = otile[m * OT_LD + f];
@@ -213,7 +213,7 @@ __global__ void mel_finalize_kernel(const MelWindow* __restrict__ wins, int max_
   const int w = blockIdx.z, m = blockIdx.y;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= max_frames_padded) return;
-  const int nf = wins[w].n_frames;
+  const int nf = wins[w].n_emit;
   float* p = out + (int64_t)w * win_stride + (int64_t)m * row_stride + t;
   if (t < nf) {
     // audio.rs:50-53: max computed as f64 from the f32 max, (max - 8.0) handed back as f32

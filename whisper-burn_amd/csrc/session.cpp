@@ -1,17 +1,430 @@
-// placeholder: stateful session entry points (filled in next)
+// Stateful session: one mel + encoder + cross-K/V pass per batch of windows, then KV-cached decode
+// steps -- the result-equivalent fast path behind /root/reference/src/transcribe.rs:148-312.
 #include "session.h"
+
+#include <cstring>
+#include <mutex>
+
 using namespace wb;
-extern "C" {
-#define NOT_YET(name) do { wb::set_error(name ": not implemented yet"); return WB_ERR_STATE; } while (0)
-int wb_session_begin(wb_model*, const float*, int64_t, const int64_t*, const int64_t*, int, int, int, wb_session**) { NOT_YET("wb_session_begin"); }
-int wb_session_begin_mel(wb_model*, const float*, const int32_t*, int, int, int, wb_session**) { NOT_YET("wb_session_begin_mel"); }
-int wb_session_set_special_mask(wb_session*, const uint8_t*) { NOT_YET("wb_session_set_special_mask"); }
-int wb_session_step(wb_session*, const int32_t*, const int32_t*, const int32_t*, int, int, int, int32_t*, float*) { NOT_YET("wb_session_step"); }
-int wb_session_last_logprobs(wb_session*, int, float*) { NOT_YET("wb_session_last_logprobs"); }
-int wb_session_encoder_output(wb_session*, int, float*, int32_t*) { NOT_YET("wb_session_encoder_output"); }
-void wb_session_free(wb_session*) {}
-int wb_session_decode(wb_session*, const wb_decode_params*, int32_t*, int32_t, int32_t*) { NOT_YET("wb_session_decode"); }
-int wb_waveform_to_tokens(wb_model*, const float*, int64_t, int, const wb_decode_params*, const uint8_t*, int, int, int32_t*, int32_t, int32_t*, int32_t*, int64_t, int64_t*) { NOT_YET("wb_waveform_to_tokens"); }
-int wb_profile_enable(int) { return WB_OK; }
-int wb_profile_read(double* o, int) { if (o) for (int i = 0; i < 8; i++) o[i] = 0; return WB_OK; }
+
+namespace wb {
+
+Profile& profile() {
+  static Profile p;
+  return p;
 }
+
+ScopedTimer::ScopedTimer(hipStream_t s, int slot_) : st(s), slot(slot_), on(profile().on) {
+  if (!on) return;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+  (void)hipEventRecord(a, st);
+}
+void ScopedTimer::stop() {
+  if (on) (void)hipEventRecord(b, st);
+}
+void ScopedTimer::collect() {
+  if (!on) return;
+  float ms = 0.f;
+  if (hipEventSynchronize(b) == hipSuccess && hipEventElapsedTime(&ms, a, b) == hipSuccess) profile().ms[slot] += ms;
+}
+ScopedTimer::~ScopedTimer() {
+  if (a) (void)hipEventDestroy(a);
+  if (b) (void)hipEventDestroy(b);
+}
+
+// sessions are recycled per model so that a transcription loop does not pay hipMalloc per batch
+static std::mutex g_pool_mu;
+static std::unordered_map<wb_model*, std::vector<wb_session*>> g_pool;
+
+int session_create(wb_model* m, int n_windows, int max_beams, int padding, wb_session** out) {
+  WB_REQUIRE(m && out, WB_ERR_ARG, "session: null argument");
+  WB_REQUIRE(n_windows >= 1, WB_ERR_ARG, "session: n_windows must be >= 1");
+  WB_REQUIRE(max_beams >= 1 && max_beams <= MAX_BEAMS, WB_ERR_ARG, "session: max_beams must be in [1, %d]", MAX_BEAMS);
+  WB_REQUIRE(padding >= 0 && padding < m->dims.n_audio_ctx, WB_ERR_ARG, "session: bad padding %d", padding);
+  WB_HIP(hipSetDevice(m->device));
+  wb_session* s = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto& v = g_pool[m];
+    if (!v.empty()) { s = v.back(); v.pop_back(); }
+  }
+  if (!s) {
+    s = new wb_session();
+    s->m = m;
+    hipError_t e = hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete s; set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); return WB_ERR_HIP; }
+  }
+  s->W = n_windows; s->max_beams = max_beams; s->S = n_windows * max_beams; s->padding = padding;
+  s->T.assign(n_windows, 0); s->C.clear(); s->row0.clear();
+  s->prev_len.clear(); s->prev_win.clear(); s->prev_n = 0; s->step = 0;
+  s->has_mask = false; s->decode_ready = false; s->last_had_logits = 0;
+  *out = s;
+  return WB_OK;
+}
+
+static int session_finish_encode(wb_session* s, const MelBatch& mb) {
+  wb_model* m = s->m;
+  const int d = m->dims.n_audio_state, NL = m->dims.n_text_layer;
+  int rows = 0;
+  for (int t : mb.T) rows += (t - 1) / 2 + 1;
+  WB_TRY(s->enc_out.ensure((size_t)rows * d * 4));
+  EncoderOut eo;
+  {
+    ScopedTimer tm(s->st, 1);
+    WB_TRY(run_encoder(m, s->st, s->ws, mb, s->enc_out.as<float>(), &eo));
+    tm.stop();
+    if (tm.on) { WB_HIP(hipStreamSynchronize(s->st)); tm.collect(); }
+  }
+  s->C = eo.C; s->row0 = eo.row0; s->enc_rows = eo.rows;
+  s->maxC = 0;
+  for (int c : s->C) s->maxC = std::max(s->maxC, c);
+  s->n_chunks = (s->maxC + cross_attn_chunk() - 1) / cross_attn_chunk();
+  // cross-attention K|V of every decoder layer, once per window (mod.rs:484-485 does it per layer/beam/step)
+  const int ldkv = NL * 2 * d;
+  WB_TRY(s->ckv.ensure((size_t)rows * ldkv * 4));
+  {
+    ScopedTimer tm(s->st, 2);
+    GemmArgs g;
+    g.A = s->enc_out.as<float>(); g.lda = d; g.B = m->ckv_all.w; g.ldb = ldkv; g.C = s->ckv.as<float>(); g.ldc = ldkv;
+    g.bias = m->ckv_all.b; g.M = rows; g.N = ldkv; g.K = d;
+    g.col_scale = m->qk_scale; g.col_scale_period = 2 * d; g.col_scale_width = d;   // K * s (mod.rs:510-514)
+    WB_REQUIRE(launch_gemm_f32(s->st, g) == 0, WB_ERR_SHAPE, "cross-KV gemm: unsupported shape");
+    tm.stop();
+    if (tm.on) { WB_HIP(hipStreamSynchronize(s->st)); tm.collect(); }
+  }
+  std::vector<int> meta(2 * s->W);
+  for (int w = 0; w < s->W; w++) { meta[w] = s->row0[w]; meta[s->W + w] = s->C[w]; }
+  WB_TRY(s->win_meta.ensure(meta.size() * 4));
+  WB_HIP(hipMemcpyAsync(s->win_meta.p, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, s->st));
+  WB_HIP(hipStreamSynchronize(s->st));
+  return WB_OK;
+}
+
+int session_encode_pcm(wb_session* s, const float* pcm, int64_t n_pcm, const int64_t* starts, const int64_t* lens) {
+  wb_model* m = s->m;
+  const int clip = m->dims.n_audio_ctx - s->padding;   // transcribe.rs:171-177
+  int64_t lo = n_pcm, hi = 0;
+  for (int w = 0; w < s->W; w++) {
+    WB_REQUIRE(starts[w] >= 0 && lens[w] >= 0 && starts[w] + lens[w] <= n_pcm, WB_ERR_ARG,
+               "window %d [%lld, +%lld) outside the waveform (%lld samples)", w, (long long)starts[w],
+               (long long)lens[w], (long long)n_pcm);
+    WB_REQUIRE(lens[w] >= MEL_N_FFT, WB_ERR_SHAPE, "window %d has %lld samples < n_fft = 400 (audio.rs:292)", w,
+               (long long)lens[w]);
+    WB_REQUIRE(lens[w] < ((int64_t)1 << 30), WB_ERR_SHAPE, "window %d too long", w);
+    lo = std::min(lo, starts[w]); hi = std::max(hi, starts[w] + lens[w]);
+  }
+  std::vector<MelWindow> wins(s->W);
+  int maxF = 0, maxT = 0;
+  for (int w = 0; w < s->W; w++) {
+    const int nf = (int)(lens[w] / MEL_HOP);
+    wins[w] = MelWindow{starts[w] - lo, (int32_t)lens[w], nf, std::min(nf, clip), 0};
+    s->T[w] = wins[w].n_emit + s->padding;
+    maxF = std::max(maxF, nf); maxT = std::max(maxT, s->T[w]);
+  }
+  const int Ts = (maxT + 3) & ~3;
+  const MelTables* tabs;
+  WB_TRY(get_mel_tables(m->device, s->sample_rate, &tabs));
+  WB_TRY(s->pcm.ensure((size_t)(hi - lo) * 4));
+  WB_TRY(s->wins.ensure(wins.size() * sizeof(MelWindow)));
+  WB_TRY(s->gmax.ensure((size_t)s->W * 4));
+  WB_TRY(s->mel.ensure((size_t)s->W * 80 * Ts * 4));
+  WB_HIP(hipMemcpyAsync(s->pcm.p, pcm + lo, (size_t)(hi - lo) * 4, hipMemcpyHostToDevice, s->st));
+  WB_HIP(hipMemcpyAsync(s->wins.p, wins.data(), wins.size() * sizeof(MelWindow), hipMemcpyHostToDevice, s->st));
+  WB_HIP(hipStreamSynchronize(s->st));   // `wins` is a stack vector
+  {
+    ScopedTimer tm(s->st, 0);
+    launch_fill_f32(s->st, s->gmax.as<float>(), s->W, -INFINITY);
+    launch_mel_spectrogram(s->st, s->pcm.as<float>(), s->wins.as<MelWindow>(), s->W, maxF, tabs, s->mel.as<float>(),
+                           (int64_t)80 * Ts, Ts, s->gmax.as<float>());
+    launch_mel_finalize(s->st, s->wins.as<MelWindow>(), s->W, Ts, s->padding, s->mel.as<float>(), (int64_t)80 * Ts,
+                        Ts, s->gmax.as<float>());
+    tm.stop();
+    if (tm.on) { WB_HIP(hipStreamSynchronize(s->st)); tm.collect(); profile().ms[5] += 1; }
+  }
+  WB_HIP(hipGetLastError());
+  MelBatch mb;
+  mb.mel = s->mel.as<float>(); mb.win_stride = (int64_t)80 * Ts; mb.row_stride = Ts; mb.T = s->T;
+  return session_finish_encode(s, mb);
+}
+
+int session_reserve(wb_session* s, int max_len) {
+  wb_model* m = s->m;
+  const wb_dims& D = m->dims;
+  const int d = D.n_text_state, NL = D.n_text_layer, V = D.n_vocab, S = s->S;
+  max_len = std::max(8, std::min(max_len, std::min(D.n_text_ctx, 448)));
+  s->Lmax = max_len;
+  const size_t pool = (size_t)max_len * S;
+  WB_TRY(s->kc.ensure((size_t)NL * pool * d * 4));
+  WB_TRY(s->vc.ensure((size_t)NL * pool * d * 4));
+  WB_TRY(s->tabs.ensure((size_t)2 * S * max_len * 4));
+  s->lay = make_step_layout(S, s->W);
+  WB_TRY(s->state.ensure((size_t)s->lay.total * 4));
+  if (s->state_host) { (void)hipHostFree(s->state_host); s->state_host = nullptr; }
+  if (s->topk_id_host) { (void)hipHostFree(s->topk_id_host); s->topk_id_host = nullptr; }
+  if (s->topk_lp_host) { (void)hipHostFree(s->topk_lp_host); s->topk_lp_host = nullptr; }
+  WB_HIP(hipHostMalloc((void**)&s->state_host, (size_t)s->lay.total * 4, hipHostMallocDefault));
+  WB_HIP(hipHostMalloc((void**)&s->topk_id_host, (size_t)S * TOPK_MAX * 4, hipHostMallocDefault));
+  WB_HIP(hipHostMalloc((void**)&s->topk_lp_host, (size_t)S * TOPK_MAX * 4, hipHostMallocDefault));
+  gemv_plan(d, 3 * d, &s->ks_qkv, &s->ksl_qkv);
+  gemv_plan(d, d, &s->ks_o, &s->ksl_o);
+  gemv_plan(d, 4 * d, &s->ks_1, &s->ksl_1);
+  gemv_plan(4 * d, d, &s->ks_2, &s->ksl_2);
+  gemv_plan(d, V, &s->ks_v, &s->ksl_v);
+  WB_TRY(s->x.ensure((size_t)S * d * 4));
+  WB_TRY(s->h.ensure((size_t)S * d * 4));
+  WB_TRY(s->att.ensure((size_t)S * d * 4));
+  WB_TRY(s->Pqkv.ensure((size_t)s->ks_qkv * S * 3 * d * 4));
+  WB_TRY(s->Po.ensure((size_t)s->ks_o * S * d * 4));
+  WB_TRY(s->Pq.ensure((size_t)s->ks_o * S * d * 4));
+  WB_TRY(s->P1.ensure((size_t)s->ks_1 * S * 4 * d * 4));
+  WB_TRY(s->P2.ensure((size_t)s->ks_2 * S * d * 4));
+  WB_TRY(s->ca.ensure((size_t)S * D.n_text_head * std::max(1, s->n_chunks) * CA_STRIDE * 4));
+  WB_TRY(s->logits.ensure((size_t)s->ks_v * S * V * 4));
+  WB_TRY(s->topk_id.ensure((size_t)S * TOPK_MAX * 4));
+  WB_TRY(s->topk_lp.ensure((size_t)S * TOPK_MAX * 4));
+  WB_TRY(s->row_stats.ensure((size_t)S * 2 * 4));
+  WB_TRY(s->lp_tmp.ensure((size_t)V * 4));
+  s->decode_ready = true;
+  return WB_OK;
+}
+
+}  // namespace wb
+
+wb_session::~wb_session() {
+  if (state_host) (void)hipHostFree(state_host);
+  if (topk_id_host) (void)hipHostFree(topk_id_host);
+  if (topk_lp_host) (void)hipHostFree(topk_lp_host);
+  if (st) (void)hipStreamDestroy(st);
+}
+
+extern "C" {
+
+int wb_session_begin(wb_model* m, const float* pcm, int64_t n_pcm, const int64_t* starts, const int64_t* lens,
+                     int n_windows, int max_beams, int padding, wb_session** out) {
+  WB_REQUIRE(m && pcm && starts && lens && out, WB_ERR_ARG, "wb_session_begin: null argument");
+  wb_session* s = nullptr;
+  WB_TRY(session_create(m, n_windows, max_beams, padding, &s));
+  int rc = session_encode_pcm(s, pcm, n_pcm, starts, lens);
+  if (rc != WB_OK) { wb_session_free(s); return rc; }
+  *out = s;
+  return WB_OK;
+}
+
+int wb_session_begin_mel(wb_model* m, const float* mel, const int32_t* T, int n_windows, int max_beams, int padding,
+                         wb_session** out) {
+  WB_REQUIRE(m && mel && T && out, WB_ERR_ARG, "wb_session_begin_mel: null argument");
+  wb_session* s = nullptr;
+  WB_TRY(session_create(m, n_windows, max_beams, padding, &s));
+  const int clip = m->dims.n_audio_ctx - padding;
+  int maxT = 0;
+  for (int w = 0; w < n_windows; w++) {
+    if (T[w] < 1) { wb_session_free(s); set_error("window %d: empty mel", w); return WB_ERR_SHAPE; }
+    s->T[w] = std::min(T[w], clip) + padding;   // transcribe.rs:171-177
+    maxT = std::max(maxT, s->T[w]);
+  }
+  const int Ts = (maxT + 3) & ~3;
+  std::vector<float> host((size_t)n_windows * 80 * Ts, 0.f);
+  const float* src = mel;
+  for (int w = 0; w < n_windows; w++) {
+    const int keep = s->T[w] - padding;
+    for (int r = 0; r < 80; r++) memcpy(&host[((size_t)w * 80 + r) * Ts], src + (size_t)r * T[w], (size_t)keep * 4);
+    src += (size_t)80 * T[w];
+  }
+  int rc = s->mel.ensure(host.size() * 4);
+  if (rc == WB_OK && hipMemcpy(s->mel.p, host.data(), host.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+    set_error("mel upload failed");
+    rc = WB_ERR_HIP;
+  }
+  if (rc == WB_OK) {
+    MelBatch mb;
+    mb.mel = s->mel.as<float>(); mb.win_stride = (int64_t)80 * Ts; mb.row_stride = Ts; mb.T = s->T;
+    rc = session_finish_encode(s, mb);
+  }
+  if (rc != WB_OK) { wb_session_free(s); return rc; }
+  *out = s;
+  return WB_OK;
+}
+
+void wb_session_free(wb_session* s) {
+  if (!s) return;
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  auto& v = g_pool[s->m];
+  if (v.size() < 2) { v.push_back(s); return; }   // keep the allocations for the next batch
+  (void)hipSetDevice(s->m->device);
+  delete s;
+}
+
+int wb_session_set_special_mask(wb_session* s, const uint8_t* is_special) {
+  WB_REQUIRE(s && is_special, WB_ERR_ARG, "wb_session_set_special_mask: null argument");
+  const int V = s->m->dims.n_vocab;
+  std::vector<float> mk(V);
+  for (int i = 0; i < V; i++) mk[i] = is_special[i] ? -INFINITY : 0.f;   // transcribe.rs:244
+  WB_HIP(hipSetDevice(s->m->device));
+  WB_TRY(s->mask.ensure((size_t)V * 4));
+  WB_HIP(hipMemcpy(s->mask.p, mk.data(), (size_t)V * 4, hipMemcpyHostToDevice));
+  s->has_mask = true;
+  return WB_OK;
+}
+
+int wb_session_step(wb_session* s, const int32_t* new_tokens, const int32_t* parent, const int32_t* window, int n,
+                    int apply_special_mask, int k, int32_t* top_ids, float* top_logprobs) {
+  WB_REQUIRE(s && new_tokens && parent && window, WB_ERR_ARG, "wb_session_step: null argument");
+  wb_model* m = s->m;
+  const wb_dims& D = m->dims;
+  const int d = D.n_text_state, H = D.n_text_head, NL = D.n_text_layer, V = D.n_vocab, S = s->S;
+  WB_HIP(hipSetDevice(m->device));
+  if (!s->decode_ready) WB_TRY(session_reserve(s, D.n_text_ctx));
+  WB_REQUIRE(n >= 1 && n <= S, WB_ERR_ARG, "wb_session_step: n = %d outside [1, %d]", n, S);
+  WB_REQUIRE(k >= 0 && k <= TOPK_MAX && (k == 0 || (top_ids && top_logprobs)), WB_ERR_ARG, "wb_session_step: bad k");
+  WB_REQUIRE(!apply_special_mask || s->has_mask, WB_ERR_STATE, "wb_session_step: special mask not set");
+  WB_REQUIRE(s->step < s->Lmax, WB_ERR_SHAPE, "Token sequence length %d must not exceed %d.", s->step + 1, s->Lmax);
+  const StepLayout& L = s->lay;
+  int* hs = s->state_host;
+  memset(hs, 0, (size_t)L.total * 4);
+  hs[ST_N] = n; hs[ST_STEP] = s->step;
+  std::vector<int> len(n);
+  for (int i = 0; i < n; i++) {
+    WB_REQUIRE(new_tokens[i] >= 0 && new_tokens[i] < V, WB_ERR_ARG, "token id %d out of range [0,%d)", new_tokens[i], V);
+    WB_REQUIRE(window[i] >= 0 && window[i] < s->W, WB_ERR_ARG, "beam %d: window %d out of range", i, window[i]);
+    if (parent[i] < 0) {
+      len[i] = 1;
+    } else {
+      WB_REQUIRE(parent[i] < s->prev_n, WB_ERR_ARG, "beam %d: parent %d is not a beam of the previous step", i, parent[i]);
+      WB_REQUIRE(s->prev_win[parent[i]] == window[i], WB_ERR_ARG, "beam %d: parent belongs to another window", i);
+      len[i] = s->prev_len[parent[i]] + 1;
+    }
+    WB_REQUIRE(len[i] <= s->Lmax, WB_ERR_SHAPE, "Token sequence length %d must not exceed %d.", len[i], s->Lmax);   // mod.rs:134-139
+    hs[L.tok + i] = new_tokens[i]; hs[L.parent + i] = parent[i]; hs[L.len + i] = len[i]; hs[L.win + i] = window[i];
+    int& nb = hs[L.win_nb + window[i]];
+    WB_REQUIRE(nb < s->max_beams, WB_ERR_ARG, "window %d has more than max_beams = %d live beams", window[i], s->max_beams);
+    hs[L.win_slots + window[i] * MAX_BEAMS + nb] = i;
+    nb++;
+  }
+  hipStream_t st = s->st;
+  ScopedTimer tm_step(st, 3);
+  WB_HIP(hipMemcpyAsync(s->state.p, hs, (size_t)L.total * 4, hipMemcpyHostToDevice, st));
+  const int* dst = s->state.as<int>();
+  int* tab_new = s->tabs.as<int>() + (size_t)(s->step & 1) * S * s->Lmax;
+  const int* tab_old = s->tabs.as<int>() + (size_t)((s->step & 1) ^ 1) * S * s->Lmax;
+  float *x = s->x.as<float>(), *h = s->h.as<float>(), *att = s->att.as<float>();
+  const size_t pool = (size_t)s->Lmax * S;
+  const int ldkv = NL * 2 * d;
+  const int* win_row0 = s->win_meta.as<int>();
+  const int* win_C = win_row0 + s->W;
+
+  launch_dec_prepare(st, dst, L, n, tab_old, tab_new, s->Lmax, m->tok_emb, m->dec_pos, d, x);
+  auto gemv = [&](const LinearW& w, int ks, int ksl, int pro, const float* src, int ld_src, float* P) {
+    GemvArgs a;
+    a.W = w.w; a.ldw = w.n; a.K = w.k; a.N = w.n; a.KS = ks; a.KSL = ksl; a.pro = pro; a.src = src; a.ld_src = ld_src;
+    a.P = P; a.st = dst; a.S = S;
+    return a;
+  };
+  for (int l = 0; l < NL; l++) {   // ResidualDecoderAttentionBlock::forward, mod.rs:345-350
+    const DecBlockW& b = m->dec[l];
+    if (l == 0)
+      launch_dec_resolve_ln(st, dst, n, x, nullptr, 0, S, nullptr, d, b.ln1, m->ln_eps_inside_sqrt, h);
+    else
+      launch_dec_resolve_ln(st, dst, n, x, s->P2.as<float>(), s->ks_2, S, m->dec[l - 1].mlp2.b, d, b.ln1,
+                            m->ln_eps_inside_sqrt, h);
+    launch_dec_gemv(st, gemv(b.qkv, s->ks_qkv, s->ksl_qkv, PRO_PLAIN, h, d, s->Pqkv.as<float>()), n);
+    launch_dec_self_attn(st, dst, L, n, H, s->Pqkv.as<float>(), s->ks_qkv, b.qkv.b, d,
+                         s->kc.as<float>() + (size_t)l * pool * d, s->vc.as<float>() + (size_t)l * pool * d, tab_new,
+                         s->Lmax, m->qk_scale, att);
+    launch_dec_gemv(st, gemv(b.out, s->ks_o, s->ksl_o, PRO_PLAIN, att, d, s->Po.as<float>()), n);
+    launch_dec_resolve_ln(st, dst, n, x, s->Po.as<float>(), s->ks_o, S, b.out.b, d, b.ln2, m->ln_eps_inside_sqrt, h);
+    launch_dec_gemv(st, gemv(b.cq, s->ks_o, s->ksl_o, PRO_PLAIN, h, d, s->Pq.as<float>()), n);
+    launch_dec_cross_attn(st, dst, L, s->W, H, s->n_chunks, s->Pq.as<float>(), s->ks_o, b.cq.b, d, s->ckv.as<float>(),
+                          ldkv, l * 2 * d, win_row0, win_C, m->qk_scale, s->ca.as<float>());
+    {
+      GemvArgs a = gemv(b.cout, s->ks_o, s->ksl_o, PRO_ATTN, s->ca.as<float>(), 0, s->Po.as<float>());
+      a.n_head = H; a.n_chunks = s->n_chunks;
+      launch_dec_gemv(st, a, n);
+    }
+    launch_dec_resolve_ln(st, dst, n, x, s->Po.as<float>(), s->ks_o, S, b.cout.b, d, b.ln3, m->ln_eps_inside_sqrt, h);
+    launch_dec_gemv(st, gemv(b.mlp1, s->ks_1, s->ksl_1, PRO_PLAIN, h, d, s->P1.as<float>()), n);
+    {
+      GemvArgs a = gemv(b.mlp2, s->ks_2, s->ksl_2, PRO_GELU, s->P1.as<float>(), 4 * d, s->P2.as<float>());
+      a.pbias = b.mlp1.b; a.KSp = s->ks_1;
+      launch_dec_gemv(st, a, n);
+    }
+  }
+  s->last_had_logits = 0;
+  if (k > 0) {
+    launch_dec_resolve_ln(st, dst, n, x, s->P2.as<float>(), s->ks_2, S, m->dec[NL - 1].mlp2.b, d, m->ln_dec,
+                          m->ln_eps_inside_sqrt, h);
+    // logits = ln(x) . token_embedding^T (mod.rs:155-156), last position only
+    ScopedTimer tm_logits(st, 6);
+    GemvArgs a;
+    a.W = m->tok_emb_t; a.ldw = m->vocab_ld; a.K = d; a.N = V; a.KS = s->ks_v; a.KSL = s->ksl_v; a.pro = PRO_PLAIN;
+    a.src = h; a.ld_src = d; a.P = s->logits.as<float>(); a.st = dst; a.S = S;
+    launch_dec_gemv(st, a, n);
+    tm_logits.stop();
+    launch_dec_topk(st, dst, n, s->logits.as<float>(), s->ks_v, (int64_t)S * V, V, s->mask.as<float>(),
+                    apply_special_mask ? 1 : 0, k,
+                    s->topk_id.as<int32_t>(), s->topk_lp.as<float>(), s->row_stats.as<float>());
+    WB_HIP(hipMemcpyAsync(s->topk_id_host, s->topk_id.p, (size_t)n * TOPK_MAX * 4, hipMemcpyDeviceToHost, st));
+    WB_HIP(hipMemcpyAsync(s->topk_lp_host, s->topk_lp.p, (size_t)n * TOPK_MAX * 4, hipMemcpyDeviceToHost, st));
+    tm_step.stop();
+    WB_HIP(hipStreamSynchronize(st));
+    tm_logits.collect();
+    if (tm_logits.on) profile().ms[7] += 1;
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < k; j++) {
+        top_ids[i * k + j] = s->topk_id_host[i * TOPK_MAX + j];
+        top_logprobs[i * k + j] = s->topk_lp_host[i * TOPK_MAX + j];
+      }
+    s->last_use_mask = apply_special_mask ? 1 : 0;
+    s->last_had_logits = 1;
+  } else {
+    tm_step.stop();
+    WB_HIP(hipStreamSynchronize(st));   // state_host is reused by the next step
+  }
+  tm_step.collect();
+  if (tm_step.on) profile().ms[4] += 1;
+  WB_HIP(hipGetLastError());
+  s->prev_len = len;
+  s->prev_win.assign(window, window + n);
+  s->prev_n = n;
+  s->step++;
+  return WB_OK;
+}
+
+int wb_session_last_logprobs(wb_session* s, int slot, float* out) {
+  WB_REQUIRE(s && out, WB_ERR_ARG, "wb_session_last_logprobs: null argument");
+  WB_REQUIRE(s->last_had_logits && slot >= 0 && slot < s->prev_n, WB_ERR_STATE,
+             "wb_session_last_logprobs: no logits for slot %d", slot);
+  const int V = s->m->dims.n_vocab;
+  WB_HIP(hipSetDevice(s->m->device));
+  launch_dec_logprob_row(s->st, s->logits.as<float>() + (size_t)slot * V, s->ks_v, (int64_t)s->S * V, V,
+                         s->mask.as<float>(), s->last_use_mask,
+                         s->row_stats.as<float>() + 2 * slot, s->lp_tmp.as<float>());
+  WB_HIP(hipMemcpyAsync(out, s->lp_tmp.p, (size_t)V * 4, hipMemcpyDeviceToHost, s->st));
+  WB_HIP(hipStreamSynchronize(s->st));
+  return WB_OK;
+}
+
+int wb_session_encoder_output(wb_session* s, int w, float* out, int32_t* C) {
+  WB_REQUIRE(s && w >= 0 && w < s->W, WB_ERR_ARG, "wb_session_encoder_output: bad argument");
+  const int d = s->m->dims.n_audio_state;
+  if (C) *C = s->C[w];
+  if (out) {
+    WB_HIP(hipSetDevice(s->m->device));
+    WB_HIP(hipMemcpy(out, s->enc_out.as<float>() + (size_t)s->row0[w] * d, (size_t)s->C[w] * d * 4,
+                     hipMemcpyDeviceToHost));
+  }
+  return WB_OK;
+}
+
+int wb_profile_enable(int on) {
+  profile().on = on != 0;
+  return WB_OK;
+}
+int wb_profile_read(double* out8, int reset) {
+  WB_REQUIRE(out8, WB_ERR_ARG, "wb_profile_read: null argument");
+  for (int i = 0; i < 8; i++) out8[i] = profile().ms[i];
+  if (reset)
+    for (int i = 0; i < 8; i++) profile().ms[i] = 0;
+  return WB_OK;
+}
+
+}  // extern "C"

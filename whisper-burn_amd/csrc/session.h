@@ -1,5 +1,51 @@
-// Stateful decode session (KV-cached fast path).
+// Stateful decode session: mel -> encoder -> cross-K/V once per window batch, then KV-cached steps.
 #pragma once
+#include <vector>
+
+#include "decode.h"
 #include "engine.h"
 
-struct wb_session;
+struct wb_session {
+  wb_model* m = nullptr;
+  hipStream_t st = nullptr;
+  int W = 0, max_beams = 0, S = 0, padding = 0;
+  double sample_rate = 16000.0;   // only feeds the mel filterbank (audio.rs:44)
+  int Lmax = 0;                 // capacity (positions) of the self-KV cache / tables
+  std::vector<int> T, C, row0;  // per window: mel frames (padded), encoder positions, first packed row
+  int enc_rows = 0, maxC = 0, n_chunks = 0;
+  wb::Workspace ws;
+  wb::DevMem pcm, mel, wins, gmax, enc_out, ckv, win_meta;
+  wb::DevMem kc, vc, tabs, state;
+  wb::StepLayout lay;
+  int* state_host = nullptr;            // pinned
+  int32_t* topk_id_host = nullptr;      // pinned [S][TOPK_MAX]
+  float* topk_lp_host = nullptr;
+  wb::DevMem x, h, att, Pqkv, Po, Pq, P1, P2, ca, logits, topk_id, topk_lp, row_stats, mask, lp_tmp;
+  int ks_qkv = 1, ksl_qkv = 0, ks_o = 1, ksl_o = 0, ks_1 = 1, ksl_1 = 0, ks_2 = 1, ksl_2 = 0, ks_v = 1, ksl_v = 0;
+  std::vector<int> prev_len, prev_win;
+  int prev_n = 0, step = 0;
+  bool has_mask = false, decode_ready = false;
+  int last_use_mask = 0, last_had_logits = 0;
+  ~wb_session();
+};
+
+namespace wb {
+// profile accumulators (session.cpp)
+struct Profile {
+  bool on = false;
+  double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+Profile& profile();
+// Timed region helper: records two events on `st` and adds the elapsed ms to slot `i` (when profiling is on).
+struct ScopedTimer {
+  hipStream_t st; int slot; hipEvent_t a = nullptr, b = nullptr; bool on;
+  ScopedTimer(hipStream_t s, int slot_);
+  void stop();          // records the end event
+  void collect();       // after the stream was synchronised: accumulate
+  ~ScopedTimer();
+};
+
+int session_create(wb_model* m, int n_windows, int max_beams, int padding, wb_session** out);
+int session_encode_pcm(wb_session* s, const float* pcm, int64_t n_pcm, const int64_t* starts, const int64_t* lens);
+int session_reserve(wb_session* s, int max_len);
+}  // namespace wb

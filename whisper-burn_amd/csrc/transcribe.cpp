@@ -96,3 +96,168 @@ int wb_stitch_windows(const int32_t* win_tokens, int32_t row_stride, const int32
 }
 
 }  // extern "C"
+
+// ---- beam search over session steps (src/beam.rs:9-110 + transcribe.rs:253-312) -----------
+namespace {
+
+struct Beam {
+  std::vector<int32_t> seq;
+  double log_prob = 0.0;
+  int prev_slot = -1;   // slot that held seq[0..len-1) in the last step it was fed
+};
+
+// beam.rs:81-110, literally (ascending list, insert before the first stored score >= score, evict index 0)
+template <class T, class F>
+std::vector<const T*> get_top_elements(const std::vector<T>& elems, F score, size_t num) {
+  std::vector<const T*> top;
+  std::vector<double> scores;
+  for (const T& e : elems) {
+    const double s = score(e);
+    if (top.size() == num) {
+      if (scores.empty() || s < scores[0]) continue;   // num == 0 would index out of bounds in the reference
+    }
+    size_t idx = scores.size();
+    for (size_t i = 0; i < scores.size(); i++)
+      if (scores[i] >= s) { idx = i; break; }
+    top.insert(top.begin() + idx, &e);
+    scores.insert(scores.begin() + idx, s);
+    if (top.size() > num) { top.erase(top.begin()); scores.erase(scores.begin()); }
+  }
+  return top;
+}
+
+// Rust Iterator::max_by(partial_cmp().unwrap()): the LAST of equal maxima; NaN panics -> error
+int max_by_log_prob(const std::vector<Beam>& beams, int* idx) {
+  *idx = -1;
+  for (size_t i = 0; i < beams.size(); i++) {
+    WB_REQUIRE(beams[i].log_prob == beams[i].log_prob, WB_ERR_STATE, "beam search: NaN log-probability (reference panics)");
+    if (*idx < 0 || beams[i].log_prob >= beams[*idx].log_prob) *idx = (int)i;
+  }
+  return WB_OK;
+}
+
+struct Cont { int32_t tok; double score; };
+
+}  // namespace
+
+extern "C" int wb_session_decode(wb_session* s, const wb_decode_params* p, int32_t* out_tokens, int32_t row_stride,
+                                 int32_t* out_lens) {
+  WB_REQUIRE(s && p && out_tokens && out_lens, WB_ERR_ARG, "wb_session_decode: null argument");
+  WB_REQUIRE(p->beam_size >= 1 && p->beam_size <= s->max_beams && p->beam_size <= TOPK_MAX, WB_ERR_ARG,
+             "beam_size %d outside [1, %d]", p->beam_size, std::min(s->max_beams, TOPK_MAX));
+  WB_REQUIRE(p->max_depth >= 0, WB_ERR_ARG, "max_depth must be >= 0");
+  const int V = s->m->dims.n_vocab, W = s->W, k = p->beam_size;
+  const int32_t prompt[4] = {p->tok_start_of_transcript, p->tok_language, p->tok_transcribe,
+                             p->tok_no_timestamps};   // transcribe.rs:203
+  for (int t : prompt) WB_REQUIRE(t >= 0 && t < V, WB_ERR_ARG, "prompt token %d out of range", t);
+  WB_REQUIRE(p->tok_end_of_text >= 0 && p->tok_end_of_text < V, WB_ERR_ARG, "end-of-text token out of range");
+  WB_REQUIRE(row_stride >= 4 + p->max_depth, WB_ERR_ARG, "row_stride %d < %d", row_stride, 4 + p->max_depth);
+  if (!s->decode_ready || s->Lmax < 4 + p->max_depth) WB_TRY(session_reserve(s, 4 + p->max_depth + 1));
+  const int32_t eot = p->tok_end_of_text;
+  auto finished = [&](const Beam& b) { return !b.seq.empty() && b.seq.back() == eot; };   // transcribe.rs:235-241
+
+  // prefill: the first three prompt tokens only feed the KV cache
+  std::vector<int32_t> tok(W), par(W), win(W);
+  for (int t = 0; t < 3; t++) {
+    for (int w = 0; w < W; w++) { tok[w] = prompt[t]; par[w] = t == 0 ? -1 : w; win[w] = w; }
+    WB_TRY(wb_session_step(s, tok.data(), par.data(), win.data(), W, 0, 0, nullptr, nullptr));
+  }
+  std::vector<std::vector<Beam>> beams(W);
+  std::vector<char> done(W, 0);
+  for (int w = 0; w < W; w++) {
+    Beam b;
+    b.seq.assign(prompt, prompt + 4); b.log_prob = 0.0; b.prev_slot = w;
+    beams[w].push_back(std::move(b));
+  }
+  std::vector<int32_t> top_ids((size_t)s->S * k);
+  std::vector<float> top_lp((size_t)s->S * k);
+  for (int depth = 0; depth < p->max_depth; depth++) {   // beam.rs:22-31
+    tok.clear(); par.clear(); win.clear();
+    std::vector<std::vector<int>> slot_of(W);   // per window: slot of each beam (-1 for finished beams)
+    for (int w = 0; w < W; w++) {
+      if (done[w]) continue;
+      int best;
+      WB_TRY(max_by_log_prob(beams[w], &best));
+      if (best >= 0 && finished(beams[w][best])) { done[w] = 1; continue; }   // beam.rs:23-27
+      slot_of[w].assign(beams[w].size(), -1);
+      for (size_t i = 0; i < beams[w].size(); i++) {
+        if (finished(beams[w][i])) continue;   // the reference evaluates them too and discards the row (beam.rs:56-57)
+        slot_of[w][i] = (int)tok.size();
+        tok.push_back(beams[w][i].seq.back()); par.push_back(beams[w][i].prev_slot); win.push_back(w);
+      }
+    }
+    if (tok.empty()) break;
+    const int apply_mask = (4 + depth) <= p->mask_until_len;   // transcribe.rs:271-275
+    WB_TRY(wb_session_step(s, tok.data(), par.data(), win.data(), (int)tok.size(), apply_mask, k, top_ids.data(),
+                           top_lp.data()));
+    for (int w = 0; w < W; w++) {   // beam_search_step, beam.rs:39-79
+      if (done[w]) continue;
+      std::vector<Beam> finished_beams, new_beams;
+      for (size_t i = 0; i < beams[w].size(); i++) {
+        Beam& b = beams[w][i];
+        if (finished(b)) { finished_beams.push_back(b); continue; }
+        const int slot = slot_of[w][i];
+        // the k best continuations by (log-prob desc, id asc) cover every element the V-wide
+        // insertion scan (beam.rs:59, :81-110) can retain; replay that scan on them in id order
+        std::vector<Cont> conts(k);
+        for (int j = 0; j < k; j++)
+          conts[j] = Cont{top_ids[(size_t)slot * k + j], b.log_prob + (double)top_lp[(size_t)slot * k + j]};   // :299
+        std::sort(conts.begin(), conts.end(), [](const Cont& a, const Cont& c) { return a.tok < c.tok; });
+        for (const Cont* c : get_top_elements(conts, [](const Cont& c) { return c.score; }, (size_t)k)) {
+          Beam nb;
+          nb.seq = b.seq; nb.seq.push_back(c->tok); nb.log_prob = c->score; nb.prev_slot = slot;
+          new_beams.push_back(std::move(nb));
+        }
+      }
+      std::vector<Beam> next;
+      for (const Beam* b : get_top_elements(new_beams, [](const Beam& b) { return b.log_prob; }, (size_t)k)) next.push_back(*b);
+      for (const Beam* b : get_top_elements(finished_beams, [](const Beam& b) { return b.log_prob; }, (size_t)k)) next.push_back(*b);
+      beams[w] = std::move(next);
+    }
+  }
+  for (int w = 0; w < W; w++) {   // beam.rs:33-36
+    int best;
+    WB_TRY(max_by_log_prob(beams[w], &best));
+    const std::vector<int32_t> empty;
+    const std::vector<int32_t>& seq = best >= 0 ? beams[w][best].seq : empty;
+    WB_REQUIRE((int)seq.size() <= row_stride, WB_ERR_ARG, "row_stride too small");
+    memcpy(out_tokens + (size_t)w * row_stride, seq.data(), seq.size() * sizeof(int32_t));
+    out_lens[w] = (int32_t)seq.size();
+  }
+  return WB_OK;
+}
+
+extern "C" int wb_waveform_to_tokens(wb_model* m, const float* pcm, int64_t n, int sample_rate,
+                                     const wb_decode_params* p, const uint8_t* is_special, int win_begin, int win_end,
+                                     int32_t* win_tokens, int32_t row_stride, int32_t* win_lens, int32_t* stitched,
+                                     int64_t stitched_cap, int64_t* n_stitched) {
+  WB_REQUIRE(m && pcm && p && is_special && win_tokens && win_lens, WB_ERR_ARG, "wb_waveform_to_tokens: null argument");
+  WB_REQUIRE(p->padding >= 0 && p->padding < m->dims.n_audio_ctx, WB_ERR_ARG, "bad padding");
+  // transcribe.rs:32-34
+  const int64_t wlen = wb_max_waveform_samples(m->dims.n_audio_ctx - p->padding);
+  const int64_t n_win = wb_window_extents(n, sample_rate, wlen, p->overlap_seconds, nullptr, nullptr, 0);
+  std::vector<int64_t> starts((size_t)n_win), lens((size_t)n_win);
+  wb_window_extents(n, sample_rate, wlen, p->overlap_seconds, starts.data(), lens.data(), n_win);
+  if (win_end < 0 || win_end > n_win) win_end = (int)n_win;
+  win_begin = std::max(0, std::min(win_begin, win_end));
+  const int n_local = win_end - win_begin;
+  int batch = p->max_batch_windows > 0 ? p->max_batch_windows : 64;
+  for (int b0 = 0; b0 < n_local; b0 += batch) {
+    const int nb = std::min(batch, n_local - b0);
+    wb_session* s = nullptr;
+    WB_TRY(session_create(m, nb, p->beam_size, p->padding, &s));
+    s->sample_rate = (double)sample_rate;
+    int rc = session_encode_pcm(s, pcm, n, starts.data() + win_begin + b0, lens.data() + win_begin + b0);
+    if (rc == WB_OK) rc = wb_session_set_special_mask(s, is_special);
+    if (rc == WB_OK) rc = session_reserve(s, 4 + p->max_depth + 1);
+    if (rc == WB_OK) rc = wb_session_decode(s, p, win_tokens + (size_t)b0 * row_stride, row_stride, win_lens + b0);
+    wb_session_free(s);
+    if (rc != WB_OK) return rc;
+  }
+  if (stitched) {
+    WB_REQUIRE(n_stitched, WB_ERR_ARG, "n_stitched is null");
+    WB_TRY(wb_stitch_windows(win_tokens, row_stride, win_lens, n_local, p->max_n_offsets, p->min_n_overlaps, stitched,
+                             stitched_cap, n_stitched));
+  }
+  return WB_OK;
+}

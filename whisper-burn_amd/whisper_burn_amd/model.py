@@ -225,3 +225,79 @@ def waveform_to_text(whisper: Whisper, bpe, lang, waveform, sample_rate: int = 1
     st = bpe.special_tokens(lang)
     tokens, _ = waveform_to_tokens(whisper, st, waveform, sample_rate)
     return bpe.decode(tokens, True), tokens
+
+
+class Session:
+    """KV-cached decode session over a batch of windows (include/whisper_hip.h, wb_session_*).
+
+    New relative to the reference, which has no KV cache (transcribe.rs:270); result-equivalent
+    to running `beamsearch_next` (transcribe.rs:253-307) on the same beams."""
+
+    def __init__(self, whisper: Whisper, handle, n_windows: int):
+        self._w = whisper
+        self._h = handle
+        self.n_windows = n_windows
+
+    @staticmethod
+    def begin(whisper: Whisper, waveform, starts, lens, max_beams: int = 5, padding: int = 10) -> "Session":
+        wav = _f32(waveform).reshape(-1)
+        st = np.ascontiguousarray(starts, dtype=np.int64)
+        ln = np.ascontiguousarray(lens, dtype=np.int64)
+        h = C.c_void_p()
+        check(_lib.load().wb_session_begin(whisper._h, _fp(wav), len(wav), st.ctypes.data_as(_lib.c_int64_p),
+                                           ln.ctypes.data_as(_lib.c_int64_p), len(st), max_beams, padding,
+                                           C.byref(h)))
+        return Session(whisper, h, len(st))
+
+    @staticmethod
+    def begin_mel(whisper: Whisper, mels: Sequence[np.ndarray], max_beams: int = 5, padding: int = 10) -> "Session":
+        mels = [_f32(m) for m in mels]
+        T = _i32([m.shape[1] for m in mels])
+        flat = np.concatenate([m.reshape(-1) for m in mels])
+        h = C.c_void_p()
+        check(_lib.load().wb_session_begin_mel(whisper._h, _fp(flat), _ip(T), len(mels), max_beams, padding,
+                                               C.byref(h)))
+        return Session(whisper, h, len(mels))
+
+    def set_special_mask(self, is_special) -> None:
+        m = np.ascontiguousarray(is_special, dtype=np.uint8)
+        check(_lib.load().wb_session_set_special_mask(self._h, m.ctypes.data_as(_lib.c_uint8_p)))
+
+    def step(self, new_tokens, parent, window, apply_special_mask: bool = False, k: int = 5):
+        t, p, w = _i32(new_tokens), _i32(parent), _i32(window)
+        n = len(t)
+        ids = np.zeros((n, max(k, 1)), dtype=np.int32)
+        lps = np.zeros((n, max(k, 1)), dtype=np.float32)
+        check(_lib.load().wb_session_step(self._h, _ip(t), _ip(p), _ip(w), n, int(apply_special_mask), k,
+                                          _ip(ids), _fp(lps)))
+        return (ids[:, :k], lps[:, :k]) if k > 0 else (None, None)
+
+    def last_logprobs(self, slot: int) -> np.ndarray:
+        out = np.empty(self._w.dims["n_vocab"], dtype=np.float32)
+        check(_lib.load().wb_session_last_logprobs(self._h, slot, _fp(out)))
+        return out
+
+    def encoder_output(self, w: int) -> np.ndarray:
+        c = C.c_int32(0)
+        check(_lib.load().wb_session_encoder_output(self._h, w, None, C.byref(c)))
+        out = np.empty((c.value, self._w.dims["n_audio_state"]), dtype=np.float32)
+        check(_lib.load().wb_session_encoder_output(self._h, w, _fp(out), C.byref(c)))
+        return out
+
+    def decode(self, params: WbDecodeParams) -> List[List[int]]:
+        stride = 4 + params.max_depth + 4
+        toks = np.zeros((self.n_windows, stride), dtype=np.int32)
+        lens = np.zeros(self.n_windows, dtype=np.int32)
+        check(_lib.load().wb_session_decode(self._h, C.byref(params), _ip(toks), stride, _ip(lens)))
+        return [toks[i, :lens[i]].tolist() for i in range(self.n_windows)]
+
+    def close(self):
+        if self._h:
+            _lib.load().wb_session_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
