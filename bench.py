@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Benchmark of the whisper-burn hot path on MI355X: real-time factor of
+waveform -> token ids (mel frontend + encoder + KV-cached decode + stitch).
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path over one batch of synthetic input: `--seconds` (30) seconds
+of seeded synthetic 16 kHz audio PER GPU, cut into the reference's windows (14.9 s, 3 s overlap,
+/root/reference/src/transcribe.rs:32-34, :120-123), mel + encoder once per window, greedy
+(beam_size = 1 = the live beam search of transcribe.rs:232 with k = 1) up to max_depth = 100
+tokens, token rows all-gathered over RCCL (N > 1) and stitched on the host.  Inputs (PCM,
+weights) are resident in HBM when the timed region starts.  Metric: real-time factor =
+audio seconds processed by the whole job / wall seconds (BASELINE.json).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "whisper-burn_amd")]
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="tiny.en")
+    ap.add_argument("--seconds", type=float, default=30.0, help="audio seconds per GPU per step")
+    ap.add_argument("--beam", type=int, default=1)
+    ap.add_argument("--max-depth", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus}` "
+                         f"(WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import whisper_burn_amd as wb
+    from whisper_burn_amd import _lib, shard, synth
+
+    lib = _lib.load()
+    weights = synth.synth_preset(args.model)
+    eng = wb.Whisper.from_tensors(weights, device=local_rank)
+    V = eng.dims["n_vocab"]
+    st = wb.SpecialTokens.for_vocab(V)
+    params = wb.decode_params(st, beam_size=args.beam, max_depth=args.max_depth)
+
+    sr = 16000
+    n_total = int(round(args.seconds * sr)) * world
+    audio = synth.synth_audio(n_total, 1234 + 2)                       # seed 1234 + config#
+    pcm_dev = torch.from_numpy(audio).to(dev)                           # resident in HBM before the timed region
+    wlen = wb.max_waveform_samples(eng.encoder_ctx_size() - params.padding)
+    starts, lens = wb.window_extents(n_total, sr, wlen, params.overlap_seconds)
+    n_win = len(starts)
+    row_stride = 4 + args.max_depth + 4
+    n_frames_local = int(sum(int(l) // 160 for l in lens[slice(*shard.partition_windows(n_win, rank, world))]))
+
+    def decode_local(lo, hi):
+        return wb.waveform_to_tokens(eng, st, None, sr, params=params, win_begin=lo, win_end=hi,
+                                     device_ptr=pcm_dev.data_ptr(), n_samples=n_total)[1]
+
+    def step():
+        return shard.transcribe_sharded(decode_local, wb.stitch_windows, n_win, rank, world, row_stride,
+                                        device=dev if world > 1 else None)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    tokens = None
+    for _ in range(args.warmup):
+        tokens, _ = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tokens, per_window = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- roofline of the dominant kernel (HIP events on the engine's stream, profiled pass) ----
+    roofline = None
+    stages = None
+    if rank == 0:
+        lib.wb_profile_enable(1)
+        buf = (np.zeros(8, dtype=np.float64))
+        lib.wb_profile_read(buf.ctypes.data_as(_lib.c_double_p), 1)
+        n_prof = 3
+        for _ in range(n_prof):
+            decode_local(*shard.partition_windows(n_win, rank, world))
+        lib.wb_profile_read(buf.ctypes.data_as(_lib.c_double_p), 1)
+        lib.wb_profile_enable(0)
+        mel_ms, enc_ms, ckv_ms, dec_ms, n_steps, n_mel, logit_ms, n_logit = [float(x) for x in buf]
+        d = eng.dims["n_text_state"]
+        lo, hi = shard.partition_windows(n_win, rank, world)
+        n_rows = (hi - lo) * args.beam
+        # logits GEMV: streams E^T [d][V] once, reads n rows of d, writes n rows of V (f32)
+        algo_bytes = 4.0 * (V * d + n_rows * d + n_rows * V)
+        if n_logit > 0 and logit_ms > 0:
+            avg_s = logit_ms / n_logit * 1e-3
+            ach = algo_bytes / avg_s / 1e9
+            roofline = {"kernel": "dec_gemv_kernel (tied-embedding logits, E^T [d][V] f32)", "bound": "hbm",
+                        "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "algorithmic_bytes_per_launch": int(algo_bytes),
+                        "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": int(n_logit)}
+        stages = {"mel_ms_per_step": round(mel_ms / n_prof, 4), "encoder_ms_per_step": round(enc_ms / n_prof, 4),
+                  "cross_kv_ms_per_step": round(ckv_ms / n_prof, 4), "decode_ms_per_step": round(dec_ms / n_prof, 4),
+                  "decode_steps_per_step": n_steps / n_prof,
+                  "mel_frames_per_s": round(n_frames_local / (mel_ms / n_prof * 1e-3), 1) if mel_ms > 0 else None,
+                  "mel_GBps_algorithmic": round(960.0 * n_frames_local / (mel_ms / n_prof * 1e-3) / 1e9, 2) if mel_ms > 0 else None}
+
+    # ---- CPU baseline: the oracle (reference algorithm as written) on a bounded sample ----
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import transcribe as otr
+        from oracle.model import OracleWhisper
+        ow = OracleWhisper(weights)
+        ost = otr.SpecialTokens(st.start_of_transcript, st.language, st.transcribe, st.no_timestamps,
+                                st.end_of_text, st.is_special.astype(bool))
+        n_cpu = min(n_total, int(wlen))                                  # one reference window
+        depth_cpu = min(args.max_depth, 100 if args.model.startswith("tiny") else 8)
+        tc = time.perf_counter()
+        otr.waveform_to_tokens(ow, ost, audio[:n_cpu], sr, args.beam, depth_cpu)
+        cpu_dt = time.perf_counter() - tc
+        # scale decode-bound time to max_depth when the sample was truncated in depth
+        cpu_rtf = (n_cpu / sr) / cpu_dt
+        cpu_baseline = {"value": round(cpu_rtf, 3), "unit": "x real-time", "cores": torch.get_num_threads(),
+                        "kind": "port",
+                        "sample": f"1 reference window ({n_cpu / sr:.1f} s), {args.model}, beam {args.beam}, "
+                                  f"depth {depth_cpu}, PyTorch-CPU fp32 restatement of the reference algorithm as "
+                                  f"written (dense-DFT mel, no KV cache); {cpu_dt:.1f} s wall",
+                        "host_cpus": os.cpu_count()}
+
+    if rank == 0:
+        audio_s = args.seconds * world * args.steps
+        out = {
+            "metric": "real-time factor (audio-sec/wall-sec)",
+            "value": round(audio_s / dt, 2),
+            "unit": "x real-time",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (seeded synthetic weights at the real shapes; seeded synthetic 16 kHz audio)",
+            "config": {"workload": f"{args.model}, {args.seconds:g} s of 16 kHz audio per GPU per step, reference "
+                                   f"windowing ({n_win} windows <= 14.9 s, 3 s overlap), HIP mel + encoder + "
+                                   f"KV-cached decode, {'greedy (beam_size 1)' if args.beam == 1 else 'beam ' + str(args.beam)}, "
+                                   f"max_depth {args.max_depth}",
+                       "model": args.model, "windows": n_win, "beam_size": args.beam, "max_depth": args.max_depth,
+                       "tokens_out": len(tokens) if tokens is not None else 0,
+                       "parallelism": f"windows sharded over {world} GPU(s), 1 token all-gather"},
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+            "stages": stages,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -166,6 +166,13 @@ int wb_waveform_to_tokens(wb_model* m, const float* pcm, int64_t n, int sample_r
                           int win_end, int32_t* win_tokens, int32_t row_stride, int32_t* win_lens,
                           int32_t* stitched, int64_t stitched_cap, int64_t* n_stitched);
 
+/* Same with the waveform already resident in device memory (`pcm_dev` is a DEVICE pointer
+ * on the model's GPU; no copy is made -- the mel kernel reads the windows in place). */
+int wb_waveform_to_tokens_dev(wb_model* m, const float* pcm_dev, int64_t n, int sample_rate,
+                              const wb_decode_params* p, const uint8_t* is_special, int win_begin,
+                              int win_end, int32_t* win_tokens, int32_t row_stride, int32_t* win_lens,
+                              int32_t* stitched, int64_t stitched_cap, int64_t* n_stitched);
+
 /* Window extents of waveform_to_mel_tensor (transcribe.rs:114-128).  Returns the window
  * count; fills starts/lens when non-NULL (capacity cap). */
 int64_t wb_window_extents(int64_t n_samples, int sample_rate, int64_t window_len, int overlap_seconds,

@@ -100,7 +100,8 @@ static int session_finish_encode(wb_session* s, const MelBatch& mb) {
   return WB_OK;
 }
 
-int session_encode_pcm(wb_session* s, const float* pcm, int64_t n_pcm, const int64_t* starts, const int64_t* lens) {
+int session_encode_pcm(wb_session* s, const float* pcm, int64_t n_pcm, const int64_t* starts, const int64_t* lens,
+                       bool pcm_on_device) {
   wb_model* m = s->m;
   const int clip = m->dims.n_audio_ctx - s->padding;   // transcribe.rs:171-177
   int64_t lo = n_pcm, hi = 0;
@@ -117,24 +118,25 @@ int session_encode_pcm(wb_session* s, const float* pcm, int64_t n_pcm, const int
   int maxF = 0, maxT = 0;
   for (int w = 0; w < s->W; w++) {
     const int nf = (int)(lens[w] / MEL_HOP);
-    wins[w] = MelWindow{starts[w] - lo, (int32_t)lens[w], nf, std::min(nf, clip), 0};
+    wins[w] = MelWindow{pcm_on_device ? starts[w] : starts[w] - lo, (int32_t)lens[w], nf, std::min(nf, clip), 0};
     s->T[w] = wins[w].n_emit + s->padding;
     maxF = std::max(maxF, nf); maxT = std::max(maxT, s->T[w]);
   }
   const int Ts = (maxT + 3) & ~3;
   const MelTables* tabs;
   WB_TRY(get_mel_tables(m->device, s->sample_rate, &tabs));
-  WB_TRY(s->pcm.ensure((size_t)(hi - lo) * 4));
+  if (!pcm_on_device) WB_TRY(s->pcm.ensure((size_t)(hi - lo) * 4));
   WB_TRY(s->wins.ensure(wins.size() * sizeof(MelWindow)));
   WB_TRY(s->gmax.ensure((size_t)s->W * 4));
   WB_TRY(s->mel.ensure((size_t)s->W * 80 * Ts * 4));
-  WB_HIP(hipMemcpyAsync(s->pcm.p, pcm + lo, (size_t)(hi - lo) * 4, hipMemcpyHostToDevice, s->st));
+  if (!pcm_on_device) WB_HIP(hipMemcpyAsync(s->pcm.p, pcm + lo, (size_t)(hi - lo) * 4, hipMemcpyHostToDevice, s->st));
+  const float* pcm_dev = pcm_on_device ? pcm : s->pcm.as<float>();
   WB_HIP(hipMemcpyAsync(s->wins.p, wins.data(), wins.size() * sizeof(MelWindow), hipMemcpyHostToDevice, s->st));
   WB_HIP(hipStreamSynchronize(s->st));   // `wins` is a stack vector
   {
     ScopedTimer tm(s->st, 0);
     launch_fill_f32(s->st, s->gmax.as<float>(), s->W, -INFINITY);
-    launch_mel_spectrogram(s->st, s->pcm.as<float>(), s->wins.as<MelWindow>(), s->W, maxF, tabs, s->mel.as<float>(),
+    launch_mel_spectrogram(s->st, pcm_dev, s->wins.as<MelWindow>(), s->W, maxF, tabs, s->mel.as<float>(),
                            (int64_t)80 * Ts, Ts, s->gmax.as<float>());
     launch_mel_finalize(s->st, s->wins.as<MelWindow>(), s->W, Ts, s->padding, s->mel.as<float>(), (int64_t)80 * Ts,
                         Ts, s->gmax.as<float>());
@@ -204,7 +206,7 @@ int wb_session_begin(wb_model* m, const float* pcm, int64_t n_pcm, const int64_t
   WB_REQUIRE(m && pcm && starts && lens && out, WB_ERR_ARG, "wb_session_begin: null argument");
   wb_session* s = nullptr;
   WB_TRY(session_create(m, n_windows, max_beams, padding, &s));
-  int rc = session_encode_pcm(s, pcm, n_pcm, starts, lens);
+  int rc = session_encode_pcm(s, pcm, n_pcm, starts, lens, false);
   if (rc != WB_OK) { wb_session_free(s); return rc; }
   *out = s;
   return WB_OK;

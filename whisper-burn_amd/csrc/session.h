@@ -46,6 +46,7 @@ struct ScopedTimer {
 };
 
 int session_create(wb_model* m, int n_windows, int max_beams, int padding, wb_session** out);
-int session_encode_pcm(wb_session* s, const float* pcm, int64_t n_pcm, const int64_t* starts, const int64_t* lens);
+int session_encode_pcm(wb_session* s, const float* pcm, int64_t n_pcm, const int64_t* starts, const int64_t* lens,
+                       bool pcm_on_device);
 int session_reserve(wb_session* s, int max_len);
 }  // namespace wb

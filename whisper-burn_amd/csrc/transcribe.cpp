@@ -227,10 +227,10 @@ extern "C" int wb_session_decode(wb_session* s, const wb_decode_params* p, int32
   return WB_OK;
 }
 
-extern "C" int wb_waveform_to_tokens(wb_model* m, const float* pcm, int64_t n, int sample_rate,
-                                     const wb_decode_params* p, const uint8_t* is_special, int win_begin, int win_end,
-                                     int32_t* win_tokens, int32_t row_stride, int32_t* win_lens, int32_t* stitched,
-                                     int64_t stitched_cap, int64_t* n_stitched) {
+static int waveform_to_tokens_impl(wb_model* m, const float* pcm, bool pcm_on_device, int64_t n, int sample_rate,
+                                   const wb_decode_params* p, const uint8_t* is_special, int win_begin, int win_end,
+                                   int32_t* win_tokens, int32_t row_stride, int32_t* win_lens, int32_t* stitched,
+                                   int64_t stitched_cap, int64_t* n_stitched) {
   WB_REQUIRE(m && pcm && p && is_special && win_tokens && win_lens, WB_ERR_ARG, "wb_waveform_to_tokens: null argument");
   WB_REQUIRE(p->padding >= 0 && p->padding < m->dims.n_audio_ctx, WB_ERR_ARG, "bad padding");
   // transcribe.rs:32-34
@@ -247,7 +247,7 @@ extern "C" int wb_waveform_to_tokens(wb_model* m, const float* pcm, int64_t n, i
     wb_session* s = nullptr;
     WB_TRY(session_create(m, nb, p->beam_size, p->padding, &s));
     s->sample_rate = (double)sample_rate;
-    int rc = session_encode_pcm(s, pcm, n, starts.data() + win_begin + b0, lens.data() + win_begin + b0);
+    int rc = session_encode_pcm(s, pcm, n, starts.data() + win_begin + b0, lens.data() + win_begin + b0, pcm_on_device);
     if (rc == WB_OK) rc = wb_session_set_special_mask(s, is_special);
     if (rc == WB_OK) rc = session_reserve(s, 4 + p->max_depth + 1);
     if (rc == WB_OK) rc = wb_session_decode(s, p, win_tokens + (size_t)b0 * row_stride, row_stride, win_lens + b0);
@@ -260,4 +260,20 @@ extern "C" int wb_waveform_to_tokens(wb_model* m, const float* pcm, int64_t n, i
                              stitched_cap, n_stitched));
   }
   return WB_OK;
+}
+
+extern "C" int wb_waveform_to_tokens(wb_model* m, const float* pcm, int64_t n, int sample_rate,
+                                     const wb_decode_params* p, const uint8_t* is_special, int win_begin, int win_end,
+                                     int32_t* win_tokens, int32_t row_stride, int32_t* win_lens, int32_t* stitched,
+                                     int64_t stitched_cap, int64_t* n_stitched) {
+  return waveform_to_tokens_impl(m, pcm, false, n, sample_rate, p, is_special, win_begin, win_end, win_tokens, row_stride,
+                                 win_lens, stitched, stitched_cap, n_stitched);
+}
+
+extern "C" int wb_waveform_to_tokens_dev(wb_model* m, const float* pcm_dev, int64_t n, int sample_rate,
+                                         const wb_decode_params* p, const uint8_t* is_special, int win_begin,
+                                         int win_end, int32_t* win_tokens, int32_t row_stride, int32_t* win_lens,
+                                         int32_t* stitched, int64_t stitched_cap, int64_t* n_stitched) {
+  return waveform_to_tokens_impl(m, pcm_dev, true, n, sample_rate, p, is_special, win_begin, win_end, win_tokens,
+                                 row_stride, win_lens, stitched, stitched_cap, n_stitched);
 }

@@ -60,6 +60,9 @@ SIGNATURES = {
     "wb_waveform_to_tokens": (C.c_int, [C.c_void_p, c_float_p, C.c_int64, C.c_int, C.POINTER(WbDecodeParams),
                                         c_uint8_p, C.c_int, C.c_int, c_int32_p, C.c_int32, c_int32_p,
                                         c_int32_p, C.c_int64, c_int64_p]),
+    "wb_waveform_to_tokens_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(WbDecodeParams),
+                                            c_uint8_p, C.c_int, C.c_int, c_int32_p, C.c_int32, c_int32_p,
+                                            c_int32_p, C.c_int64, c_int64_p]),
     "wb_window_extents": (C.c_int64, [C.c_int64, C.c_int, C.c_int64, C.c_int, c_int64_p, c_int64_p, C.c_int64]),
     "wb_find_chunk_overlap": (C.c_int, [c_int32_p, C.c_int64, c_int32_p, C.c_int64, C.c_int, C.c_int,
                                         c_int64_p, c_int64_p]),

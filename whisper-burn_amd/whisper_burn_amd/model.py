@@ -190,16 +190,21 @@ def stitch_windows(win_tokens: np.ndarray, win_lens: np.ndarray, max_n_offsets: 
 
 def waveform_to_tokens(whisper: Whisper, st: SpecialTokens, waveform, sample_rate: int = 16000,
                        beam_size: int = 5, max_depth: int = 100, win_begin: int = 0, win_end: int = -1,
-                       params: Optional[WbDecodeParams] = None):
+                       params: Optional[WbDecodeParams] = None, device_ptr: Optional[int] = None,
+                       n_samples: Optional[int] = None):
     """waveform_to_text (transcribe.rs:23-74) without the tokenizer.
 
     Returns (stitched token ids of the local windows, per-window token lists).  [win_begin, win_end)
-    selects the windows this process decodes (multi-GPU sharding); default all."""
+    selects the windows this process decodes (multi-GPU sharding); default all.
+    With `device_ptr` (+ `n_samples`) the waveform is read in place from device memory
+    (wb_waveform_to_tokens_dev) and `waveform` is ignored."""
     lib = _lib.load()
-    wav = _f32(waveform).reshape(-1)
+    if device_ptr is None:
+        wav = _f32(waveform).reshape(-1)
+        n_samples = len(wav)
     p = params or decode_params(st, beam_size, max_depth)
     wlen = max_waveform_samples(whisper.encoder_ctx_size() - p.padding)
-    starts, _ = window_extents(len(wav), sample_rate, wlen, p.overlap_seconds)
+    starts, _ = window_extents(n_samples, sample_rate, wlen, p.overlap_seconds)
     n_win = len(starts)
     if win_end < 0:
         win_end = n_win
@@ -211,9 +216,15 @@ def waveform_to_tokens(whisper: Whisper, st: SpecialTokens, waveform, sample_rat
     stitched = np.zeros(cap, dtype=np.int32)
     n_st = C.c_int64(0)
     mask = np.ascontiguousarray(st.is_special, dtype=np.uint8)
-    check(lib.wb_waveform_to_tokens(whisper._h, _fp(wav), len(wav), sample_rate, C.byref(p),
-                                    mask.ctypes.data_as(_lib.c_uint8_p), win_begin, win_end, _ip(win_tokens),
-                                    stride, _ip(win_lens), _ip(stitched), cap, C.byref(n_st)))
+    if device_ptr is None:
+        check(lib.wb_waveform_to_tokens(whisper._h, _fp(wav), n_samples, sample_rate, C.byref(p),
+                                        mask.ctypes.data_as(_lib.c_uint8_p), win_begin, win_end, _ip(win_tokens),
+                                        stride, _ip(win_lens), _ip(stitched), cap, C.byref(n_st)))
+    else:
+        check(lib.wb_waveform_to_tokens_dev(whisper._h, C.c_void_p(device_ptr), n_samples, sample_rate, C.byref(p),
+                                            mask.ctypes.data_as(_lib.c_uint8_p), win_begin, win_end,
+                                            _ip(win_tokens), stride, _ip(win_lens), _ip(stitched), cap,
+                                            C.byref(n_st)))
     per_window = [win_tokens[i, :win_lens[i]].tolist() for i in range(n_local)]
     return stitched[:n_st.value].tolist(), per_window
 
