@@ -155,6 +155,15 @@ void wb_session_free(wb_session* s);
 int wb_session_decode(wb_session* s, const wb_decode_params* p, int32_t* out_tokens,
                       int32_t row_stride, int32_t* out_lens);
 
+/* The same beam search (src/beam.rs:9-110 driving the closure of transcribe.rs:253-307) over a
+ * caller-supplied step function with wb_session_step's contract -- the host logic without the
+ * GPU, e.g. for a Rust caller that owns its own model, and for CPU tests of the bookkeeping. */
+typedef int (*wb_step_fn)(void* user, const int32_t* new_tokens, const int32_t* parent,
+                          const int32_t* window, int n, int apply_special_mask, int k,
+                          int32_t* top_ids, float* top_logprobs);
+int wb_beam_search(const wb_decode_params* p, int n_windows, int n_vocab, wb_step_fn step, void* user,
+                   int32_t* out_tokens, int32_t row_stride, int32_t* out_lens);
+
 /* waveform_to_text (transcribe.rs:23-74) without the tokenizer: windows
  * (transcribe.rs:114-128), per-window decode, token-overlap stitch
  * (find_chunk_overlap, transcribe.rs:76-110).  Only windows [win_begin, win_end) are

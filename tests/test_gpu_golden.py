@@ -1,0 +1,53 @@
+"""GPU: the HIP path against the COMMITTED golden vectors (no oracle run needed): config #1 of
+BASELINE.json -- the reference's bundled audio.wav (resampled to 16 kHz), tiny.en, greedy."""
+import numpy as np
+import pytest
+
+import whisper_burn_amd as wb
+from test_oracle_golden import golden
+from whisper_burn_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_mel_of_reference_wav_matches_golden():
+    g, audio = golden()
+    mel = wb.prep_audio(audio[None])[0]
+    assert list(mel.shape) == g["mel_shape"].tolist()
+    # vs the oracle's f32 recipe: <= 2e-3 on the bins near the clamp floor, <= 2e-4 on 95 % (the
+    # HIP FFT is closer to the exact f64 result than the reference's own f32 dense DFT is)
+    d = np.abs(mel[:, :160] - g["mel_head"])
+    assert d.max() < 2e-3 and np.mean(d > 2e-4) < 0.05
+    from oracle import mel as omel
+    assert np.abs(mel - omel.prep_audio_f64(audio)).max() < 5e-5
+
+
+def test_micro_model_matches_golden():
+    g, audio = golden()
+    dims = synth.micro_dims(n_state=128, n_head=2, n_layer=2, n_vocab=1031)
+    eng = wb.Whisper.from_tensors(synth.synth_weights(dims, seed=4242))
+    st = wb.SpecialTokens.for_vocab(1031)
+    mel = np.concatenate([wb.prep_audio(audio[None]), np.zeros((1, 80, 10), np.float32)], 2)
+    enc = eng.forward_encoder(mel)
+    assert list(enc.shape) == g["micro_enc_shape"].tolist()
+    assert np.abs(enc[0, ::6, ::3] - g["micro_enc_strided"]).max() < 3e-4
+    logits = eng.forward_decoder(g["micro_prefix"].astype(np.int32), enc)[0]
+    m = logits.max(1, keepdims=True)
+    lp = logits - m - np.log(np.exp(logits - m).sum(1, keepdims=True))
+    ids = np.argsort(-lp, axis=1, kind="stable")[:, :8]
+    assert np.array_equal(ids, g["micro_top_id"])
+    assert np.abs(np.take_along_axis(lp, ids, 1) - g["micro_top_lp"]).max() < 1e-3
+    assert wb.waveform_to_tokens(eng, st, audio, 16000, 1, 24)[0] == g["micro_greedy"].tolist()
+    assert wb.waveform_to_tokens(eng, st, audio, 16000, 5, 24)[0] == g["micro_beam5"].tolist()
+
+
+def test_tiny_en_on_reference_wav_matches_golden(tmp_path):
+    g, audio = golden()
+    w = synth.synth_preset("tiny.en")
+    from whisper_burn_amd import dumpdir
+    dumpdir.write_dump_dir(w, str(tmp_path))                 # exercise load_whisper's on-disk format too
+    eng = wb.Whisper.load_dump_dir(str(tmp_path))
+    assert eng.dims == dict(synth.preset_dims("tiny.en"))
+    st = wb.SpecialTokens.for_vocab(51864)
+    assert wb.waveform_to_tokens(eng, st, audio, 16000, 1, 16)[0] == g["tiny_en_greedy"].tolist()
+    assert wb.waveform_to_tokens(eng, st, audio, 16000, 5, 8)[0] == g["tiny_en_beam5"].tolist()

@@ -1,0 +1,59 @@
+"""CPU, world_size 2, gloo: window sharding + one token all-gather + host stitch reproduces the
+single-process result exactly (the N > 1 path of bench.py without GPUs)."""
+import os
+import socket
+
+import numpy as np
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import whisper_burn_amd as wb
+from whisper_burn_amd import shard
+
+ROW = 24
+
+
+def fake_decode(lo, hi):
+    """Deterministic per-window token rows with overlaps between neighbours (so the stitch matters)."""
+    out = []
+    for w in range(lo, hi):
+        rng = np.random.default_rng(1000 + w)
+        prev_tail = np.random.default_rng(1000 + w - 1).integers(0, 50, 16)[-5:] if w > 0 else []
+        out.append([7, 8, 9, 10] + list(map(int, prev_tail)) + list(map(int, rng.integers(0, 50, 16)))[:ROW - 9])
+    return out
+
+
+def _worker(rank, world, port, n_windows, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        toks, per_window = shard.transcribe_sharded(fake_decode, wb.stitch_windows, n_windows, rank, world, ROW)
+        q.put((rank, toks, per_window))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_sharding_equals_single_process():
+    for n_windows in (1, 5):
+        ref_toks, ref_pw = shard.transcribe_sharded(fake_decode, wb.stitch_windows, n_windows, 0, 1, ROW)
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, n_windows, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=120) for _ in procs]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        for _, toks, pw in res:
+            assert pw == ref_pw
+            assert toks == ref_toks

@@ -140,19 +140,19 @@ struct Cont { int32_t tok; double score; };
 
 }  // namespace
 
-extern "C" int wb_session_decode(wb_session* s, const wb_decode_params* p, int32_t* out_tokens, int32_t row_stride,
-                                 int32_t* out_lens) {
-  WB_REQUIRE(s && p && out_tokens && out_lens, WB_ERR_ARG, "wb_session_decode: null argument");
-  WB_REQUIRE(p->beam_size >= 1 && p->beam_size <= s->max_beams && p->beam_size <= TOPK_MAX, WB_ERR_ARG,
-             "beam_size %d outside [1, %d]", p->beam_size, std::min(s->max_beams, TOPK_MAX));
+// Beam search over an abstract step function (the session step on the GPU, or a caller's own).
+static int beam_search_windows(const wb_decode_params* p, int W, int V, int S, wb_step_fn step, void* user,
+                               int32_t* out_tokens, int32_t row_stride, int32_t* out_lens) {
+  WB_REQUIRE(p && step && out_tokens && out_lens && W >= 1, WB_ERR_ARG, "beam search: null / bad argument");
+  WB_REQUIRE(p->beam_size >= 1 && p->beam_size <= TOPK_MAX, WB_ERR_ARG, "beam_size %d outside [1, %d]", p->beam_size,
+             TOPK_MAX);
   WB_REQUIRE(p->max_depth >= 0, WB_ERR_ARG, "max_depth must be >= 0");
-  const int V = s->m->dims.n_vocab, W = s->W, k = p->beam_size;
+  const int k = p->beam_size;
   const int32_t prompt[4] = {p->tok_start_of_transcript, p->tok_language, p->tok_transcribe,
                              p->tok_no_timestamps};   // transcribe.rs:203
   for (int t : prompt) WB_REQUIRE(t >= 0 && t < V, WB_ERR_ARG, "prompt token %d out of range", t);
   WB_REQUIRE(p->tok_end_of_text >= 0 && p->tok_end_of_text < V, WB_ERR_ARG, "end-of-text token out of range");
   WB_REQUIRE(row_stride >= 4 + p->max_depth, WB_ERR_ARG, "row_stride %d < %d", row_stride, 4 + p->max_depth);
-  if (!s->decode_ready || s->Lmax < 4 + p->max_depth) WB_TRY(session_reserve(s, 4 + p->max_depth + 1));
   const int32_t eot = p->tok_end_of_text;
   auto finished = [&](const Beam& b) { return !b.seq.empty() && b.seq.back() == eot; };   // transcribe.rs:235-241
 
@@ -160,7 +160,7 @@ extern "C" int wb_session_decode(wb_session* s, const wb_decode_params* p, int32
   std::vector<int32_t> tok(W), par(W), win(W);
   for (int t = 0; t < 3; t++) {
     for (int w = 0; w < W; w++) { tok[w] = prompt[t]; par[w] = t == 0 ? -1 : w; win[w] = w; }
-    WB_TRY(wb_session_step(s, tok.data(), par.data(), win.data(), W, 0, 0, nullptr, nullptr));
+    WB_TRY(step(user, tok.data(), par.data(), win.data(), W, 0, 0, nullptr, nullptr));
   }
   std::vector<std::vector<Beam>> beams(W);
   std::vector<char> done(W, 0);
@@ -169,8 +169,8 @@ extern "C" int wb_session_decode(wb_session* s, const wb_decode_params* p, int32
     b.seq.assign(prompt, prompt + 4); b.log_prob = 0.0; b.prev_slot = w;
     beams[w].push_back(std::move(b));
   }
-  std::vector<int32_t> top_ids((size_t)s->S * k);
-  std::vector<float> top_lp((size_t)s->S * k);
+  std::vector<int32_t> top_ids((size_t)S * k);
+  std::vector<float> top_lp((size_t)S * k);
   for (int depth = 0; depth < p->max_depth; depth++) {   // beam.rs:22-31
     tok.clear(); par.clear(); win.clear();
     std::vector<std::vector<int>> slot_of(W);   // per window: slot of each beam (-1 for finished beams)
@@ -188,8 +188,8 @@ extern "C" int wb_session_decode(wb_session* s, const wb_decode_params* p, int32
     }
     if (tok.empty()) break;
     const int apply_mask = (4 + depth) <= p->mask_until_len;   // transcribe.rs:271-275
-    WB_TRY(wb_session_step(s, tok.data(), par.data(), win.data(), (int)tok.size(), apply_mask, k, top_ids.data(),
-                           top_lp.data()));
+    WB_TRY(step(user, tok.data(), par.data(), win.data(), (int)tok.size(), apply_mask, k, top_ids.data(),
+                top_lp.data()));
     for (int w = 0; w < W; w++) {   // beam_search_step, beam.rs:39-79
       if (done[w]) continue;
       std::vector<Beam> finished_beams, new_beams;
@@ -225,6 +225,28 @@ extern "C" int wb_session_decode(wb_session* s, const wb_decode_params* p, int32
     out_lens[w] = (int32_t)seq.size();
   }
   return WB_OK;
+}
+
+static int session_step_thunk(void* user, const int32_t* new_tokens, const int32_t* parent, const int32_t* window,
+                              int n, int apply_special_mask, int k, int32_t* top_ids, float* top_logprobs) {
+  return wb_session_step(static_cast<wb_session*>(user), new_tokens, parent, window, n, apply_special_mask, k, top_ids,
+                         top_logprobs);
+}
+
+extern "C" int wb_session_decode(wb_session* s, const wb_decode_params* p, int32_t* out_tokens, int32_t row_stride,
+                                 int32_t* out_lens) {
+  WB_REQUIRE(s && p && out_tokens && out_lens, WB_ERR_ARG, "wb_session_decode: null argument");
+  WB_REQUIRE(p->beam_size >= 1 && p->beam_size <= s->max_beams, WB_ERR_ARG, "beam_size %d outside [1, %d]",
+             p->beam_size, s->max_beams);
+  if (!s->decode_ready || s->Lmax < 4 + p->max_depth) WB_TRY(session_reserve(s, 4 + p->max_depth + 1));
+  return beam_search_windows(p, s->W, s->m->dims.n_vocab, s->S, session_step_thunk, s, out_tokens, row_stride, out_lens);
+}
+
+extern "C" int wb_beam_search(const wb_decode_params* p, int n_windows, int n_vocab, wb_step_fn step, void* user,
+                              int32_t* out_tokens, int32_t row_stride, int32_t* out_lens) {
+  WB_REQUIRE(p, WB_ERR_ARG, "wb_beam_search: null params");
+  return beam_search_windows(p, n_windows, n_vocab, n_windows * std::max(1, p->beam_size), step, user, out_tokens,
+                             row_stride, out_lens);
 }
 
 static int waveform_to_tokens_impl(wb_model* m, const float* pcm, bool pcm_on_device, int64_t n, int sample_rate,

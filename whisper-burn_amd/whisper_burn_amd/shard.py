@@ -59,12 +59,12 @@ def all_gather_rows(local: np.ndarray, world: int, device=None) -> np.ndarray:
         return local[None]
     import torch
     import torch.distributed as dist
-    t = torch.from_numpy(np.ascontiguousarray(local))
+    t = torch.from_numpy(np.ascontiguousarray(local)).reshape(-1)
     if device is not None and str(device) != "cpu":
         t = t.to(device)
-    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, t)
-    return out.cpu().numpy()
+    out = torch.empty(world * t.numel(), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t)          # concatenation along dim 0 (gloo and nccl agree on this form)
+    return out.cpu().numpy().reshape((world,) + tuple(local.shape))
 
 
 def transcribe_sharded(decode_local: Callable[[int, int], List[List[int]]], stitch: Callable[[np.ndarray, np.ndarray], List[int]],
