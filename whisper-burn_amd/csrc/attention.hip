@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
+#include "wave_ops.h"
 
 namespace wb {
 namespace {
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(const float* __r
       sacc[r] = ok ? sacc[r] : -INFINITY;
       tmax = fmaxf(tmax, sacc[r]);
     }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    tmax = xor32_max(tmax);
     const float m_new = fmaxf(m_run, tmax);
     const float alpha = expf(m_run - m_new);
     float psum = 0.f;
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(const float* __r
     __syncthreads();
   }
 
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float l_tot = xor32_sum(l_run);
   if (qi < seg.q_len) {
     float* op = O + (int64_t)(seg.q_row0 + qi) * ldo + head * 64;
 #pragma unroll

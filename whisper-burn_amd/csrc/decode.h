@@ -12,8 +12,12 @@ namespace wb {
 constexpr int MAX_BEAMS = 8;     // live beams per window (reference: beam_size 5, transcribe.rs:232)
 constexpr int TOPK_MAX = 8;
 constexpr int CA_STRIDE = 66;    // cross-attention chunk partial: m, l, o[64]
+constexpr int TS_STRIDE = 2 + 2 * TOPK_MAX;   // logits tile partial: max, sum-exp, k x (value, id)
+constexpr int GV_CT = 128;       // columns per GEMV block tile
+constexpr int KS_MAX = 16;       // most K-split partials any consumer folds
 
-// Per-step state block in device memory (ints).  Header, then per-slot arrays, then per-window lists.
+// Per-step state block (ints): header, per-slot arrays, per-window lists.  The host writes it into
+// mapped pinned memory; dec_prepare_kernel copies it to device memory for the rest of the step.
 enum { ST_N = 0, ST_STEP = 1, ST_HDR = 4 };
 struct StepLayout {
   int S = 0, W = 0;                                  // slot capacity, windows
@@ -29,34 +33,42 @@ inline StepLayout make_step_layout(int S, int W) {
   return l;
 }
 
-enum { PRO_PLAIN = 0, PRO_GELU = 1, PRO_ATTN = 2 };
+enum { PRO_PLAIN = 0, PRO_GELU = 1, PRO_ATTN = 2, PRO_LN = 3 };
 struct GemvArgs {
   const float* W = nullptr; int ldw = 0;    // [K][ldw] row-major
   int K = 0, N = 0, KS = 1, KSL = 0;        // K-split count / slice length
   int pro = PRO_PLAIN;
-  const float* src = nullptr; int ld_src = 0;   // PLAIN: [rows][K]; GELU: partials [KSp][S][K]; ATTN: chunk partials
-  const float* pbias = nullptr; int KSp = 0;    // GELU prologue
-  int n_head = 0, n_chunks = 0;                 // ATTN prologue
+  // PLAIN: src [rows][K].  GELU: src = partials [KSp][S][K] of lin1, pbias.  ATTN: src = chunk partials.
+  // LN: src = residual stream x_in [S][K] (K == d); pending partials pend [KSp][S][K] + pbias are folded
+  //     first (KSp = 0: none), block (0,0) writes the folded stream to x_out, then LayerNorm(g, b, eps).
+  const float* src = nullptr; int ld_src = 0;
+  const float* pend = nullptr; const float* pbias = nullptr; int KSp = 0;
+  float* x_out = nullptr;
+  const float* ln_g = nullptr; const float* ln_b = nullptr; float ln_eps = 0.f; int ln_inside = 0;
+  int n_head = 0, n_chunks = 0;             // ATTN prologue
   float* P = nullptr;                       // out partials [KS][S][N]
+  // STATS epilogue (logits): + mask, per-tile max / sum-exp / top-k -> tstats [row][n_tiles][TS_STRIDE]
+  const float* mask = nullptr; int use_mask = 0, topk = 0; float* tstats = nullptr;
   const int* st = nullptr; int S = 0;
 };
 
 void gemv_plan(int K, int N, int* KS, int* KSL);
 int cross_attn_chunk();
 
-void launch_dec_prepare(hipStream_t st, const int* state, const StepLayout& lay, int n_max, const int* tab_old,
-                        int* tab_new, int Lmax, const float* E, const float* pos, int d, float* x);
-void launch_dec_resolve_ln(hipStream_t st, const int* state, int n_max, float* x, const float* P, int KS, int S,
-                           const float* bias, int d, const LayerNormW& ln, int eps_inside_sqrt, float* h);
-void launch_dec_gemv(hipStream_t st, const GemvArgs& a, int n_rows_hint);
+void launch_dec_prepare(hipStream_t st, const int* state_host_mapped, int* state_dev, const StepLayout& lay, int n,
+                        int* tabs, int Lmax, const float* E, const float* pos, int d, float* x);
+void launch_dec_resolve_ln(hipStream_t st, const int* state, int n_max, const float* x_in, float* x_out,
+                           const float* P, int KS, int S, const float* bias, int d, const LayerNormW& ln,
+                           int eps_inside_sqrt, float* h);
+void launch_dec_gemv(hipStream_t st, const GemvArgs& a, int n_rows_hint, bool stats);
 void launch_dec_self_attn(hipStream_t st, const int* state, const StepLayout& lay, int n_max, int n_head,
                           const float* Pqkv, int KS, const float* bqkv, int d, float* Kc, float* Vc, const int* tab,
                           int Lmax, float scale, float* att);
 void launch_dec_cross_attn(hipStream_t st, const int* state, const StepLayout& lay, int n_windows, int n_head,
                            int n_chunks, const float* Pq, int KS, const float* bq, int d, const float* ckv, int ldkv,
-                           int koff, const int* win_row0, const int* win_C, float scale, float* ca);
-void launch_dec_topk(hipStream_t st, const int* state, int n_max, const float* logits, int KS, int64_t plane, int V,
-                     const float* mask, int use_mask, int k, int32_t* out_id, float* out_lp, float* row_stats);
+                           int koff, const int* win_row0, const int* win_C, float scale, float* ca, int max_nb);
+void launch_dec_topk_merge(hipStream_t st, const int* state, int n_max, const float* tstats, int n_tiles, int k,
+                           int32_t* out_id, float* out_lp, float* row_stats);
 void launch_dec_logprob_row(hipStream_t st, const float* x, int KS, int64_t plane, int V, const float* mask,
                             int use_mask, const float* stats, float* out);
 

@@ -1,47 +1,60 @@
-// K7/K8: KV-cached single-token decode step (HBM-bound weight / KV streaming).
+// K7/K8: KV-cached single-token decode step (HBM-bound weight / KV streaming, latency-critical).
 //
 // The reference re-runs the whole decoder over the whole prefix for every beam at every step
 // and re-projects the cross-attention K/V in every layer (/root/reference/src/transcribe.rs:270,
 // src/model/mod.rs:482-490), then ships [n, L, V] logits to log_softmax and V floats per beam to
-// the host (transcribe.rs:276-284).  Here a step touches each decoder weight once:
-//   skinny GEMMs (rows = live beams) stream W[K][N] with K split over blocks into deterministic
-//   partial sums; consumers fold the partials (+bias, residual, LayerNorm / GELU / q-scale) in
-//   their prologues, so no reduction kernel or atomics are needed;
+// the host (transcribe.rs:276-284).  Here a step touches each decoder weight once, in 8 launches
+// per layer + 3:
+//   skinny GEMMs (rows = live beams) stream W[K][N] once with K split over blocks into
+//   deterministic partial sums; the CONSUMER folds the partials in its prologue (+bias, residual,
+//   LayerNorm / GELU / q-scale / attention-chunk combine), so there is no reduction kernel and
+//   no atomic; the first weight tile is prefetched ahead of the prologue so the two global
+//   latencies overlap;
 //   self-attention reads a paged self-KV cache through per-beam position tables (beam
-//   re-indexing = copying a row of ints);  cross-attention streams each window's cached K/V once
-//   for all of that window's beams, split over key chunks (flash-decoding), combined by the
-//   out-projection's prologue;
-//   the tied-embedding logits stream E^T [d][V], then one block per beam does mask +
-//   log-softmax + top-k (value descending, id ascending) so only k pairs go back to the host.
+//   re-indexing = copying a row of ints); cross-attention streams each window's cached K/V once
+//   for all of that window's beams, split over key chunks (flash-decoding);
+//   the tied-embedding logits kernel streams E^T [d][V] and leaves per-128-column-tile
+//   max / sum-exp / top-k, merged by one small block per beam that writes the k (id, log-prob)
+//   pairs straight into mapped host memory.
 #include <hip/hip_runtime.h>
 
 #include "decode.h"
+#include "wave_ops.h"
 
 namespace wb {
 namespace {
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
-}
+constexpr int GV_KSL_MAX = 512;   // K-slice capacity of the non-LN prologues
+constexpr int DMAX = 1280;        // largest n_state (large-v2); LN prologues keep whole rows in LDS
+
 __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
-// ---- step prepare: position tables + token/position embedding (mod.rs:141-146) ----------
-__global__ void dec_prepare_kernel(const int* __restrict__ st, StepLayout lay, const int* __restrict__ tab_old,
-                                   int* __restrict__ tab_new, int Lmax, const float* __restrict__ E,
+// bias[c] + sum_s P[s][row][c] with the loads issued together (fixed summation order)
+__device__ __forceinline__ float fold_partials(const float* __restrict__ P, int KS, int64_t plane, int64_t off,
+                                               float init) {
+  float v[KS_MAX];
+#pragma unroll
+  for (int s = 0; s < KS_MAX; s++) v[s] = (s < KS) ? P[(int64_t)s * plane + off] : 0.f;
+  float acc = init;
+#pragma unroll
+  for (int s = 0; s < KS_MAX; s++) acc += v[s];
+  return acc;
+}
+
+// ---- step prepare: state host->device, position tables, token/position embedding (mod.rs:141-146) ----
+__global__ void dec_prepare_kernel(const int* __restrict__ st_host, int* __restrict__ st_dev, StepLayout lay,
+                                   int* __restrict__ tabs, int Lmax, const float* __restrict__ E,
                                    const float* __restrict__ pos, int d, float* __restrict__ x) {
   const int i = blockIdx.x;
-  if (i >= st[ST_N]) return;
-  const int len = st[lay.len + i], parent = st[lay.parent + i], tok = st[lay.tok + i];
-  const int step = st[ST_STEP];
+  if (i == 0)
+    for (int e = threadIdx.x; e < lay.total; e += blockDim.x) st_dev[e] = st_host[e];
+  if (i >= st_host[ST_N]) return;
+  const int len = st_host[lay.len + i], parent = st_host[lay.parent + i], tok = st_host[lay.tok + i];
+  const int step = st_host[ST_STEP];
+  int* tab_new = tabs + (size_t)(step & 1) * lay.S * Lmax;           // position tables are double-buffered by step parity
+  const int* tab_old = tabs + (size_t)((step & 1) ^ 1) * lay.S * Lmax;
   if (parent >= 0)
     for (int p = threadIdx.x; p < len - 1; p += blockDim.x) tab_new[i * Lmax + p] = tab_old[parent * Lmax + p];
   if (threadIdx.x == 0) tab_new[i * Lmax + len - 1] = step * lay.S + i;
@@ -54,11 +67,11 @@ __global__ void dec_prepare_kernel(const int* __restrict__ st, StepLayout lay, c
   }
 }
 
-// ---- residual resolve + LayerNorm: x += bias + sum_s P[s]; h = LN(x) -----------------------
+// ---- stand-alone residual resolve + LayerNorm (used when more than 8 beams are live) ------------
 template <int VPT>
-__global__ __launch_bounds__(256) void dec_resolve_ln_kernel(const int* __restrict__ st, float* __restrict__ x,
-                                                             const float* __restrict__ P, int KS, int S,
-                                                             const float* __restrict__ bias, int d,
+__global__ __launch_bounds__(256) void dec_resolve_ln_kernel(const int* __restrict__ st, const float* __restrict__ x_in,
+                                                             float* __restrict__ x_out, const float* __restrict__ P,
+                                                             int KS, int S, const float* __restrict__ bias, int d,
                                                              const float* __restrict__ g,
                                                              const float* __restrict__ b, float eps,
                                                              int eps_inside_sqrt, float* __restrict__ h) {
@@ -73,13 +86,9 @@ __global__ __launch_bounds__(256) void dec_resolve_ln_kernel(const int* __restri
     const int c = tid + i * 256;
     v[i] = 0.f;
     if (c < d) {
-      float a = x[(int64_t)r * d + c];
-      if (KS > 0) {
-        float acc = bias[c];
-        for (int k = 0; k < KS; k++) acc += P[((int64_t)k * S + r) * d + c];
-        a = a + acc;                       // x + (attn/mlp output), mod.rs:346-348
-        x[(int64_t)r * d + c] = a;
-      }
+      float a = x_in[(int64_t)r * d + c];
+      if (KS > 0) a = a + fold_partials(P, KS, (int64_t)S * d, (int64_t)r * d + c, bias[c]);   // mod.rs:346-348
+      x_out[(int64_t)r * d + c] = a;
       v[i] = a;
       s += a;
     }
@@ -106,16 +115,16 @@ __global__ __launch_bounds__(256) void dec_resolve_ln_kernel(const int* __restri
   }
 }
 
-// ---- skinny GEMM: P[ks][r][n] = sum_{k in slice ks} in[r][k] * W[k][n],  r < n_rows <= S ----
+// ---- skinny GEMM: P[ks][r][n] = sum_{k in slice ks} in[r][k] * W[k][n],  r < n_rows <= S -------
 // block = 4 waves, column tile 128 (32 lanes x float4), each half-wave owns 4 consecutive k per
-// 32-deep iteration; input rows staged in LDS with the prologue applied.
-constexpr int GV_CT = 128;
-constexpr int GV_KSL_MAX = 512;
-
-template <int MR>
+// 32-deep step, two steps (8 x 16 B per lane) in flight; input rows staged in LDS with the
+// prologue applied.  LN prologue: one wave per row folds x + pending partials, takes the
+// LayerNorm statistics with shuffles only, and stages the block's K-slice.
+template <int MR, int XLD, int DPL, bool LN, bool STATS>
 __global__ __launch_bounds__(256) void dec_gemv_kernel(GemvArgs a) {
-  __shared__ __attribute__((aligned(16))) float xs[MR * GV_KSL_MAX];   // also the cross-wave reduction buffer
-  static_assert(MR * GV_KSL_MAX >= 4 * MR * GV_CT, "reduction buffer must fit");
+  __shared__ __attribute__((aligned(16))) float xbuf[MR * XLD];   // input rows; later the cross-wave reduction buffer
+  __shared__ float tilev[STATS ? MR : 1][GV_CT];
+  static_assert(MR * XLD >= 4 * MR * GV_CT, "reduction buffer must fit");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, c4 = (lane & 31) * 4;
   const int n0 = blockIdx.x * GV_CT, ks = blockIdx.y;
@@ -125,157 +134,351 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(GemvArgs a) {
   const int unit = wave * 2 + half;
   const bool col_ok = (n0 + c4) < a.ldw;
   const float* Wp = a.W + (int64_t)k0 * a.ldw + n0 + c4;
+  const int64_t ldw = a.ldw;
+
+  float4 w[8];
+  auto load_pair = [&](int kb) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int k = kb + (j >> 2) * 32 + (j & 3);
+      w[j] = (col_ok && k < kn) ? *reinterpret_cast<const float4*>(Wp + k * ldw) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  load_pair(unit * 4);   // first weight tiles in flight before the prologue touches memory
 
   for (int r0 = 0; r0 < n_rows; r0 += MR) {
-    // ---- stage in[r0..r0+MR)[k0..k0+kn) with the prologue ----
-    for (int e = tid; e < MR * kn; e += 256) {
-      const int r = e / kn, kk = e - r * kn;
-      const int row = r0 + r, k = k0 + kk;
-      float v = 0.f;
-      if (row < n_rows) {
-        if (a.pro == PRO_PLAIN) {
-          v = a.src[(int64_t)row * a.ld_src + k];
-        } else if (a.pro == PRO_GELU) {           // GELU(lin1(x)), mod.rs:377-378, lin1 partials folded here
-          float acc = a.pbias[k];
-          for (int s = 0; s < a.KSp; s++) acc += a.src[((int64_t)s * a.S + row) * a.ld_src + k];
-          v = gelu_erf(acc);
-        } else {                                  // PRO_ATTN: combine the key-chunk partials of cross-attention
-          const int hh = k >> 6, dh = k & 63;
-          const float* ca = a.src + ((int64_t)(row * a.n_head + hh) * a.n_chunks) * CA_STRIDE;
-          float M = -1.0e30f;
-          for (int c = 0; c < a.n_chunks; c++) M = fmaxf(M, ca[c * CA_STRIDE]);
-          float num = 0.f, den = 0.f;
-          for (int c = 0; c < a.n_chunks; c++) {
-            const float w = expf(ca[c * CA_STRIDE] - M);
-            num += w * ca[c * CA_STRIDE + 2 + dh];
-            den += w * ca[c * CA_STRIDE + 1];
+    // ---- prologue: stage in[r0..r0+MR)[k0..k0+kn) ----
+    if constexpr (LN) {
+      const int d = a.K;
+      const bool writer = (blockIdx.x == 0 && blockIdx.y == 0);
+      for (int r = wave; r < MR; r += 4) {
+        const int row = r0 + r;
+        if (row >= n_rows) {   // padding row of the chunk (wave-uniform)
+          for (int c = lane; c < kn; c += 64) xbuf[r * XLD + c] = 0.f;
+          continue;
+        }
+        // LayerNorm scale/shift of this block's K-slice: in flight together with the row itself
+        float gv[DPL], bv[DPL];
+#pragma unroll
+        for (int i = 0; i < DPL; i++) {
+          const int c = lane + 64 * i;
+          const bool in = c >= k0 && c < k0 + kn;
+          gv[i] = in ? a.ln_g[c] : 0.f;
+          bv[i] = in ? a.ln_b[c] : 0.f;
+        }
+        float v[DPL];
+        const float* xr = a.src + (int64_t)row * d;
+#pragma unroll
+        for (int i = 0; i < DPL; i++) {
+          const int c = lane + 64 * i;
+          v[i] = c < d ? xr[c] : 0.f;
+        }
+        if (a.KSp > 0) {       // x + (attn/mlp output) = x + bias + sum_s partial_s, s ascending  (mod.rs:346-348)
+          float acc[DPL];
+#pragma unroll
+          for (int i = 0; i < DPL; i++) { const int c = lane + 64 * i; acc[i] = c < d ? a.pbias[c] : 0.f; }
+          const float* pp = a.pend + (int64_t)row * d;
+          const int64_t plane = (int64_t)a.S * d;
+          // all loads of a chunk of partial planes are issued before the first add (memory-level
+          // parallelism is what bounds this prologue); the summation order stays s ascending
+          constexpr int CH = 8;
+          for (int sp = 0; sp < a.KSp; sp += CH) {
+            float t[CH][DPL];
+#pragma unroll
+            for (int j = 0; j < CH; j++)
+#pragma unroll
+              for (int i = 0; i < DPL; i++) {
+                const int c = lane + 64 * i;
+                t[j][i] = (sp + j < a.KSp && c < d) ? pp[(int64_t)(sp + j) * plane + c] : 0.f;
+              }
+#pragma unroll
+            for (int j = 0; j < CH; j++)
+#pragma unroll
+              for (int i = 0; i < DPL; i++) acc[i] += t[j][i];
           }
-          v = num / den;
+#pragma unroll
+          for (int i = 0; i < DPL; i++) v[i] = v[i] + acc[i];
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < DPL; i++) {
+          const int c = lane + 64 * i;
+          if (c < d) { s += v[i]; if (writer) a.x_out[(int64_t)row * d + c] = v[i]; }
+        }
+        const float mean = wave_sum(s) / (float)d;          // Burn nn::LayerNorm: biased variance, two passes
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < DPL; i++) {
+          const int c = lane + 64 * i;
+          if (c < d) { const float t = v[i] - mean; q += t * t; }
+        }
+        const float var = wave_sum(q) / (float)d;
+        const float denom = a.ln_inside ? sqrtf(var + a.ln_eps) : (sqrtf(var) + a.ln_eps);
+#pragma unroll
+        for (int i = 0; i < DPL; i++) {
+          const int c = lane + 64 * i;
+          if (c >= k0 && c < k0 + kn) xbuf[r * XLD + (c - k0)] = (v[i] - mean) / denom * gv[i] + bv[i];
         }
       }
-      xs[r * GV_KSL_MAX + kk] = v;
+    } else {
+      for (int e = tid; e < MR * kn; e += 256) {
+        const int r = e / kn, kk = e - r * kn;
+        const int row = r0 + r, k = k0 + kk;
+        float v = 0.f;
+        if (row < n_rows) {
+          if (a.pro == PRO_PLAIN) {
+            v = a.src[(int64_t)row * a.ld_src + k];
+          } else if (a.pro == PRO_GELU) {           // GELU(lin1(x)), mod.rs:377-378, lin1 partials folded here
+            v = gelu_erf(fold_partials(a.src, a.KSp, (int64_t)a.S * a.ld_src, (int64_t)row * a.ld_src + k, a.pbias[k]));
+          } else {                                  // PRO_ATTN: combine the key-chunk partials of cross-attention
+            const int hh = k >> 6, dh = k & 63;
+            const float* ca = a.src + ((int64_t)(row * a.n_head + hh) * a.n_chunks) * CA_STRIDE;
+            float M = -1.0e30f;
+            for (int c = 0; c < a.n_chunks; c++) M = fmaxf(M, ca[c * CA_STRIDE]);
+            float num = 0.f, den = 0.f;
+            for (int c = 0; c < a.n_chunks; c++) {
+              const float wgt = expf(ca[c * CA_STRIDE] - M);
+              num += wgt * ca[c * CA_STRIDE + 2 + dh];
+              den += wgt * ca[c * CA_STRIDE + 1];
+            }
+            v = num / den;
+          }
+        }
+        xbuf[r * XLD + kk] = v;
+      }
     }
     __syncthreads();
+    // ---- main loop ----
     float acc[MR][4];
 #pragma unroll
     for (int r = 0; r < MR; r++) { acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.f; }
-    if (col_ok) {
-      for (int kb = unit * 4; kb < kn; kb += 32) {
-        const float* wp = Wp + (int64_t)kb * a.ldw;
-        const float4 w0 = *reinterpret_cast<const float4*>(wp);
-        const float4 w1 = *reinterpret_cast<const float4*>(wp + a.ldw);
-        const float4 w2 = *reinterpret_cast<const float4*>(wp + 2 * (int64_t)a.ldw);
-        const float4 w3 = *reinterpret_cast<const float4*>(wp + 3 * (int64_t)a.ldw);
+    for (int kb = unit * 4; kb < kn; kb += 64) {
+      if (kb != unit * 4 || r0 != 0) load_pair(kb);   // (the first pair of the first row chunk was prefetched)
 #pragma unroll
-        for (int r = 0; r < MR; r++) {
-          const float4 xv = *reinterpret_cast<const float4*>(&xs[r * GV_KSL_MAX + kb]);
-          acc[r][0] += xv.x * w0.x; acc[r][1] += xv.x * w0.y; acc[r][2] += xv.x * w0.z; acc[r][3] += xv.x * w0.w;
-          acc[r][0] += xv.y * w1.x; acc[r][1] += xv.y * w1.y; acc[r][2] += xv.y * w1.z; acc[r][3] += xv.y * w1.w;
-          acc[r][0] += xv.z * w2.x; acc[r][1] += xv.z * w2.y; acc[r][2] += xv.z * w2.z; acc[r][3] += xv.z * w2.w;
-          acc[r][0] += xv.w * w3.x; acc[r][1] += xv.w * w3.y; acc[r][2] += xv.w * w3.z; acc[r][3] += xv.w * w3.w;
+      for (int hstep = 0; hstep < 2; hstep++) {
+        if (kb + hstep * 32 < kn) {
+#pragma unroll
+          for (int r = 0; r < MR; r++) {
+            const float4 xv = *reinterpret_cast<const float4*>(&xbuf[r * XLD + kb + hstep * 32]);
+            const float4 wa = w[hstep * 4 + 0], wb_ = w[hstep * 4 + 1], wc = w[hstep * 4 + 2], wd = w[hstep * 4 + 3];
+            acc[r][0] += xv.x * wa.x; acc[r][1] += xv.x * wa.y; acc[r][2] += xv.x * wa.z; acc[r][3] += xv.x * wa.w;
+            acc[r][0] += xv.y * wb_.x; acc[r][1] += xv.y * wb_.y; acc[r][2] += xv.y * wb_.z; acc[r][3] += xv.y * wb_.w;
+            acc[r][0] += xv.z * wc.x; acc[r][1] += xv.z * wc.y; acc[r][2] += xv.z * wc.z; acc[r][3] += xv.z * wc.w;
+            acc[r][0] += xv.w * wd.x; acc[r][1] += xv.w * wd.y; acc[r][2] += xv.w * wd.z; acc[r][3] += xv.w * wd.w;
+          }
         }
       }
     }
-    __syncthreads();   // everyone is done reading xs: reuse it as red[4][MR][128]
+    __syncthreads();   // everyone is done reading the input rows: reuse the buffer as red[4][MR][128]
 #pragma unroll
     for (int r = 0; r < MR; r++)
 #pragma unroll
-      for (int c = 0; c < 4; c++) acc[r][c] += __shfl_xor(acc[r][c], 32);
+      for (int c = 0; c < 4; c++) acc[r][c] = xor32_sum(acc[r][c]);
     if (half == 0) {
 #pragma unroll
       for (int r = 0; r < MR; r++)
-        *reinterpret_cast<float4*>(&xs[(wave * MR + r) * GV_CT + c4]) =
+        *reinterpret_cast<float4*>(&xbuf[(wave * MR + r) * GV_CT + c4]) =
             make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
     }
     __syncthreads();
     for (int e = tid; e < MR * GV_CT; e += 256) {
       const int r = e / GV_CT, c = e - r * GV_CT;
       const int row = r0 + r, col = n0 + c;
+      float v = -INFINITY;
       if (row < n_rows && col < a.N) {
-        const float v = (xs[(0 * MR + r) * GV_CT + c] + xs[(1 * MR + r) * GV_CT + c]) +
-                        (xs[(2 * MR + r) * GV_CT + c] + xs[(3 * MR + r) * GV_CT + c]);
+        v = (xbuf[(0 * MR + r) * GV_CT + c] + xbuf[(1 * MR + r) * GV_CT + c]) +
+            (xbuf[(2 * MR + r) * GV_CT + c] + xbuf[(3 * MR + r) * GV_CT + c]);
         a.P[((int64_t)ks * a.S + row) * a.N + col] = v;
+        if constexpr (STATS) { if (a.use_mask) v += a.mask[col]; }   // transcribe.rs:271-275
       }
+      if constexpr (STATS) tilev[r][c] = v;
     }
     __syncthreads();
+    if constexpr (STATS) {
+      // per-tile log-softmax statistics and top-k candidates of each row (one wave per row)
+      for (int r = wave; r < MR; r += 4) {
+        const int row = r0 + r;
+        if (row >= n_rows) continue;
+        float v0 = tilev[r][lane], v1 = tilev[r][lane + 64];
+        const float m = wave_max(fmaxf(v0, v1));
+        const float se = m > -INFINITY ? wave_sum(expf(v0 - m) + expf(v1 - m)) : 0.f;
+        float* ts = a.tstats + ((int64_t)row * gridDim.x + blockIdx.x) * TS_STRIDE;
+        if (lane == 0) { ts[0] = m; ts[1] = se; }
+        for (int j = 0; j < a.topk; j++) {
+          float bv; int bi;
+          if (better(v0, lane, v1, lane + 64)) { bv = v0; bi = lane; } else { bv = v1; bi = lane + 64; }
+          wave_argmax(bv, bi);
+          if (lane == 0) { ts[2 + 2 * j] = bv; ts[3 + 2 * j] = __int_as_float(n0 + bi); }
+          if (bi == lane) v0 = -INFINITY;
+          if (bi == lane + 64) v1 = -INFINITY;
+        }
+      }
+      __syncthreads();
+    }
   }
 }
 
-// ---- masked self-attention over the paged self-KV cache, one wave per (beam, head) ------
+// ---- merge the per-tile statistics of one beam's logits row: log_softmax + top-k ------------------
+__global__ __launch_bounds__(256) void dec_topk_merge_kernel(const int* __restrict__ st, const float* __restrict__ tstats,
+                                                             int n_tiles, int k, int32_t* __restrict__ out_id,
+                                                             float* __restrict__ out_lp, float* __restrict__ row_stats) {
+  __shared__ float redv[4];
+  __shared__ int redi[4];
+  __shared__ float bc[2];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (r >= st[ST_N]) return;
+  const float* ts = tstats + (int64_t)r * n_tiles * TS_STRIDE;
+  float m = -INFINITY;
+  for (int t = tid; t < n_tiles; t += 256) m = fmaxf(m, ts[t * TS_STRIDE]);
+  m = wave_max(m);
+  if (lane == 0) redv[wave] = m;
+  __syncthreads();
+  const float M = fmaxf(fmaxf(redv[0], redv[1]), fmaxf(redv[2], redv[3]));
+  float s = 0.f;
+  for (int t = tid; t < n_tiles; t += 256) {
+    const float mt = ts[t * TS_STRIDE];
+    if (mt > -INFINITY) s += expf(mt - M) * ts[t * TS_STRIDE + 1];
+  }
+  s = wave_sum(s);
+  __syncthreads();
+  if (lane == 0) redv[wave] = s;
+  __syncthreads();
+  if (tid == 0) {
+    bc[0] = logf((redv[0] + redv[1]) + (redv[2] + redv[3]));
+    row_stats[2 * r] = M; row_stats[2 * r + 1] = bc[0];
+  }
+  // local top-k over this thread's candidates (value desc, id asc)
+  float tv[TOPK_MAX]; int ti[TOPK_MAX];
+#pragma unroll
+  for (int j = 0; j < TOPK_MAX; j++) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
+  for (int c = tid; c < n_tiles * k; c += 256) {
+    const int t = c / k, j = c - t * k;
+    float cv = ts[t * TS_STRIDE + 2 + 2 * j]; int ci = __float_as_int(ts[t * TS_STRIDE + 3 + 2 * j]);
+    if (cv > -INFINITY) {
+#pragma unroll
+      for (int q = 0; q < TOPK_MAX; q++)
+        if (better(cv, ci, tv[q], ti[q])) { float a = tv[q]; int b = ti[q]; tv[q] = cv; ti[q] = ci; cv = a; ci = b; }
+    }
+  }
+  __syncthreads();
+  const float lse = bc[0];
+  for (int round = 0; round < k; round++) {
+    float bv = tv[0]; int bi = ti[0];
+    wave_argmax(bv, bi);
+    __syncthreads();
+    if (lane == 0) { redv[wave] = bv; redi[wave] = bi; }
+    __syncthreads();
+    float gv = redv[0]; int gi = redi[0];
+    for (int j = 1; j < 4; j++)
+      if (better(redv[j], redi[j], gv, gi)) { gv = redv[j]; gi = redi[j]; }
+    if (tid == 0) {
+      out_id[r * TOPK_MAX + round] = gi;
+      out_lp[r * TOPK_MAX + round] = (gv - M) - lse;   // log_softmax, transcribe.rs:276
+    }
+    if (ti[0] == gi) {   // the winner pops its head
+#pragma unroll
+      for (int j = 0; j < TOPK_MAX - 1; j++) { tv[j] = tv[j + 1]; ti[j] = ti[j + 1]; }
+      tv[TOPK_MAX - 1] = -INFINITY; ti[TOPK_MAX - 1] = 0x7fffffff;
+    }
+  }
+}
+
+// ---- masked self-attention over the paged self-KV cache, one block per (beam, head) --------------
 constexpr int SA_MAXPOS = 448;
-__global__ __launch_bounds__(64) void dec_self_attn_kernel(const int* __restrict__ st, StepLayout lay,
-                                                           const float* __restrict__ Pqkv, int KS,
-                                                           const float* __restrict__ bqkv, int d,
-                                                           float* __restrict__ Kc, float* __restrict__ Vc,
-                                                           const int* __restrict__ tab, int Lmax, float scale,
-                                                           float* __restrict__ att) {
-  __shared__ __attribute__((aligned(16))) float qs[64];
-  __shared__ __attribute__((aligned(16))) float knew[64];
-  __shared__ float vnew[64];
+__global__ __launch_bounds__(256) void dec_self_attn_kernel(const int* __restrict__ st, StepLayout lay,
+                                                            const float* __restrict__ Pqkv, int KS,
+                                                            const float* __restrict__ bqkv, int d,
+                                                            float* __restrict__ Kc, float* __restrict__ Vc,
+                                                            const int* __restrict__ tabs, int Lmax, float scale,
+                                                            float* __restrict__ att) {
+  __shared__ __attribute__((aligned(16))) float qkv[3][64];   // q*s, k*s, v of the new token
+  __shared__ int tbs[SA_MAXPOS];
   __shared__ float ps[SA_MAXPOS];
-  const int i = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+  __shared__ float red[8];
+  __shared__ float ored[4][64];
+  const int i = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (i >= st[ST_N]) return;
   const int len = st[lay.len + i];
-  const int col = h * 64 + lane;
-  // fold the QKV partials: q = (xWq + bq) * s, k = (xWk) * s, v = xWv + bv  (mod.rs:429-431, :506-514)
-  float q = bqkv[col], k = bqkv[d + col], v = bqkv[2 * d + col];
-  for (int s = 0; s < KS; s++) {
-    const float* p = Pqkv + ((int64_t)s * lay.S + i) * (3 * d);
-    q += p[col]; k += p[d + col]; v += p[2 * d + col];
+  const int* tb = tabs + (size_t)(st[ST_STEP] & 1) * lay.S * Lmax + i * Lmax;
+  for (int p = tid; p < len; p += 256) tbs[p] = tb[p];
+  if (tid < 192) {   // fold the QKV partials: q = (xWq + bq) * s, k = (xWk) * s, v = xWv + bv  (mod.rs:429-431, :506-514)
+    const int which = tid >> 6, col = which * d + h * 64 + lane;
+    float v = fold_partials(Pqkv, KS, (int64_t)lay.S * 3 * d, (int64_t)i * 3 * d + col, bqkv[col]);
+    if (which < 2) v *= scale;
+    qkv[which][lane] = v;
   }
-  q *= scale; k *= scale;
-  const int* tb = tab + i * Lmax;
-  const int newrow = tb[len - 1];
-  Kc[(int64_t)newrow * d + col] = k;
-  Vc[(int64_t)newrow * d + col] = v;
-  qs[lane] = q; knew[lane] = k; vnew[lane] = v;
   __syncthreads();
-  constexpr int NPL = SA_MAXPOS / 64;
-  float sc[NPL];
+  if (tid >= 64 && tid < 192) {   // append to the cache
+    const int which = tid >> 6;
+    float* dst = (which == 1 ? Kc : Vc) + (int64_t)tbs[len - 1] * d + h * 64 + lane;
+    *dst = qkv[which][lane];
+  }
+  // scores: one position per thread (len <= 448 -> at most 2 passes)
+  float sc[2];
   float m = -INFINITY;
 #pragma unroll
-  for (int j = 0; j < NPL; j++) {
-    const int p = lane + j * 64;
+  for (int j = 0; j < 2; j++) {
+    const int p = tid + j * 256;
     sc[j] = -INFINITY;
     if (p < len) {
       float acc = 0.f;
       if (p == len - 1) {
 #pragma unroll
-        for (int c = 0; c < 64; c++) acc += qs[c] * knew[c];
+        for (int c = 0; c < 64; c++) acc += qkv[0][c] * qkv[1][c];
       } else {
-        const float4* kr = reinterpret_cast<const float4*>(Kc + (int64_t)tb[p] * d + h * 64);
+        const float4* kr = reinterpret_cast<const float4*>(Kc + (int64_t)tbs[p] * d + h * 64);
+        float4 kv[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) kv[c] = kr[c];
 #pragma unroll
         for (int c = 0; c < 16; c++) {
-          const float4 kv = kr[c];
-          const float4 qv = *reinterpret_cast<const float4*>(&qs[4 * c]);
-          acc += qv.x * kv.x + qv.y * kv.y + qv.z * kv.z + qv.w * kv.w;
+          const float4 qv = *reinterpret_cast<const float4*>(&qkv[0][4 * c]);
+          acc += qv.x * kv[c].x + qv.y * kv[c].y + qv.z * kv[c].z + qv.w * kv[c].w;
         }
       }
       sc[j] = acc;
       m = fmaxf(m, acc);
     }
   }
+  // this thread's V column for positions p = wave (mod 4): issued before the softmax reductions
+  const int col = h * 64 + lane;
+  float vpre[28];
+#pragma unroll
+  for (int i = 0; i < 28; i++) {
+    const int p = wave + 4 * i;
+    vpre[i] = p < len - 1 ? Vc[(int64_t)tbs[p] * d + col] : 0.f;
+  }
   m = wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   float l = 0.f;
 #pragma unroll
-  for (int j = 0; j < NPL; j++) {
-    const int p = lane + j * 64;
-    if (p < len) {
-      const float e = expf(sc[j] - m);
-      ps[p] = e;
-      l += e;
-    }
+  for (int j = 0; j < 2; j++) {
+    const int p = tid + j * 256;
+    if (p < len) { const float e = expf(sc[j] - m); ps[p] = e; l += e; }
   }
   l = wave_sum(l);
+  if (lane == 0) red[4 + wave] = l;
   __syncthreads();
+  l = (red[4] + red[5]) + (red[6] + red[7]);
+  // o[dh] = sum_p ps[p] V[p][dh]: wave g takes positions p = g (mod 4), four loads in flight
   float o = 0.f;
-  for (int p = 0; p < len - 1; p++) o += ps[p] * Vc[(int64_t)tb[p] * d + col];
-  o += ps[len - 1] * vnew[lane];
-  att[(int64_t)i * d + col] = o / l;
+#pragma unroll
+  for (int i = 0; i < 28; i++) {
+    const int p = wave + 4 * i;
+    if (p < len - 1) o += ps[p] * vpre[i];
+  }
+  for (int p = wave + 4 * 28; p < len - 1; p += 4) o += ps[p] * Vc[(int64_t)tbs[p] * d + col];   // len > 112
+  if (wave == ((len - 1) & 3)) o += ps[len - 1] * qkv[2][lane];
+  ored[wave][lane] = o;
+  __syncthreads();
+  if (tid < 64) att[(int64_t)i * d + col] = ((ored[0][lane] + ored[1][lane]) + (ored[2][lane] + ored[3][lane])) / l;
 }
 
 // ---- cross-attention over one key chunk of one window's cached K/V, all of its beams -----
 constexpr int CA_CH = 128;   // keys per chunk
+template <int NB>            // register-resident beams per window (>= the largest live count this step)
 __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const int* __restrict__ st, StepLayout lay,
                                                              const float* __restrict__ Pq, int KS,
                                                              const float* __restrict__ bq, int d,
@@ -303,35 +506,46 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const int* __restri
     }
     return;
   }
+  const float* Kb = ckv + (int64_t)(win_row0[w] + j0) * ldkv + koff + h * 64;   // K pre-scaled at projection time
+  const float* Vb = Kb + d;
+  // issue the K tile and this thread's V column first; the q fold rides under their latency
+  float4 kreg[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int e = tid + i * 256, r = e >> 4, q4 = (e & 15) * 4;
+    kreg[i] = r < nk ? *reinterpret_cast<const float4*>(Kb + (int64_t)r * ldkv + q4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int dh_t = tid & 63, gq = tid >> 6;
+  float vreg[32];
+#pragma unroll
+  for (int i = 0; i < 32; i++) {
+    const int j = gq * 32 + i;
+    vreg[i] = j < nk ? Vb[(int64_t)j * ldkv + dh_t] : 0.f;
+  }
   // q = (x Wq + bq) * s  (mod.rs:483, :506-509)
   for (int e = tid; e < nb * 64; e += 256) {
     const int b = e >> 6, dh = e & 63, col = h * 64 + dh;
-    float q = bq[col];
-    for (int s = 0; s < KS; s++) q += Pq[((int64_t)s * lay.S + slots[b]) * d + col];
-    qs[b][dh] = q * scale;
+    qs[b][dh] = fold_partials(Pq, KS, (int64_t)lay.S * d, (int64_t)slots[b] * d + col, bq[col]) * scale;
   }
-  const float* Kb = ckv + (int64_t)(win_row0[w] + j0) * ldkv + koff + h * 64;   // K pre-scaled at projection time
-  const float* Vb = Kb + d;
-  for (int e = tid; e < CA_CH * 16; e += 256) {
-    const int r = e >> 4, q4 = (e & 15) * 4;
-    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < nk) kv = *reinterpret_cast<const float4*>(Kb + (int64_t)r * ldkv + q4);
-    Kt[r][q4 + 0] = kv.x; Kt[r][q4 + 1] = kv.y; Kt[r][q4 + 2] = kv.z; Kt[r][q4 + 3] = kv.w;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int e = tid + i * 256, r = e >> 4, q4 = (e & 15) * 4;
+    Kt[r][q4 + 0] = kreg[i].x; Kt[r][q4 + 1] = kreg[i].y; Kt[r][q4 + 2] = kreg[i].z; Kt[r][q4 + 3] = kreg[i].w;
   }
   __syncthreads();
   {
     const int j = tid & (CA_CH - 1), hf = tid >> 7;
-    float acc[MAX_BEAMS];
+    float acc[NB];
 #pragma unroll
-    for (int b = 0; b < MAX_BEAMS; b++) acc[b] = 0.f;
+    for (int b = 0; b < NB; b++) acc[b] = 0.f;
 #pragma unroll 8
     for (int dh = hf * 32; dh < hf * 32 + 32; dh++) {
       const float kv = Kt[j][dh];
 #pragma unroll
-      for (int b = 0; b < MAX_BEAMS; b++) acc[b] += qs[b][dh] * kv;   // rows b >= nb hold stale q: never read back
+      for (int b = 0; b < NB; b++) acc[b] += qs[b][dh] * kv;   // rows b >= nb hold stale q: never read back
     }
 #pragma unroll
-    for (int b = 0; b < MAX_BEAMS; b++) sp[hf][b][j] = acc[b];
+    for (int b = 0; b < NB; b++) sp[hf][b][j] = acc[b];
   }
   __syncthreads();
   {
@@ -349,18 +563,17 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const int* __restri
   }
   __syncthreads();
   {
-    const int dh = tid & 63, gq = tid >> 6;
-    float o[MAX_BEAMS];
+    float o[NB];
 #pragma unroll
-    for (int b = 0; b < MAX_BEAMS; b++) o[b] = 0.f;
-    const int jb = gq * 32, je = min(jb + 32, nk);
-    for (int j = jb; j < je; j++) {
-      const float vv = Vb[(int64_t)j * ldkv + dh];
+    for (int b = 0; b < NB; b++) o[b] = 0.f;
 #pragma unroll
-      for (int b = 0; b < MAX_BEAMS; b++) o[b] += pb[b][j] * vv;
+    for (int i = 0; i < 32; i++) {
+      const int j = gq * 32 + i;
+#pragma unroll
+      for (int b = 0; b < NB; b++) o[b] += (b < nb ? pb[b][j] : 0.f) * vreg[i];   // rows past nk carry p = 0 / v = 0
     }
 #pragma unroll
-    for (int b = 0; b < MAX_BEAMS; b++) ored[gq][b][dh] = o[b];
+    for (int b = 0; b < NB; b++) ored[gq][b][dh_t] = o[b];
   }
   __syncthreads();
   for (int e = tid; e < nb * 64; e += 256) {
@@ -368,97 +581,6 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const int* __restri
     float* dst = ca + ((int64_t)(slots[b] * n_head + h) * n_chunks + c) * CA_STRIDE;
     dst[2 + dh] = (ored[0][b][dh] + ored[1][b][dh]) + (ored[2][b][dh] + ored[3][b][dh]);
     if (dh == 0) { dst[0] = stat[b][0]; dst[1] = stat[b][1]; }
-  }
-}
-
-// ---- mask + log_softmax + top-k of one beam's logits row (transcribe.rs:271-304) ---------
-struct Cand { float v; int id; };
-__device__ __forceinline__ bool better(float v, int id, float bv, int bid) {
-  return v > bv || (v == bv && id < bid);
-}
-
-__global__ __launch_bounds__(1024) void dec_topk_kernel(const int* __restrict__ st, const float* __restrict__ logits,
-                                                         int KS, int64_t plane, int V,
-                                                         const float* __restrict__ mask, int use_mask,
-                                                         int k, int32_t* __restrict__ out_id,
-                                                         float* __restrict__ out_lp, float* __restrict__ row_stats) {
-  __shared__ float redv[16];
-  __shared__ int redi[16];
-  __shared__ float bc[2];
-  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (r >= st[ST_N]) return;
-  const float* x = logits + (int64_t)r * V;
-  float tv[TOPK_MAX];
-  int ti[TOPK_MAX];
-#pragma unroll
-  for (int j = 0; j < TOPK_MAX; j++) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
-  float m = -INFINITY;
-  for (int c = tid; c < V; c += 1024) {
-    float v = x[c];
-    for (int s2 = 1; s2 < KS; s2++) v += x[(int64_t)s2 * plane + c];   // K-split logits partials, fixed order
-    if (use_mask) v += mask[c];
-    m = fmaxf(m, v);
-    // sorted insertion, (value desc, id asc); ids arrive ascending so equal values never displace
-    if (v > tv[TOPK_MAX - 1]) {
-      float cv = v; int ci = c;
-#pragma unroll
-      for (int j = 0; j < TOPK_MAX; j++) {
-        if (cv > tv[j]) { float t = tv[j]; int u = ti[j]; tv[j] = cv; ti[j] = ci; cv = t; ci = u; }
-      }
-    }
-  }
-  m = wave_max(m);
-  if (lane == 0) redv[wave] = m;
-  __syncthreads();
-  if (tid == 0) {
-    float mm = redv[0];
-    for (int j = 1; j < 16; j++) mm = fmaxf(mm, redv[j]);
-    bc[0] = mm;
-  }
-  __syncthreads();
-  const float M = bc[0];
-  float s = 0.f;
-  for (int c = tid; c < V; c += 1024) {
-    float v = x[c];
-    for (int s2 = 1; s2 < KS; s2++) v += x[(int64_t)s2 * plane + c];
-    if (use_mask) v += mask[c];
-    s += expf(v - M);
-  }
-  s = wave_sum(s);
-  __syncthreads();
-  if (lane == 0) redv[wave] = s;
-  __syncthreads();
-  if (tid == 0) {
-    float ss = 0.f;
-    for (int j = 0; j < 16; j++) ss += redv[j];
-    bc[1] = logf(ss);
-    row_stats[2 * r] = M; row_stats[2 * r + 1] = bc[1];
-  }
-  __syncthreads();
-  const float lse = bc[1];
-  // k rounds of block-wide argmax over the threads' list heads
-  for (int round = 0; round < k; round++) {
-    float bv = tv[0]; int bi = ti[0];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
-      if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
-    }
-    __syncthreads();
-    if (lane == 0) { redv[wave] = bv; redi[wave] = bi; }
-    __syncthreads();
-    float gv = redv[0]; int gi = redi[0];
-    for (int j = 1; j < 16; j++)
-      if (better(redv[j], redi[j], gv, gi)) { gv = redv[j]; gi = redi[j]; }
-    if (tid == 0) {
-      out_id[r * TOPK_MAX + round] = gi;
-      out_lp[r * TOPK_MAX + round] = (gv - M) - lse;   // log_softmax, transcribe.rs:276
-    }
-    if (ti[0] == gi) {   // the winner pops its head
-#pragma unroll
-      for (int j = 0; j < TOPK_MAX - 1; j++) { tv[j] = tv[j + 1]; ti[j] = ti[j + 1]; }
-      tv[TOPK_MAX - 1] = -INFINITY; ti[TOPK_MAX - 1] = 0x7fffffff;
-    }
   }
 }
 
@@ -475,61 +597,85 @@ __global__ void dec_logprob_row_kernel(const float* __restrict__ x, int KS, int6
 
 }  // namespace
 
-void launch_dec_prepare(hipStream_t st, const int* state, const StepLayout& lay, int n_max, const int* tab_old,
-                        int* tab_new, int Lmax, const float* E, const float* pos, int d, float* x) {
-  hipLaunchKernelGGL(dec_prepare_kernel, dim3(n_max), dim3(128), 0, st, state, lay, tab_old, tab_new, Lmax, E, pos, d,
-                     x);
+void launch_dec_prepare(hipStream_t st, const int* state_host_mapped, int* state_dev, const StepLayout& lay, int n,
+                        int* tabs, int Lmax, const float* E, const float* pos, int d, float* x) {
+  hipLaunchKernelGGL(dec_prepare_kernel, dim3(n), dim3(128), 0, st, state_host_mapped, state_dev, lay, tabs, Lmax, E, pos,
+                     d, x);
 }
 
-void launch_dec_resolve_ln(hipStream_t st, const int* state, int n_max, float* x, const float* P, int KS, int S,
-                           const float* bias, int d, const LayerNormW& ln, int eps_inside_sqrt, float* h) {
+void launch_dec_resolve_ln(hipStream_t st, const int* state, int n_max, const float* x_in, float* x_out,
+                           const float* P, int KS, int S, const float* bias, int d, const LayerNormW& ln,
+                           int eps_inside_sqrt, float* h) {
   if (d <= 1024)
-    hipLaunchKernelGGL(dec_resolve_ln_kernel<4>, dim3(n_max), dim3(256), 0, st, state, x, P, KS, S, bias, d, ln.g,
-                       ln.b, ln.eps, eps_inside_sqrt, h);
+    hipLaunchKernelGGL(dec_resolve_ln_kernel<4>, dim3(n_max), dim3(256), 0, st, state, x_in, x_out, P, KS, S, bias, d,
+                       ln.g, ln.b, ln.eps, eps_inside_sqrt, h);
   else
-    hipLaunchKernelGGL(dec_resolve_ln_kernel<8>, dim3(n_max), dim3(256), 0, st, state, x, P, KS, S, bias, d, ln.g,
-                       ln.b, ln.eps, eps_inside_sqrt, h);
+    hipLaunchKernelGGL(dec_resolve_ln_kernel<8>, dim3(n_max), dim3(256), 0, st, state, x_in, x_out, P, KS, S, bias, d,
+                       ln.g, ln.b, ln.eps, eps_inside_sqrt, h);
 }
 
 void gemv_plan(int K, int N, int* KS, int* KSL) {
-  // slices of >= 64 rows, <= GV_KSL_MAX, at most 16 partials, aiming at >= ~512 blocks
+  // slices of >= 64 rows, <= GV_KSL_MAX, at most KS_MAX partials, aiming at >= ~512 blocks
   const int tiles = (N + GV_CT - 1) / GV_CT;
-  int ks = std::max(1, std::min(16, 512 / std::max(tiles, 1)));
+  int ks = std::max(1, std::min(KS_MAX, 512 / std::max(tiles, 1)));
   ks = std::min(ks, std::max(1, K / 64));
   int ksl = ((K + ks - 1) / ks + 31) / 32 * 32;
-  if (ksl > GV_KSL_MAX) { ksl = GV_KSL_MAX; }
+  if (ksl > GV_KSL_MAX) ksl = GV_KSL_MAX;
   ks = (K + ksl - 1) / ksl;
   *KS = ks; *KSL = ksl;
 }
 
-void launch_dec_gemv(hipStream_t st, const GemvArgs& a, int n_rows_hint) {
+template <int MR, int XLD, bool LN, bool STATS>
+static void launch_gemv_dpl(hipStream_t st, dim3 grid, const GemvArgs& a) {
+  if (!LN) { hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, 1, LN, STATS>), grid, dim3(256), 0, st, a); return; }
+  if (a.K <= 384) hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, LN ? 6 : 1, LN, STATS>), grid, dim3(256), 0, st, a);
+  else if (a.K <= 512) hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, LN ? 8 : 1, LN, STATS>), grid, dim3(256), 0, st, a);
+  else if (a.K <= 768) hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, LN ? 12 : 1, LN, STATS>), grid, dim3(256), 0, st, a);
+  else if (a.K <= 1024) hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, LN ? 16 : 1, LN, STATS>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, LN ? 20 : 1, LN, STATS>), grid, dim3(256), 0, st, a);
+}
+
+void launch_dec_gemv(hipStream_t st, const GemvArgs& a, int n_rows_hint, bool stats) {
   dim3 grid((a.N + GV_CT - 1) / GV_CT, a.KS);
-  if (n_rows_hint <= 4)
-    hipLaunchKernelGGL(dec_gemv_kernel<4>, grid, dim3(256), 0, st, a);
-  else if (n_rows_hint <= 8)
-    hipLaunchKernelGGL(dec_gemv_kernel<8>, grid, dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL(dec_gemv_kernel<16>, grid, dim3(256), 0, st, a);
+  const bool ln = a.pro == PRO_LN;
+  if (stats) {   // logits: LN prologue over whole rows + tile statistics; rows chunked by <= 8
+    if (n_rows_hint <= 4) launch_gemv_dpl<4, DMAX, true, true>(st, grid, a);
+    else launch_gemv_dpl<8, DMAX, true, true>(st, grid, a);
+  } else if (ln) {
+    if (n_rows_hint <= 4) launch_gemv_dpl<4, GV_KSL_MAX, true, false>(st, grid, a);
+    else launch_gemv_dpl<8, GV_KSL_MAX, true, false>(st, grid, a);
+  } else {
+    if (n_rows_hint <= 4) launch_gemv_dpl<4, GV_KSL_MAX, false, false>(st, grid, a);
+    else if (n_rows_hint <= 8) launch_gemv_dpl<8, GV_KSL_MAX, false, false>(st, grid, a);
+    else launch_gemv_dpl<16, GV_KSL_MAX, false, false>(st, grid, a);
+  }
 }
 
 void launch_dec_self_attn(hipStream_t st, const int* state, const StepLayout& lay, int n_max, int n_head,
                           const float* Pqkv, int KS, const float* bqkv, int d, float* Kc, float* Vc, const int* tab,
                           int Lmax, float scale, float* att) {
-  hipLaunchKernelGGL(dec_self_attn_kernel, dim3(n_max, n_head), dim3(64), 0, st, state, lay, Pqkv, KS, bqkv, d, Kc, Vc,
+  hipLaunchKernelGGL(dec_self_attn_kernel, dim3(n_max, n_head), dim3(256), 0, st, state, lay, Pqkv, KS, bqkv, d, Kc, Vc,
                      tab, Lmax, scale, att);
 }
 
 void launch_dec_cross_attn(hipStream_t st, const int* state, const StepLayout& lay, int n_windows, int n_head,
                            int n_chunks, const float* Pq, int KS, const float* bq, int d, const float* ckv, int ldkv,
-                           int koff, const int* win_row0, const int* win_C, float scale, float* ca) {
-  hipLaunchKernelGGL(dec_cross_attn_kernel, dim3(n_chunks, n_head, n_windows), dim3(256), 0, st, state, lay, Pq, KS, bq,
-                     d, ckv, ldkv, koff, win_row0, win_C, scale, n_head, n_chunks, ca);
+                           int koff, const int* win_row0, const int* win_C, float scale, float* ca, int max_nb) {
+  dim3 grid(n_chunks, n_head, n_windows);
+#define WB_CA(NB_)                                                                                                   \
+  hipLaunchKernelGGL(dec_cross_attn_kernel<NB_>, grid, dim3(256), 0, st, state, lay, Pq, KS, bq, d, ckv, ldkv, koff, \
+                     win_row0, win_C, scale, n_head, n_chunks, ca)
+  if (max_nb <= 1) WB_CA(1);
+  else if (max_nb <= 2) WB_CA(2);
+  else if (max_nb <= 4) WB_CA(4);
+  else WB_CA(8);
+#undef WB_CA
 }
 
-void launch_dec_topk(hipStream_t st, const int* state, int n_max, const float* logits, int KS, int64_t plane, int V,
-                     const float* mask, int use_mask, int k, int32_t* out_id, float* out_lp, float* row_stats) {
-  hipLaunchKernelGGL(dec_topk_kernel, dim3(n_max), dim3(1024), 0, st, state, logits, KS, plane, V, mask, use_mask, k,
-                     out_id, out_lp, row_stats);
+void launch_dec_topk_merge(hipStream_t st, const int* state, int n_max, const float* tstats, int n_tiles, int k,
+                           int32_t* out_id, float* out_lp, float* row_stats) {
+  hipLaunchKernelGGL(dec_topk_merge_kernel, dim3(n_max), dim3(256), 0, st, state, tstats, n_tiles, k, out_id, out_lp,
+                     row_stats);
 }
 
 void launch_dec_logprob_row(hipStream_t st, const float* x, int KS, int64_t plane, int V, const float* mask,

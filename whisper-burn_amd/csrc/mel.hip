@@ -19,6 +19,7 @@
 #include <cstring>
 
 #include "kernels.h"
+#include "wave_ops.h"
 
 namespace wb {
 
@@ -194,8 +195,7 @@ __global__ __launch_bounds__(MEL_THREADS) void mel_spectrogram_kernel(
     if (f0 + 2 * p < w.n_frames) lmax = fmaxf(lmax, va);
     if (f0 + 2 * p + 1 < w.n_frames) lmax = fmaxf(lmax, vb);
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+  lmax = wave_max(lmax);
   if ((tid & 63) == 0 && lmax > -INFINITY) atomic_max_float(&gmax[blockIdx.y], lmax);
   __syncthreads();
   // ---- stage 5: coalesced store of the [80][32] tile ----

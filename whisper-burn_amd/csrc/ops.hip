@@ -2,15 +2,10 @@
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
+#include "wave_ops.h"
 
 namespace wb {
 namespace {
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
 
 // One wave per row.  Burn 0.9 nn::LayerNorm (used at /root/reference/src/model/mod.rs:155, :259,
 // :300-301, :346-348): biased variance over the last dim, (x - mu) / (sqrt(var) + eps) * g + b;

@@ -153,6 +153,7 @@ int session_reserve(wb_session* s, int max_len) {
   wb_model* m = s->m;
   const wb_dims& D = m->dims;
   const int d = D.n_text_state, NL = D.n_text_layer, V = D.n_vocab, S = s->S;
+  WB_REQUIRE(d <= 1280, WB_ERR_SHAPE, "decode kernels keep whole rows in LDS: n_state %d > 1280", d);
   max_len = std::max(8, std::min(max_len, std::min(D.n_text_ctx, 448)));
   s->Lmax = max_len;
   const size_t pool = (size_t)max_len * S;
@@ -161,18 +162,25 @@ int session_reserve(wb_session* s, int max_len) {
   WB_TRY(s->tabs.ensure((size_t)2 * S * max_len * 4));
   s->lay = make_step_layout(S, s->W);
   WB_TRY(s->state.ensure((size_t)s->lay.total * 4));
-  if (s->state_host) { (void)hipHostFree(s->state_host); s->state_host = nullptr; }
-  if (s->topk_id_host) { (void)hipHostFree(s->topk_id_host); s->topk_id_host = nullptr; }
-  if (s->topk_lp_host) { (void)hipHostFree(s->topk_lp_host); s->topk_lp_host = nullptr; }
-  WB_HIP(hipHostMalloc((void**)&s->state_host, (size_t)s->lay.total * 4, hipHostMallocDefault));
-  WB_HIP(hipHostMalloc((void**)&s->topk_id_host, (size_t)S * TOPK_MAX * 4, hipHostMallocDefault));
-  WB_HIP(hipHostMalloc((void**)&s->topk_lp_host, (size_t)S * TOPK_MAX * 4, hipHostMallocDefault));
+  // step state and top-k results live in mapped pinned host memory: the prepare kernel pulls the
+  // state over PCIe, the merge kernel pushes the k (id, log-prob) pairs -- no copy launches per step
+  const size_t host_bytes = (size_t)s->lay.total * 4 + (size_t)S * TOPK_MAX * 8;
+  if (s->host_bytes < host_bytes) {
+    if (s->host_block) { (void)hipHostFree(s->host_block); s->host_block = nullptr; s->host_bytes = 0; }
+    WB_HIP(hipHostMalloc((void**)&s->host_block, host_bytes, hipHostMallocMapped));
+    s->host_bytes = host_bytes;
+  }
+  WB_HIP(hipHostGetDevicePointer((void**)&s->host_block_dev, s->host_block, 0));
+  s->state_host = reinterpret_cast<int*>(s->host_block);
+  s->topk_id_host = reinterpret_cast<int32_t*>(s->host_block + (size_t)s->lay.total * 4);
+  s->topk_lp_host = reinterpret_cast<float*>(s->host_block + (size_t)s->lay.total * 4 + (size_t)S * TOPK_MAX * 4);
   gemv_plan(d, 3 * d, &s->ks_qkv, &s->ksl_qkv);
   gemv_plan(d, d, &s->ks_o, &s->ksl_o);
   gemv_plan(d, 4 * d, &s->ks_1, &s->ksl_1);
   gemv_plan(4 * d, d, &s->ks_2, &s->ksl_2);
-  gemv_plan(d, V, &s->ks_v, &s->ksl_v);
-  WB_TRY(s->x.ensure((size_t)S * d * 4));
+  s->ks_v = 1; s->ksl_v = d;                    // logits: whole rows per block (tile statistics need complete sums)
+  s->n_tiles_v = (V + GV_CT - 1) / GV_CT;
+  WB_TRY(s->x.ensure((size_t)2 * S * d * 4));   // residual stream, ping-pong
   WB_TRY(s->h.ensure((size_t)S * d * 4));
   WB_TRY(s->att.ensure((size_t)S * d * 4));
   WB_TRY(s->Pqkv.ensure((size_t)s->ks_qkv * S * 3 * d * 4));
@@ -181,9 +189,8 @@ int session_reserve(wb_session* s, int max_len) {
   WB_TRY(s->P1.ensure((size_t)s->ks_1 * S * 4 * d * 4));
   WB_TRY(s->P2.ensure((size_t)s->ks_2 * S * d * 4));
   WB_TRY(s->ca.ensure((size_t)S * D.n_text_head * std::max(1, s->n_chunks) * CA_STRIDE * 4));
-  WB_TRY(s->logits.ensure((size_t)s->ks_v * S * V * 4));
-  WB_TRY(s->topk_id.ensure((size_t)S * TOPK_MAX * 4));
-  WB_TRY(s->topk_lp.ensure((size_t)S * TOPK_MAX * 4));
+  WB_TRY(s->logits.ensure((size_t)S * V * 4));
+  WB_TRY(s->tstats.ensure((size_t)S * s->n_tiles_v * TS_STRIDE * 4));
   WB_TRY(s->row_stats.ensure((size_t)S * 2 * 4));
   WB_TRY(s->lp_tmp.ensure((size_t)V * 4));
   s->decode_ready = true;
@@ -192,10 +199,14 @@ int session_reserve(wb_session* s, int max_len) {
 
 }  // namespace wb
 
+void wb_session::clear_graphs() {
+  for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
+  graphs.clear();
+}
+
 wb_session::~wb_session() {
-  if (state_host) (void)hipHostFree(state_host);
-  if (topk_id_host) (void)hipHostFree(topk_id_host);
-  if (topk_lp_host) (void)hipHostFree(topk_lp_host);
+  clear_graphs();
+  if (host_block) (void)hipHostFree(host_block);
   if (st) (void)hipStreamDestroy(st);
 }
 
@@ -268,12 +279,109 @@ int wb_session_set_special_mask(wb_session* s, const uint8_t* is_special) {
   return WB_OK;
 }
 
+// Enqueue the kernels of one decode step on `st`.  Everything that changes from step to step (token
+// ids, parents, lengths, the live-beam count, table parity) is read by the kernels from the step
+// state, so for a given (row bucket, k, mask, fuse) the launch sequence is identical every step and
+// can be captured once into a hipGraph and replayed.
+static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool fuse_ln, int max_nb, bool timed) {
+  wb_model* m = s->m;
+  const wb_dims& D = m->dims;
+  const int d = D.n_text_state, H = D.n_text_head, NL = D.n_text_layer, V = D.n_vocab, S = s->S;
+  const StepLayout& L = s->lay;
+  hipStream_t st = s->st;
+  const int* hst = reinterpret_cast<const int*>(s->host_block_dev);           // mapped view of state_host
+  int32_t* out_id_dev = reinterpret_cast<int32_t*>(s->host_block_dev + (size_t)L.total * 4);
+  float* out_lp_dev = reinterpret_cast<float*>(s->host_block_dev + (size_t)L.total * 4 + (size_t)S * TOPK_MAX * 4);
+  const int* dst = s->state.as<int>();
+  int* tabs = s->tabs.as<int>();
+  float* xb[2] = {s->x.as<float>(), s->x.as<float>() + (size_t)S * d};
+  int xi = 0;                                     // xb[xi] holds the current residual stream
+  float *h = s->h.as<float>(), *att = s->att.as<float>();
+  const size_t pool = (size_t)s->Lmax * S;
+  const int ldkv = NL * 2 * d;
+  const int* win_row0 = s->win_meta.as<int>();
+  const int* win_C = win_row0 + s->W;
+  const int n = n_launch;
+
+  launch_dec_prepare(st, hst, s->state.as<int>(), L, n, tabs, s->Lmax, m->tok_emb, m->dec_pos, d, xb[0]);
+  auto gemv = [&](const LinearW& w, int ks, int ksl, int pro, const float* src, int ld_src, float* P) {
+    GemvArgs a;
+    a.W = w.w; a.ldw = w.n; a.K = w.k; a.N = w.n; a.KS = ks; a.KSL = ksl; a.pro = pro; a.src = src; a.ld_src = ld_src;
+    a.P = P; a.st = dst; a.S = S;
+    return a;
+  };
+  // y = W . LN(x + pending): folds the pending sublayer output into the residual stream (ping-pong),
+  // normalises, multiplies -- in one launch when few beams are live
+  auto ln_gemv = [&](GemvArgs a, const float* pend, int ks_pend, const float* pbias, const LayerNormW& ln, bool stats) {
+    a.ln_g = ln.g; a.ln_b = ln.b; a.ln_eps = ln.eps; a.ln_inside = m->ln_eps_inside_sqrt;
+    if (fuse_ln) {
+      a.pro = PRO_LN; a.src = xb[xi]; a.ld_src = d; a.pend = pend; a.KSp = ks_pend; a.pbias = pbias; a.x_out = xb[xi ^ 1];
+      launch_dec_gemv(st, a, n, stats);
+      xi ^= 1;
+    } else if (stats) {
+      // the tile-statistics kernel is an LN-prologue instantiation: fold in its own launch first
+      launch_dec_resolve_ln(st, dst, n, xb[xi], xb[xi ^ 1], pend, ks_pend, S, pbias, d, ln, m->ln_eps_inside_sqrt, h);
+      a.pro = PRO_LN; a.src = xb[xi ^ 1]; a.ld_src = d; a.pend = nullptr; a.KSp = 0; a.pbias = nullptr; a.x_out = xb[xi];
+      launch_dec_gemv(st, a, n, true);            // (re-writes the same stream into the other buffer)
+    } else {
+      launch_dec_resolve_ln(st, dst, n, xb[xi], xb[xi ^ 1], pend, ks_pend, S, pbias, d, ln, m->ln_eps_inside_sqrt, h);
+      a.pro = PRO_PLAIN; a.src = h; a.ld_src = d;
+      launch_dec_gemv(st, a, n, false);
+      xi ^= 1;
+    }
+  };
+  for (int l = 0; l < NL; l++) {   // ResidualDecoderAttentionBlock::forward, mod.rs:345-350
+    const DecBlockW& b = m->dec[l];
+    ln_gemv(gemv(b.qkv, s->ks_qkv, s->ksl_qkv, PRO_PLAIN, nullptr, d, s->Pqkv.as<float>()),
+            l == 0 ? nullptr : s->P2.as<float>(), l == 0 ? 0 : s->ks_2, l == 0 ? nullptr : m->dec[l - 1].mlp2.b, b.ln1,
+            false);
+    launch_dec_self_attn(st, dst, L, n, H, s->Pqkv.as<float>(), s->ks_qkv, b.qkv.b, d,
+                         s->kc.as<float>() + (size_t)l * pool * d, s->vc.as<float>() + (size_t)l * pool * d, tabs,
+                         s->Lmax, m->qk_scale, att);
+    launch_dec_gemv(st, gemv(b.out, s->ks_o, s->ksl_o, PRO_PLAIN, att, d, s->Po.as<float>()), n, false);
+    ln_gemv(gemv(b.cq, s->ks_o, s->ksl_o, PRO_PLAIN, nullptr, d, s->Pq.as<float>()), s->Po.as<float>(), s->ks_o,
+            b.out.b, b.ln2, false);
+    launch_dec_cross_attn(st, dst, L, s->W, H, s->n_chunks, s->Pq.as<float>(), s->ks_o, b.cq.b, d, s->ckv.as<float>(),
+                          ldkv, l * 2 * d, win_row0, win_C, m->qk_scale, s->ca.as<float>(), max_nb);
+    {
+      GemvArgs a = gemv(b.cout, s->ks_o, s->ksl_o, PRO_ATTN, s->ca.as<float>(), 0, s->Po.as<float>());
+      a.n_head = H; a.n_chunks = s->n_chunks;
+      launch_dec_gemv(st, a, n, false);
+    }
+    ln_gemv(gemv(b.mlp1, s->ks_1, s->ksl_1, PRO_PLAIN, nullptr, d, s->P1.as<float>()), s->Po.as<float>(), s->ks_o,
+            b.cout.b, b.ln3, false);
+    {
+      GemvArgs a = gemv(b.mlp2, s->ks_2, s->ksl_2, PRO_GELU, s->P1.as<float>(), 4 * d, s->P2.as<float>());
+      a.pbias = b.mlp1.b; a.KSp = s->ks_1;
+      launch_dec_gemv(st, a, n, false);
+    }
+  }
+  if (k > 0) {
+    // logits = ln(x) . token_embedding^T (mod.rs:155-156), last position only; + mask, tile statistics
+    ScopedTimer tm_logits(st, 6);
+    GemvArgs a;
+    a.W = m->tok_emb_t; a.ldw = m->vocab_ld; a.K = d; a.N = V; a.KS = 1; a.KSL = d;
+    a.P = s->logits.as<float>(); a.st = dst; a.S = S;
+    a.mask = s->mask.as<float>(); a.use_mask = use_mask; a.topk = k; a.tstats = s->tstats.as<float>();
+    ln_gemv(a, s->P2.as<float>(), s->ks_2, m->dec[NL - 1].mlp2.b, m->ln_dec, true);
+    tm_logits.stop();
+    launch_dec_topk_merge(st, dst, n, s->tstats.as<float>(), s->n_tiles_v, k, out_id_dev, out_lp_dev,
+                          s->row_stats.as<float>());
+    if (timed && tm_logits.on) {
+      WB_HIP(hipStreamSynchronize(st));
+      tm_logits.collect();
+      profile().ms[7] += 1;
+    }
+  }
+  return WB_OK;
+}
+
 int wb_session_step(wb_session* s, const int32_t* new_tokens, const int32_t* parent, const int32_t* window, int n,
                     int apply_special_mask, int k, int32_t* top_ids, float* top_logprobs) {
   WB_REQUIRE(s && new_tokens && parent && window, WB_ERR_ARG, "wb_session_step: null argument");
   wb_model* m = s->m;
   const wb_dims& D = m->dims;
-  const int d = D.n_text_state, H = D.n_text_head, NL = D.n_text_layer, V = D.n_vocab, S = s->S;
+  const int V = D.n_vocab, S = s->S;
   WB_HIP(hipSetDevice(m->device));
   if (!s->decode_ready) WB_TRY(session_reserve(s, D.n_text_ctx));
   WB_REQUIRE(n >= 1 && n <= S, WB_ERR_ARG, "wb_session_step: n = %d outside [1, %d]", n, S);
@@ -302,84 +410,55 @@ int wb_session_step(wb_session* s, const int32_t* new_tokens, const int32_t* par
     hs[L.win_slots + window[i] * MAX_BEAMS + nb] = i;
     nb++;
   }
+  // launch shape: bucketed so that the same captured graph serves every step of a decode
+  const int n_launch = n <= 4 ? std::min(4, S) : n <= 8 ? std::min(8, S) : S;
+  const bool fuse_ln = n_launch <= 8;             // LayerNorm in the GEMV prologue (redundant per block) vs its own launch
+  const int max_nb = s->max_beams <= 1 ? 1 : s->max_beams <= 2 ? 2 : s->max_beams <= 4 ? 4 : 8;
+  const int use_mask = apply_special_mask ? 1 : 0;
   hipStream_t st = s->st;
+  const bool profiling = profile().on;
+  static const bool graphs_enabled = []() { const char* e = getenv("WHISPER_HIP_GRAPH"); return !(e && e[0] == '0'); }();
   ScopedTimer tm_step(st, 3);
-  WB_HIP(hipMemcpyAsync(s->state.p, hs, (size_t)L.total * 4, hipMemcpyHostToDevice, st));
-  const int* dst = s->state.as<int>();
-  int* tab_new = s->tabs.as<int>() + (size_t)(s->step & 1) * S * s->Lmax;
-  const int* tab_old = s->tabs.as<int>() + (size_t)((s->step & 1) ^ 1) * S * s->Lmax;
-  float *x = s->x.as<float>(), *h = s->h.as<float>(), *att = s->att.as<float>();
-  const size_t pool = (size_t)s->Lmax * S;
-  const int ldkv = NL * 2 * d;
-  const int* win_row0 = s->win_meta.as<int>();
-  const int* win_C = win_row0 + s->W;
-
-  launch_dec_prepare(st, dst, L, n, tab_old, tab_new, s->Lmax, m->tok_emb, m->dec_pos, d, x);
-  auto gemv = [&](const LinearW& w, int ks, int ksl, int pro, const float* src, int ld_src, float* P) {
-    GemvArgs a;
-    a.W = w.w; a.ldw = w.n; a.K = w.k; a.N = w.n; a.KS = ks; a.KSL = ksl; a.pro = pro; a.src = src; a.ld_src = ld_src;
-    a.P = P; a.st = dst; a.S = S;
-    return a;
-  };
-  for (int l = 0; l < NL; l++) {   // ResidualDecoderAttentionBlock::forward, mod.rs:345-350
-    const DecBlockW& b = m->dec[l];
-    if (l == 0)
-      launch_dec_resolve_ln(st, dst, n, x, nullptr, 0, S, nullptr, d, b.ln1, m->ln_eps_inside_sqrt, h);
-    else
-      launch_dec_resolve_ln(st, dst, n, x, s->P2.as<float>(), s->ks_2, S, m->dec[l - 1].mlp2.b, d, b.ln1,
-                            m->ln_eps_inside_sqrt, h);
-    launch_dec_gemv(st, gemv(b.qkv, s->ks_qkv, s->ksl_qkv, PRO_PLAIN, h, d, s->Pqkv.as<float>()), n);
-    launch_dec_self_attn(st, dst, L, n, H, s->Pqkv.as<float>(), s->ks_qkv, b.qkv.b, d,
-                         s->kc.as<float>() + (size_t)l * pool * d, s->vc.as<float>() + (size_t)l * pool * d, tab_new,
-                         s->Lmax, m->qk_scale, att);
-    launch_dec_gemv(st, gemv(b.out, s->ks_o, s->ksl_o, PRO_PLAIN, att, d, s->Po.as<float>()), n);
-    launch_dec_resolve_ln(st, dst, n, x, s->Po.as<float>(), s->ks_o, S, b.out.b, d, b.ln2, m->ln_eps_inside_sqrt, h);
-    launch_dec_gemv(st, gemv(b.cq, s->ks_o, s->ksl_o, PRO_PLAIN, h, d, s->Pq.as<float>()), n);
-    launch_dec_cross_attn(st, dst, L, s->W, H, s->n_chunks, s->Pq.as<float>(), s->ks_o, b.cq.b, d, s->ckv.as<float>(),
-                          ldkv, l * 2 * d, win_row0, win_C, m->qk_scale, s->ca.as<float>());
-    {
-      GemvArgs a = gemv(b.cout, s->ks_o, s->ksl_o, PRO_ATTN, s->ca.as<float>(), 0, s->Po.as<float>());
-      a.n_head = H; a.n_chunks = s->n_chunks;
-      launch_dec_gemv(st, a, n);
+  if (graphs_enabled && !profiling) {
+    // graphs bake in buffer addresses and launch geometry: drop them if anything moved since capture
+    uint64_t sig = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) { sig = (sig ^ v) * 1099511628211ull; };
+    for (const wb::DevMem* b : {&s->kc, &s->vc, &s->tabs, &s->state, &s->x, &s->h, &s->att, &s->Pqkv, &s->Po, &s->Pq,
+                                &s->P1, &s->P2, &s->ca, &s->logits, &s->tstats, &s->row_stats, &s->mask, &s->ckv,
+                                &s->win_meta})
+      mix((uint64_t)(uintptr_t)b->p);
+    mix((uint64_t)(uintptr_t)s->host_block_dev);
+    for (int v : {S, s->W, s->Lmax, s->n_chunks, s->max_beams, m->ln_eps_inside_sqrt}) mix((uint64_t)v);
+    if (sig != s->buf_sig) { s->clear_graphs(); s->buf_sig = sig; }
+    const uint64_t key = ((uint64_t)n_launch << 32) | ((uint64_t)k << 8) | ((uint64_t)use_mask << 1) | (fuse_ln ? 1 : 0);
+    auto it = s->graphs.find(key);
+    if (it == s->graphs.end()) {
+      hipGraph_t g = nullptr;
+      hipGraphExec_t ge = nullptr;
+      WB_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      int rc = enqueue_step(s, n_launch, k, use_mask, fuse_ln, max_nb, false);
+      hipError_t e = hipStreamEndCapture(st, &g);
+      WB_TRY(rc);
+      WB_HIP(e);
+      WB_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(g);
+      it = s->graphs.emplace(key, ge).first;
     }
-    launch_dec_resolve_ln(st, dst, n, x, s->Po.as<float>(), s->ks_o, S, b.cout.b, d, b.ln3, m->ln_eps_inside_sqrt, h);
-    launch_dec_gemv(st, gemv(b.mlp1, s->ks_1, s->ksl_1, PRO_PLAIN, h, d, s->P1.as<float>()), n);
-    {
-      GemvArgs a = gemv(b.mlp2, s->ks_2, s->ksl_2, PRO_GELU, s->P1.as<float>(), 4 * d, s->P2.as<float>());
-      a.pbias = b.mlp1.b; a.KSp = s->ks_1;
-      launch_dec_gemv(st, a, n);
-    }
+    WB_HIP(hipGraphLaunch(it->second, st));
+  } else {
+    WB_TRY(enqueue_step(s, n_launch, k, use_mask, fuse_ln, max_nb, true));
   }
+  tm_step.stop();
+  WB_HIP(hipStreamSynchronize(st));   // results land in mapped host memory; state_host is reused by the next step
   s->last_had_logits = 0;
   if (k > 0) {
-    launch_dec_resolve_ln(st, dst, n, x, s->P2.as<float>(), s->ks_2, S, m->dec[NL - 1].mlp2.b, d, m->ln_dec,
-                          m->ln_eps_inside_sqrt, h);
-    // logits = ln(x) . token_embedding^T (mod.rs:155-156), last position only
-    ScopedTimer tm_logits(st, 6);
-    GemvArgs a;
-    a.W = m->tok_emb_t; a.ldw = m->vocab_ld; a.K = d; a.N = V; a.KS = s->ks_v; a.KSL = s->ksl_v; a.pro = PRO_PLAIN;
-    a.src = h; a.ld_src = d; a.P = s->logits.as<float>(); a.st = dst; a.S = S;
-    launch_dec_gemv(st, a, n);
-    tm_logits.stop();
-    launch_dec_topk(st, dst, n, s->logits.as<float>(), s->ks_v, (int64_t)S * V, V, s->mask.as<float>(),
-                    apply_special_mask ? 1 : 0, k,
-                    s->topk_id.as<int32_t>(), s->topk_lp.as<float>(), s->row_stats.as<float>());
-    WB_HIP(hipMemcpyAsync(s->topk_id_host, s->topk_id.p, (size_t)n * TOPK_MAX * 4, hipMemcpyDeviceToHost, st));
-    WB_HIP(hipMemcpyAsync(s->topk_lp_host, s->topk_lp.p, (size_t)n * TOPK_MAX * 4, hipMemcpyDeviceToHost, st));
-    tm_step.stop();
-    WB_HIP(hipStreamSynchronize(st));
-    tm_logits.collect();
-    if (tm_logits.on) profile().ms[7] += 1;
     for (int i = 0; i < n; i++)
       for (int j = 0; j < k; j++) {
         top_ids[i * k + j] = s->topk_id_host[i * TOPK_MAX + j];
         top_logprobs[i * k + j] = s->topk_lp_host[i * TOPK_MAX + j];
       }
-    s->last_use_mask = apply_special_mask ? 1 : 0;
+    s->last_use_mask = use_mask;
     s->last_had_logits = 1;
-  } else {
-    tm_step.stop();
-    WB_HIP(hipStreamSynchronize(st));   // state_host is reused by the next step
   }
   tm_step.collect();
   if (tm_step.on) profile().ms[4] += 1;
@@ -397,7 +476,7 @@ int wb_session_last_logprobs(wb_session* s, int slot, float* out) {
              "wb_session_last_logprobs: no logits for slot %d", slot);
   const int V = s->m->dims.n_vocab;
   WB_HIP(hipSetDevice(s->m->device));
-  launch_dec_logprob_row(s->st, s->logits.as<float>() + (size_t)slot * V, s->ks_v, (int64_t)s->S * V, V,
+  launch_dec_logprob_row(s->st, s->logits.as<float>() + (size_t)slot * V, 1, (int64_t)s->S * V, V,
                          s->mask.as<float>(), s->last_use_mask,
                          s->row_stats.as<float>() + 2 * slot, s->lp_tmp.as<float>());
   WB_HIP(hipMemcpyAsync(out, s->lp_tmp.p, (size_t)V * 4, hipMemcpyDeviceToHost, s->st));

@@ -17,15 +17,22 @@ struct wb_session {
   wb::DevMem pcm, mel, wins, gmax, enc_out, ckv, win_meta;
   wb::DevMem kc, vc, tabs, state;
   wb::StepLayout lay;
-  int* state_host = nullptr;            // pinned
-  int32_t* topk_id_host = nullptr;      // pinned [S][TOPK_MAX]
+  char* host_block = nullptr;           // mapped pinned host memory: step state | top-k ids | top-k log-probs
+  char* host_block_dev = nullptr;       // its device-visible address
+  size_t host_bytes = 0;
+  int* state_host = nullptr;            // views into host_block
+  int32_t* topk_id_host = nullptr;      // [S][TOPK_MAX]
   float* topk_lp_host = nullptr;
-  wb::DevMem x, h, att, Pqkv, Po, Pq, P1, P2, ca, logits, topk_id, topk_lp, row_stats, mask, lp_tmp;
+  wb::DevMem x, h, att, Pqkv, Po, Pq, P1, P2, ca, logits, tstats, row_stats, mask, lp_tmp;
+  int n_tiles_v = 0;
   int ks_qkv = 1, ksl_qkv = 0, ks_o = 1, ksl_o = 0, ks_1 = 1, ksl_1 = 0, ks_2 = 1, ksl_2 = 0, ks_v = 1, ksl_v = 0;
   std::vector<int> prev_len, prev_win;
   int prev_n = 0, step = 0;
   bool has_mask = false, decode_ready = false;
   int last_use_mask = 0, last_had_logits = 0;
+  std::unordered_map<uint64_t, hipGraphExec_t> graphs;   // captured decode steps, keyed by launch shape
+  uint64_t buf_sig = 0;                                  // signature of the buffers the graphs were captured with
+  void clear_graphs();
   ~wb_session();
 };
 

@@ -1,0 +1,108 @@
+// Developer probe (not part of the library): per-kernel latency of the decode-step kernels at
+// tiny.en geometry, launched back to back, warm vs rotating (cold) weights, eager vs hipGraph.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/decode_probe.cpp csrc/build/decode.hip.o -o tools/decode_probe
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <functional>
+#include <vector>
+#include "../csrc/decode.h"
+using namespace wb;
+namespace wb { void set_error(const char*, ...) {} }
+__global__ void k_empty() {}
+static hipStream_t st;
+static double bench(int reps, const std::function<void(int)>& f, bool graph) {
+  if (graph) {
+    hipGraph_t g; hipGraphExec_t ge;
+    hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    for (int i = 0; i < 100; i++) f(i);
+    hipStreamEndCapture(st, &g);
+    hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    hipGraphLaunch(ge, st); hipStreamSynchronize(st);
+    auto t0 = std::chrono::high_resolution_clock::now();
+    for (int r = 0; r < reps / 100; r++) hipGraphLaunch(ge, st);
+    hipStreamSynchronize(st);
+    auto t1 = std::chrono::high_resolution_clock::now();
+    hipGraphExecDestroy(ge); hipGraphDestroy(g);
+    return std::chrono::duration<double, std::micro>(t1 - t0).count() / (reps / 100 * 100);
+  }
+  for (int i = 0; i < 20; i++) f(i);
+  hipStreamSynchronize(st);
+  auto t0 = std::chrono::high_resolution_clock::now();
+  for (int i = 0; i < reps; i++) f(i);
+  hipStreamSynchronize(st);
+  auto t1 = std::chrono::high_resolution_clock::now();
+  return std::chrono::duration<double, std::micro>(t1 - t0).count() / reps;
+}
+int main(int argc, char** argv) {
+  const int d = argc > 1 ? atoi(argv[1]) : 384, H = d / 64, n = argc > 2 ? atoi(argv[2]) : 3, S = n, V = 51864, Vp = (V + 63) / 64 * 64;
+  hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+  const int NCOPY = 48;
+  auto dmalloc = [](size_t bytes) { void* p; hipMalloc(&p, bytes); hipMemset(p, 0, bytes); return p; };
+  float* Wdd = (float*)dmalloc((size_t)NCOPY * d * d * 4);
+  float* Wqkv = (float*)dmalloc((size_t)NCOPY * d * 3 * d * 4);
+  float* W1 = (float*)dmalloc((size_t)NCOPY * d * 4 * d * 4);
+  float* Et = (float*)dmalloc((size_t)d * Vp * 4);
+  float* x = (float*)dmalloc((size_t)2 * S * d * 4);
+  float* P = (float*)dmalloc((size_t)16 * S * 4 * d * 4);
+  float* P2 = (float*)dmalloc((size_t)16 * S * 4 * d * 4);
+  float* bias = (float*)dmalloc(4 * d * 4);
+  float* g = (float*)dmalloc(d * 4); float* b = (float*)dmalloc(d * 4);
+  float* logits = (float*)dmalloc((size_t)S * V * 4);
+  float* tstats = (float*)dmalloc((size_t)S * 512 * TS_STRIDE * 4);
+  float* mask = (float*)dmalloc(V * 4);
+  StepLayout L = make_step_layout(S, S);
+  std::vector<int> hs(L.total, 0);
+  hs[ST_N] = n; hs[ST_STEP] = 0;
+  for (int i = 0; i < n; i++) { hs[L.tok + i] = 5; hs[L.parent + i] = -1; hs[L.len + i] = 50; hs[L.win + i] = i; hs[L.win_nb + i] = 1; hs[L.win_slots + i * MAX_BEAMS] = i; }
+  int* stdev = (int*)dmalloc(L.total * 4);
+  hipMemcpy(stdev, hs.data(), L.total * 4, hipMemcpyHostToDevice);
+  const int Lmax = 128;
+  int* tabs = (int*)dmalloc((size_t)2 * S * Lmax * 4);
+  std::vector<int> ht(2 * S * Lmax);
+  for (size_t i = 0; i < ht.size(); i++) ht[i] = (int)(i % (S * Lmax));
+  hipMemcpy(tabs, ht.data(), ht.size() * 4, hipMemcpyHostToDevice);
+  float* Kc = (float*)dmalloc((size_t)S * Lmax * d * 4); float* Vc = (float*)dmalloc((size_t)S * Lmax * d * 4);
+  float* att = (float*)dmalloc((size_t)S * d * 4);
+  const int C = 750, NL = 4, ldkv = NL * 2 * d, nch = (C + 127) / 128;
+  float* ckv = (float*)dmalloc((size_t)S * C * ldkv * 4);
+  std::vector<int> meta(2 * S);
+  for (int w = 0; w < S; w++) { meta[w] = w * C; meta[S + w] = C; }
+  int* wmeta = (int*)dmalloc(meta.size() * 4);
+  hipMemcpy(wmeta, meta.data(), meta.size() * 4, hipMemcpyHostToDevice);
+  float* ca = (float*)dmalloc((size_t)S * H * nch * CA_STRIDE * 4);
+  int ks_o, ksl_o, ks_q, ksl_q, ks_1, ksl_1;
+  gemv_plan(d, d, &ks_o, &ksl_o); gemv_plan(d, 3 * d, &ks_q, &ksl_q); gemv_plan(d, 4 * d, &ks_1, &ksl_1);
+  printf("d=%d n=%d plans: o ks=%d ksl=%d | qkv ks=%d ksl=%d | mlp1 ks=%d ksl=%d\n", d, n, ks_o, ksl_o, ks_q, ksl_q, ks_1, ksl_1);
+  auto base = [&](const float* W, int K, int N, int ks, int ksl) {
+    GemvArgs a; a.W = W; a.ldw = N; a.K = K; a.N = N; a.KS = ks; a.KSL = ksl; a.P = P2; a.st = stdev; a.S = S; return a;
+  };
+  struct Case { const char* name; std::function<void(int)> f; };
+  std::vector<Case> cases;
+  cases.push_back({"empty kernel (3 blocks)", [&](int) { hipLaunchKernelGGL(k_empty, dim3(3), dim3(256), 0, st); }});
+  for (int cold = 0; cold < 2; cold++) {
+    cases.push_back({cold ? "gemv plain Wo [d,d] cold" : "gemv plain Wo [d,d] warm", [&, cold](int i) {
+      GemvArgs a = base(Wdd + (size_t)(cold ? i % NCOPY : 0) * d * d, d, d, ks_o, ksl_o); a.pro = PRO_PLAIN; a.src = att; a.ld_src = d;
+      launch_dec_gemv(st, a, n, false); }});
+    cases.push_back({cold ? "gemv LN qkv [d,3d] cold" : "gemv LN qkv [d,3d] warm", [&, cold](int i) {
+      GemvArgs a = base(Wqkv + (size_t)(cold ? i % NCOPY : 0) * d * 3 * d, d, 3 * d, ks_q, ksl_q); a.pro = PRO_LN; a.src = x; a.ld_src = d;
+      a.pend = P; a.KSp = ks_o; a.pbias = bias; a.x_out = x + (size_t)S * d; a.ln_g = g; a.ln_b = b; a.ln_eps = 1e-5f;
+      launch_dec_gemv(st, a, n, false); }});
+    cases.push_back({cold ? "gemv LN mlp1 [d,4d] cold" : "gemv LN mlp1 [d,4d] warm", [&, cold](int i) {
+      GemvArgs a = base(W1 + (size_t)(cold ? i % NCOPY : 0) * d * 4 * d, d, 4 * d, ks_1, ksl_1); a.pro = PRO_LN; a.src = x; a.ld_src = d;
+      a.pend = P; a.KSp = ks_o; a.pbias = bias; a.x_out = x + (size_t)S * d; a.ln_g = g; a.ln_b = b; a.ln_eps = 1e-5f;
+      launch_dec_gemv(st, a, n, false); }});
+  }
+  cases.push_back({"self-attn len 50", [&](int) { launch_dec_self_attn(st, stdev, L, n, H, P, ks_q, bias, d, Kc, Vc, tabs, Lmax, 0.35f, att); }});
+  cases.push_back({"cross-attn C 750", [&](int) { launch_dec_cross_attn(st, stdev, L, S, H, nch, P, ks_o, bias, d, ckv, ldkv, 0, wmeta, wmeta + S, 0.35f, ca, 1); }});
+  cases.push_back({"logits + stats", [&](int) {
+    GemvArgs a = base(Et, d, V, 1, d); a.ldw = Vp; a.P = logits; a.pro = PRO_LN; a.src = x; a.ld_src = d; a.pend = P; a.KSp = ks_o; a.pbias = bias;
+    a.x_out = x + (size_t)S * d; a.ln_g = g; a.ln_b = b; a.ln_eps = 1e-5f; a.mask = mask; a.topk = 1; a.tstats = tstats;
+    launch_dec_gemv(st, a, n, true); }});
+  cases.push_back({"topk merge", [&](int) { launch_dec_topk_merge(st, stdev, n, tstats, (V + 127) / 128, 1, (int32_t*)att, att + 64, att + 128); }});
+  for (auto& c : cases) {
+    double e = bench(1000, c.f, false), gph = bench(1000, c.f, true);
+    printf("%-28s eager %6.2f us   graph %6.2f us\n", c.name, e, gph);
+  }
+  return 0;
+}
