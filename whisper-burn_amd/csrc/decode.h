@@ -19,6 +19,8 @@ constexpr int KS_MAX = 16;       // most K-split partials any consumer folds
 // Per-step state block (ints): header, per-slot arrays, per-window lists.  The host writes it into
 // mapped pinned memory; dec_prepare_kernel copies it to device memory for the rest of the step.
 enum { ST_N = 0, ST_STEP = 1, ST_HDR = 4 };
+// Device control block of the chained greedy decode (ints): step, then cur_tok[S], done[S], out_len[S].
+enum { GC_STEP = 0, GC_HDR = 4 };
 struct StepLayout {
   int S = 0, W = 0;                                  // slot capacity, windows
   int tok = 0, parent = 0, len = 0, win = 0;         // offsets of int[S] arrays
@@ -56,7 +58,7 @@ void gemv_plan(int K, int N, int* KS, int* KSL);
 int cross_attn_chunk();
 
 void launch_dec_prepare(hipStream_t st, const int* state_host_mapped, int* state_dev, const StepLayout& lay, int n,
-                        int* tabs, int Lmax, const float* E, const float* pos, int d, float* x);
+                        int* tabs, int Lmax, const float* E, const float* pos, int d, float* x, const int* gctl);
 void launch_dec_resolve_ln(hipStream_t st, const int* state, int n_max, const float* x_in, float* x_out,
                            const float* P, int KS, int S, const float* bias, int d, const LayerNormW& ln,
                            int eps_inside_sqrt, float* h);
@@ -68,7 +70,8 @@ void launch_dec_cross_attn(hipStream_t st, const int* state, const StepLayout& l
                            int n_chunks, const float* Pq, int KS, const float* bq, int d, const float* ckv, int ldkv,
                            int koff, const int* win_row0, const int* win_C, float scale, float* ca, int max_nb);
 void launch_dec_topk_merge(hipStream_t st, const int* state, int n_max, const float* tstats, int n_tiles, int k,
-                           int32_t* out_id, float* out_lp, float* row_stats);
+                           int32_t* out_id, float* out_lp, float* row_stats, const StepLayout& lay, int* gctl, int* gtok,
+                           int Lmax, int eot);
 void launch_dec_logprob_row(hipStream_t st, const float* x, int KS, int64_t plane, int V, const float* mask,
                             int use_mask, const float* stats, float* out);
 

@@ -46,13 +46,35 @@ __device__ __forceinline__ float fold_partials(const float* __restrict__ P, int 
 // ---- step prepare: state host->device, position tables, token/position embedding (mod.rs:141-146) ----
 __global__ void dec_prepare_kernel(const int* __restrict__ st_host, int* __restrict__ st_dev, StepLayout lay,
                                    int* __restrict__ tabs, int Lmax, const float* __restrict__ E,
-                                   const float* __restrict__ pos, int d, float* __restrict__ x) {
+                                   const float* __restrict__ pos, int d, float* __restrict__ x,
+                                   const int* __restrict__ gctl) {
   const int i = blockIdx.x;
-  if (i == 0)
-    for (int e = threadIdx.x; e < lay.total; e += blockDim.x) st_dev[e] = st_host[e];
-  if (i >= st_host[ST_N]) return;
-  const int len = st_host[lay.len + i], parent = st_host[lay.parent + i], tok = st_host[lay.tok + i];
-  const int step = st_host[ST_STEP];
+  int n, step, len, parent, tok;
+  if (gctl) {
+    // device-chained greedy decode: the step state is derived on the device from the control block
+    // the previous step's merge kernel left behind (one beam per window, slot == window)
+    n = lay.W; step = gctl[GC_STEP]; len = step + 1; parent = i; tok = i < n ? gctl[GC_HDR + i] : 0;
+    if (i == 0)
+      for (int e = threadIdx.x; e < lay.total; e += blockDim.x) {
+        int v = 0;
+        if (e == ST_N) v = n;
+        else if (e == ST_STEP) v = step;
+        else if (e >= lay.tok && e < lay.tok + n) v = gctl[GC_HDR + (e - lay.tok)];
+        else if (e >= lay.parent && e < lay.parent + n) v = e - lay.parent;
+        else if (e >= lay.len && e < lay.len + n) v = len;
+        else if (e >= lay.win && e < lay.win + n) v = e - lay.win;
+        else if (e >= lay.win_nb && e < lay.win_nb + n) v = 1;
+        else if (e >= lay.win_slots && (e - lay.win_slots) % MAX_BEAMS == 0 && (e - lay.win_slots) / MAX_BEAMS < n)
+          v = (e - lay.win_slots) / MAX_BEAMS;
+        st_dev[e] = v;
+      }
+  } else {
+    if (i == 0)
+      for (int e = threadIdx.x; e < lay.total; e += blockDim.x) st_dev[e] = st_host[e];
+    n = st_host[ST_N]; step = st_host[ST_STEP];
+    len = st_host[lay.len + i]; parent = st_host[lay.parent + i]; tok = st_host[lay.tok + i];
+  }
+  if (i >= n) return;
   int* tab_new = tabs + (size_t)(step & 1) * lay.S * Lmax;           // position tables are double-buffered by step parity
   const int* tab_old = tabs + (size_t)((step & 1) ^ 1) * lay.S * Lmax;
   if (parent >= 0)
@@ -321,7 +343,9 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(GemvArgs a) {
 // ---- merge the per-tile statistics of one beam's logits row: log_softmax + top-k ------------------
 __global__ __launch_bounds__(256) void dec_topk_merge_kernel(const int* __restrict__ st, const float* __restrict__ tstats,
                                                              int n_tiles, int k, int32_t* __restrict__ out_id,
-                                                             float* __restrict__ out_lp, float* __restrict__ row_stats) {
+                                                             float* __restrict__ out_lp, float* __restrict__ row_stats,
+                                                             StepLayout lay, int* __restrict__ gctl,
+                                                             int* __restrict__ gtok, int Lmax, int eot) {
   __shared__ float redv[4];
   __shared__ int redi[4];
   __shared__ float bc[2];
@@ -374,6 +398,16 @@ __global__ __launch_bounds__(256) void dec_topk_merge_kernel(const int* __restri
     if (tid == 0) {
       out_id[r * TOPK_MAX + round] = gi;
       out_lp[r * TOPK_MAX + round] = (gv - M) - lse;   // log_softmax, transcribe.rs:276
+      if (gctl && round == 0) {   // device-chained greedy: argmax feeds the next step, tokens stay on the device
+        const int len = st[lay.len + r];
+        gctl[GC_HDR + r] = gi;
+        if (!gctl[GC_HDR + lay.S + r]) {
+          gtok[r * Lmax + len] = gi;
+          gctl[GC_HDR + 2 * lay.S + r] = len + 1;
+          if (gi == eot) gctl[GC_HDR + lay.S + r] = 1;   // finished (transcribe.rs:235-241): later tokens are ignored
+        }
+        if (r == 0) gctl[GC_STEP] = st[ST_STEP] + 1;
+      }
     }
     if (ti[0] == gi) {   // the winner pops its head
 #pragma unroll
@@ -598,9 +632,9 @@ __global__ void dec_logprob_row_kernel(const float* __restrict__ x, int KS, int6
 }  // namespace
 
 void launch_dec_prepare(hipStream_t st, const int* state_host_mapped, int* state_dev, const StepLayout& lay, int n,
-                        int* tabs, int Lmax, const float* E, const float* pos, int d, float* x) {
+                        int* tabs, int Lmax, const float* E, const float* pos, int d, float* x, const int* gctl) {
   hipLaunchKernelGGL(dec_prepare_kernel, dim3(n), dim3(128), 0, st, state_host_mapped, state_dev, lay, tabs, Lmax, E, pos,
-                     d, x);
+                     d, x, gctl);
 }
 
 void launch_dec_resolve_ln(hipStream_t st, const int* state, int n_max, const float* x_in, float* x_out,
@@ -673,9 +707,10 @@ void launch_dec_cross_attn(hipStream_t st, const int* state, const StepLayout& l
 }
 
 void launch_dec_topk_merge(hipStream_t st, const int* state, int n_max, const float* tstats, int n_tiles, int k,
-                           int32_t* out_id, float* out_lp, float* row_stats) {
+                           int32_t* out_id, float* out_lp, float* row_stats, const StepLayout& lay, int* gctl, int* gtok,
+                           int Lmax, int eot) {
   hipLaunchKernelGGL(dec_topk_merge_kernel, dim3(n_max), dim3(256), 0, st, state, tstats, n_tiles, k, out_id, out_lp,
-                     row_stats);
+                     row_stats, lay, gctl, gtok, Lmax, eot);
 }
 
 void launch_dec_logprob_row(hipStream_t st, const float* x, int KS, int64_t plane, int V, const float* mask,

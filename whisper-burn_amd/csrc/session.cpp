@@ -283,7 +283,8 @@ int wb_session_set_special_mask(wb_session* s, const uint8_t* is_special) {
 // ids, parents, lengths, the live-beam count, table parity) is read by the kernels from the step
 // state, so for a given (row bucket, k, mask, fuse) the launch sequence is identical every step and
 // can be captured once into a hipGraph and replayed.
-static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool fuse_ln, int max_nb, bool timed) {
+static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool fuse_ln, int max_nb, bool timed,
+                        bool chained = false, int eot = -1) {
   wb_model* m = s->m;
   const wb_dims& D = m->dims;
   const int d = D.n_text_state, H = D.n_text_head, NL = D.n_text_layer, V = D.n_vocab, S = s->S;
@@ -303,7 +304,8 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
   const int* win_C = win_row0 + s->W;
   const int n = n_launch;
 
-  launch_dec_prepare(st, hst, s->state.as<int>(), L, n, tabs, s->Lmax, m->tok_emb, m->dec_pos, d, xb[0]);
+  int* gctl = chained ? s->gctl.as<int>() : nullptr;
+  launch_dec_prepare(st, hst, s->state.as<int>(), L, n, tabs, s->Lmax, m->tok_emb, m->dec_pos, d, xb[0], gctl);
   auto gemv = [&](const LinearW& w, int ks, int ksl, int pro, const float* src, int ld_src, float* P) {
     GemvArgs a;
     a.W = w.w; a.ldw = w.n; a.K = w.k; a.N = w.n; a.KS = ks; a.KSL = ksl; a.pro = pro; a.src = src; a.ld_src = ld_src;
@@ -366,7 +368,7 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
     ln_gemv(a, s->P2.as<float>(), s->ks_2, m->dec[NL - 1].mlp2.b, m->ln_dec, true);
     tm_logits.stop();
     launch_dec_topk_merge(st, dst, n, s->tstats.as<float>(), s->n_tiles_v, k, out_id_dev, out_lp_dev,
-                          s->row_stats.as<float>());
+                          s->row_stats.as<float>(), L, gctl, s->gtok.as<int>(), s->Lmax, eot);
     if (timed && tm_logits.on) {
       WB_HIP(hipStreamSynchronize(st));
       tm_logits.collect();
@@ -375,6 +377,109 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
   }
   return WB_OK;
 }
+
+// Launch one decode step: replay the captured graph for this launch shape (capturing it on first use),
+// or enqueue the kernels eagerly.
+static int launch_step(wb_session* s, int n_launch, int k, int use_mask, bool fuse_ln, int max_nb, bool use_graph,
+                       bool chained, int eot) {
+  wb_model* m = s->m;
+  hipStream_t st = s->st;
+  if (!use_graph) return enqueue_step(s, n_launch, k, use_mask, fuse_ln, max_nb, true, chained, eot);
+  // graphs bake in buffer addresses and launch geometry: drop them if anything moved since capture
+  uint64_t sig = 1469598103934665603ull;
+  auto mix = [&](uint64_t v) { sig = (sig ^ v) * 1099511628211ull; };
+  for (const wb::DevMem* b : {&s->kc, &s->vc, &s->tabs, &s->state, &s->x, &s->h, &s->att, &s->Pqkv, &s->Po, &s->Pq,
+                              &s->P1, &s->P2, &s->ca, &s->logits, &s->tstats, &s->row_stats, &s->mask, &s->ckv,
+                              &s->win_meta, &s->gctl, &s->gtok})
+    mix((uint64_t)(uintptr_t)b->p);
+  mix((uint64_t)(uintptr_t)s->host_block_dev);
+  for (int v : {s->S, s->W, s->Lmax, s->n_chunks, s->max_beams, m->ln_eps_inside_sqrt, eot}) mix((uint64_t)(int64_t)v);
+  if (sig != s->buf_sig) { s->clear_graphs(); s->buf_sig = sig; }
+  const uint64_t key = ((uint64_t)n_launch << 32) | ((uint64_t)k << 8) | (chained ? 4u : 0u) | ((uint64_t)use_mask << 1) |
+                       (fuse_ln ? 1u : 0u);
+  auto it = s->graphs.find(key);
+  if (it == s->graphs.end()) {
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    WB_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    int rc = enqueue_step(s, n_launch, k, use_mask, fuse_ln, max_nb, false, chained, eot);
+    hipError_t e = hipStreamEndCapture(st, &g);
+    WB_TRY(rc);
+    WB_HIP(e);
+    WB_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(g);
+    it = s->graphs.emplace(key, ge).first;
+  }
+  WB_HIP(hipGraphLaunch(it->second, st));
+  return WB_OK;
+}
+
+}  // extern "C"
+
+namespace wb {
+// Device-chained greedy decode (beam_size == 1): after the host-driven prompt prefill, every step's
+// argmax is fed to the next step on the device; the host only replays the step graph and checks the
+// per-window finished flags every `chunk` steps.  Equivalent to beam.rs with k = 1: the single beam is
+// extended by its best continuation (lowest id on ties) until it ends in EOT or max_depth tokens.
+int session_greedy_chain(wb_session* s, int first_token, int eot, int max_depth, int mask_until_len, int prompt_len,
+                         int32_t* out_tokens, int32_t row_stride, int32_t* out_lens) {
+  wb_model* m = s->m;
+  const int S = s->S, W = s->W;
+  WB_REQUIRE(S == W, WB_ERR_STATE, "chained greedy decode needs max_beams == 1");
+  WB_REQUIRE(s->prev_n == W && s->step == prompt_len - 1, WB_ERR_STATE, "chained greedy decode: prompt prefill missing");
+  WB_REQUIRE(s->step + max_depth <= s->Lmax, WB_ERR_SHAPE, "Token sequence length %d must not exceed %d.",
+             s->step + max_depth, s->Lmax);
+  WB_HIP(hipSetDevice(m->device));
+  hipStream_t st = s->st;
+  const size_t ctl_ints = GC_HDR + 3 * (size_t)S;
+  WB_TRY(s->gctl.ensure(ctl_ints * 4));
+  WB_TRY(s->gtok.ensure((size_t)S * s->Lmax * 4));
+  std::vector<int> ctl(ctl_ints, 0);
+  ctl[GC_STEP] = s->step;
+  for (int i = 0; i < W; i++) ctl[GC_HDR + i] = first_token;
+  WB_HIP(hipMemcpyAsync(s->gctl.p, ctl.data(), ctl_ints * 4, hipMemcpyHostToDevice, st));
+  WB_HIP(hipStreamSynchronize(st));
+  const int n_launch = W <= 4 ? std::min(4, S) : W <= 8 ? std::min(8, S) : S;
+  const bool fuse_ln = n_launch <= 8;
+  static const bool graphs_enabled = []() { const char* e = getenv("WHISPER_HIP_GRAPH"); return !(e && e[0] == '0'); }();
+  const bool use_graph = graphs_enabled && !profile().on;
+  const int chunk = 16;
+  int depth = 0;
+  ScopedTimer tm(st, 3);
+  while (depth < max_depth) {
+    const int end = std::min(max_depth, depth + chunk);
+    for (; depth < end; depth++) {
+      const int use_mask = (prompt_len + depth) <= mask_until_len ? 1 : 0;   // transcribe.rs:271-275
+      WB_TRY(launch_step(s, n_launch, 1, use_mask, fuse_ln, 1, use_graph, true, eot));
+      if (profile().on) profile().ms[4] += 1;
+    }
+    WB_HIP(hipMemcpyAsync(ctl.data(), s->gctl.p, ctl_ints * 4, hipMemcpyDeviceToHost, st));
+    WB_HIP(hipStreamSynchronize(st));
+    bool all_done = true;
+    for (int i = 0; i < W; i++) all_done = all_done && ctl[GC_HDR + S + i] != 0;
+    if (all_done) break;
+  }
+  tm.stop();
+  std::vector<int> toks((size_t)S * s->Lmax);
+  WB_HIP(hipMemcpyAsync(toks.data(), s->gtok.p, toks.size() * 4, hipMemcpyDeviceToHost, st));
+  WB_HIP(hipStreamSynchronize(st));
+  tm.collect();
+  for (int w = 0; w < W; w++) {
+    int len = ctl[GC_HDR + 2 * S + w];                 // prompt + generated (through EOT if it came)
+    if (len < prompt_len) len = prompt_len;
+    len = std::min(len, prompt_len + max_depth);
+    WB_REQUIRE(len <= row_stride, WB_ERR_ARG, "row_stride too small");
+    for (int p = prompt_len; p < len; p++) out_tokens[(size_t)w * row_stride + p] = toks[(size_t)w * s->Lmax + p];
+    out_lens[w] = len;
+  }
+  s->step += depth;
+  s->prev_len.assign(W, s->step);
+  s->last_had_logits = 0;
+  return WB_OK;
+}
+}  // namespace wb
+
+extern "C" {
 
 int wb_session_step(wb_session* s, const int32_t* new_tokens, const int32_t* parent, const int32_t* window, int n,
                     int apply_special_mask, int k, int32_t* top_ids, float* top_logprobs) {
@@ -419,35 +524,7 @@ int wb_session_step(wb_session* s, const int32_t* new_tokens, const int32_t* par
   const bool profiling = profile().on;
   static const bool graphs_enabled = []() { const char* e = getenv("WHISPER_HIP_GRAPH"); return !(e && e[0] == '0'); }();
   ScopedTimer tm_step(st, 3);
-  if (graphs_enabled && !profiling) {
-    // graphs bake in buffer addresses and launch geometry: drop them if anything moved since capture
-    uint64_t sig = 1469598103934665603ull;
-    auto mix = [&](uint64_t v) { sig = (sig ^ v) * 1099511628211ull; };
-    for (const wb::DevMem* b : {&s->kc, &s->vc, &s->tabs, &s->state, &s->x, &s->h, &s->att, &s->Pqkv, &s->Po, &s->Pq,
-                                &s->P1, &s->P2, &s->ca, &s->logits, &s->tstats, &s->row_stats, &s->mask, &s->ckv,
-                                &s->win_meta})
-      mix((uint64_t)(uintptr_t)b->p);
-    mix((uint64_t)(uintptr_t)s->host_block_dev);
-    for (int v : {S, s->W, s->Lmax, s->n_chunks, s->max_beams, m->ln_eps_inside_sqrt}) mix((uint64_t)v);
-    if (sig != s->buf_sig) { s->clear_graphs(); s->buf_sig = sig; }
-    const uint64_t key = ((uint64_t)n_launch << 32) | ((uint64_t)k << 8) | ((uint64_t)use_mask << 1) | (fuse_ln ? 1 : 0);
-    auto it = s->graphs.find(key);
-    if (it == s->graphs.end()) {
-      hipGraph_t g = nullptr;
-      hipGraphExec_t ge = nullptr;
-      WB_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-      int rc = enqueue_step(s, n_launch, k, use_mask, fuse_ln, max_nb, false);
-      hipError_t e = hipStreamEndCapture(st, &g);
-      WB_TRY(rc);
-      WB_HIP(e);
-      WB_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-      (void)hipGraphDestroy(g);
-      it = s->graphs.emplace(key, ge).first;
-    }
-    WB_HIP(hipGraphLaunch(it->second, st));
-  } else {
-    WB_TRY(enqueue_step(s, n_launch, k, use_mask, fuse_ln, max_nb, true));
-  }
+  WB_TRY(launch_step(s, n_launch, k, use_mask, fuse_ln, max_nb, graphs_enabled && !profiling, false, -1));
   tm_step.stop();
   WB_HIP(hipStreamSynchronize(st));   // results land in mapped host memory; state_host is reused by the next step
   s->last_had_logits = 0;

@@ -23,7 +23,7 @@ struct wb_session {
   int* state_host = nullptr;            // views into host_block
   int32_t* topk_id_host = nullptr;      // [S][TOPK_MAX]
   float* topk_lp_host = nullptr;
-  wb::DevMem x, h, att, Pqkv, Po, Pq, P1, P2, ca, logits, tstats, row_stats, mask, lp_tmp;
+  wb::DevMem x, h, att, Pqkv, Po, Pq, P1, P2, ca, logits, tstats, row_stats, mask, lp_tmp, gctl, gtok;
   int n_tiles_v = 0;
   int ks_qkv = 1, ksl_qkv = 0, ks_o = 1, ksl_o = 0, ks_1 = 1, ksl_1 = 0, ks_2 = 1, ksl_2 = 0, ks_v = 1, ksl_v = 0;
   std::vector<int> prev_len, prev_win;
@@ -56,4 +56,6 @@ int session_create(wb_model* m, int n_windows, int max_beams, int padding, wb_se
 int session_encode_pcm(wb_session* s, const float* pcm, int64_t n_pcm, const int64_t* starts, const int64_t* lens,
                        bool pcm_on_device);
 int session_reserve(wb_session* s, int max_len);
+int session_greedy_chain(wb_session* s, int first_token, int eot, int max_depth, int mask_until_len, int prompt_len,
+                         int32_t* out_tokens, int32_t row_stride, int32_t* out_lens);
 }  // namespace wb

@@ -239,6 +239,23 @@ extern "C" int wb_session_decode(wb_session* s, const wb_decode_params* p, int32
   WB_REQUIRE(p->beam_size >= 1 && p->beam_size <= s->max_beams, WB_ERR_ARG, "beam_size %d outside [1, %d]",
              p->beam_size, s->max_beams);
   if (!s->decode_ready || s->Lmax < 4 + p->max_depth) WB_TRY(session_reserve(s, 4 + p->max_depth + 1));
+  static const bool chain_enabled = []() { const char* e = getenv("WHISPER_HIP_CHAIN"); return !(e && e[0] == '0'); }();
+  if (p->beam_size == 1 && s->max_beams == 1 && chain_enabled && p->max_depth > 0 && s->step == 0) {
+    // greedy: prompt prefill through the ordinary step, then the device-chained loop (no per-step host round trip)
+    const int V = s->m->dims.n_vocab, W = s->W;
+    const int32_t prompt[4] = {p->tok_start_of_transcript, p->tok_language, p->tok_transcribe, p->tok_no_timestamps};
+    for (int t : prompt) WB_REQUIRE(t >= 0 && t < V, WB_ERR_ARG, "prompt token %d out of range", t);
+    WB_REQUIRE(p->tok_end_of_text >= 0 && p->tok_end_of_text < V, WB_ERR_ARG, "end-of-text token out of range");
+    WB_REQUIRE(row_stride >= 4 + p->max_depth, WB_ERR_ARG, "row_stride %d < %d", row_stride, 4 + p->max_depth);
+    std::vector<int32_t> tok(W), par(W), win(W);
+    for (int t = 0; t < 3; t++) {
+      for (int w = 0; w < W; w++) { tok[w] = prompt[t]; par[w] = t == 0 ? -1 : w; win[w] = w; }
+      WB_TRY(wb_session_step(s, tok.data(), par.data(), win.data(), W, 0, 0, nullptr, nullptr));
+    }
+    for (int w = 0; w < W; w++) memcpy(out_tokens + (size_t)w * row_stride, prompt, sizeof(prompt));
+    return session_greedy_chain(s, prompt[3], p->tok_end_of_text, p->max_depth, p->mask_until_len, 4, out_tokens,
+                                row_stride, out_lens);
+  }
   return beam_search_windows(p, s->W, s->m->dims.n_vocab, s->S, session_step_thunk, s, out_tokens, row_stride, out_lens);
 }
 
