@@ -147,3 +147,17 @@ def test_tiny_en_beam5_matches_oracle(tiny):
     ref = otr.waveform_to_tokens(oracle, _special(st), audio, 16000, 5, 8)
     got, _ = wb.waveform_to_tokens(eng, st, audio, 16000, 5, 8)
     assert got == ref
+
+
+@pytest.mark.parametrize("beam_size", [1, 3])
+def test_many_windows_batch_mode_matches_oracle(micro, beam_size):
+    """> 8 live beams: the batch-mode decode path (split-K MFMA GEMMs, stand-alone LayerNorm, row top-k)
+    and, for beam 1, the device-chained greedy loop over more than 8 windows."""
+    oracle, eng, st = micro
+    audio = synth.synth_audio(16000 * 150, 4321)      # 150 s -> 13 reference windows
+    depth = 10
+    ref, ref_win = otr.waveform_to_tokens(oracle, _special(st), audio, 16000, beam_size, depth, return_windows=True)
+    got, got_win = wb.waveform_to_tokens(eng, st, audio, 16000, beam_size, depth)
+    assert len(got_win) == 13
+    assert got_win == ref_win
+    assert got == ref

@@ -72,6 +72,13 @@ void launch_dec_cross_attn(hipStream_t st, const int* state, const StepLayout& l
 void launch_dec_topk_merge(hipStream_t st, const int* state, int n_max, const float* tstats, int n_tiles, int k,
                            int32_t* out_id, float* out_lp, float* row_stats, const StepLayout& lay, int* gctl, int* gtok,
                            int Lmax, int eot);
+void launch_dec_gelu_fold(hipStream_t st, const int* state, int n_max, const float* P, int KS, int S, int K,
+                          const float* bias, float* out);
+void launch_dec_attn_combine(hipStream_t st, const int* state, int n_max, const float* ca, int n_head, int n_chunks,
+                             float* out);
+void launch_dec_topk_rows(hipStream_t st, const int* state, int n_max, const float* logits, int V, const float* mask,
+                          int use_mask, int k, int32_t* out_id, float* out_lp, float* row_stats, const StepLayout& lay,
+                          int* gctl, int* gtok, int Lmax, int eot);
 void launch_dec_logprob_row(hipStream_t st, const float* x, int KS, int64_t plane, int V, const float* mask,
                             int use_mask, const float* stats, float* out);
 

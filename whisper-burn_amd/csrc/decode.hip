@@ -340,6 +340,19 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(GemvArgs a) {
   }
 }
 
+// device-chained greedy: the argmax feeds the next step, tokens stay on the device
+__device__ __forceinline__ void chained_update(const int* st, const StepLayout& lay, int* gctl, int* gtok, int Lmax,
+                                               int eot, int r, int gi) {
+  const int len = st[lay.len + r];
+  gctl[GC_HDR + r] = gi;
+  if (!gctl[GC_HDR + lay.S + r]) {
+    gtok[r * Lmax + len] = gi;
+    gctl[GC_HDR + 2 * lay.S + r] = len + 1;
+    if (gi == eot) gctl[GC_HDR + lay.S + r] = 1;   // finished (transcribe.rs:235-241): later tokens are ignored
+  }
+  if (r == 0) gctl[GC_STEP] = st[ST_STEP] + 1;
+}
+
 // ---- merge the per-tile statistics of one beam's logits row: log_softmax + top-k ------------------
 __global__ __launch_bounds__(256) void dec_topk_merge_kernel(const int* __restrict__ st, const float* __restrict__ tstats,
                                                              int n_tiles, int k, int32_t* __restrict__ out_id,
@@ -398,16 +411,7 @@ __global__ __launch_bounds__(256) void dec_topk_merge_kernel(const int* __restri
     if (tid == 0) {
       out_id[r * TOPK_MAX + round] = gi;
       out_lp[r * TOPK_MAX + round] = (gv - M) - lse;   // log_softmax, transcribe.rs:276
-      if (gctl && round == 0) {   // device-chained greedy: argmax feeds the next step, tokens stay on the device
-        const int len = st[lay.len + r];
-        gctl[GC_HDR + r] = gi;
-        if (!gctl[GC_HDR + lay.S + r]) {
-          gtok[r * Lmax + len] = gi;
-          gctl[GC_HDR + 2 * lay.S + r] = len + 1;
-          if (gi == eot) gctl[GC_HDR + lay.S + r] = 1;   // finished (transcribe.rs:235-241): later tokens are ignored
-        }
-        if (r == 0) gctl[GC_STEP] = st[ST_STEP] + 1;
-      }
+      if (gctl && round == 0) chained_update(st, lay, gctl, gtok, Lmax, eot, r, gi);
     }
     if (ti[0] == gi) {   // the winner pops its head
 #pragma unroll
@@ -618,6 +622,110 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const int* __restri
   }
 }
 
+// ---- batch mode (more than 8 live beams): prologues materialised for the split-K MFMA GEMM ------
+// out[r][k] = GELU(bias[k] + sum_s P[s][r][k])   (mod.rs:377-378)
+__global__ void dec_gelu_fold_kernel(const int* __restrict__ st, const float* __restrict__ P, int KS, int S, int K,
+                                     const float* __restrict__ bias, float* __restrict__ out) {
+  const int r = blockIdx.y;
+  if (r >= st[ST_N]) return;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  out[(int64_t)r * K + k] = gelu_erf(fold_partials(P, KS, (int64_t)S * K, (int64_t)r * K + k, bias[k]));
+}
+// out[r][h*64+dh] = combine of the cross-attention key-chunk partials
+__global__ void dec_attn_combine_kernel(const int* __restrict__ st, const float* __restrict__ ca, int n_head,
+                                        int n_chunks, float* __restrict__ out) {
+  const int r = blockIdx.y;
+  if (r >= st[ST_N]) return;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, d = n_head * 64;
+  if (k >= d) return;
+  const int hh = k >> 6, dh = k & 63;
+  const float* c0 = ca + ((int64_t)(r * n_head + hh) * n_chunks) * CA_STRIDE;
+  float M = -1.0e30f;
+  for (int c = 0; c < n_chunks; c++) M = fmaxf(M, c0[c * CA_STRIDE]);
+  float num = 0.f, den = 0.f;
+  for (int c = 0; c < n_chunks; c++) {
+    const float w = expf(c0[c * CA_STRIDE] - M);
+    num += w * c0[c * CA_STRIDE + 2 + dh];
+    den += w * c0[c * CA_STRIDE + 1];
+  }
+  out[(int64_t)r * d + k] = num / den;
+}
+
+// mask + log_softmax + top-k of one beam's full logits row (batch mode; transcribe.rs:271-304)
+__global__ __launch_bounds__(1024) void dec_topk_rows_kernel(const int* __restrict__ st, const float* __restrict__ logits,
+                                                              int V, const float* __restrict__ mask, int use_mask,
+                                                              int k, int32_t* __restrict__ out_id,
+                                                              float* __restrict__ out_lp, float* __restrict__ row_stats,
+                                                              StepLayout lay, int* __restrict__ gctl,
+                                                              int* __restrict__ gtok, int Lmax, int eot) {
+  __shared__ float redv[16];
+  __shared__ int redi[16];
+  __shared__ float bc[2];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (r >= st[ST_N]) return;
+  const float* x = logits + (int64_t)r * V;
+  float tv[TOPK_MAX];
+  int ti[TOPK_MAX];
+#pragma unroll
+  for (int j = 0; j < TOPK_MAX; j++) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
+  float m = -INFINITY;
+  for (int c = tid; c < V; c += 1024) {
+    float v = x[c];
+    if (use_mask) v += mask[c];
+    m = fmaxf(m, v);
+    if (v > tv[TOPK_MAX - 1]) {   // ids arrive ascending per thread: equal values never displace
+      float cv = v; int ci = c;
+#pragma unroll
+      for (int j = 0; j < TOPK_MAX; j++)
+        if (cv > tv[j]) { float t = tv[j]; int u = ti[j]; tv[j] = cv; ti[j] = ci; cv = t; ci = u; }
+    }
+  }
+  m = wave_max(m);
+  if (lane == 0) redv[wave] = m;
+  __syncthreads();
+  float M = redv[0];
+  for (int j = 1; j < 16; j++) M = fmaxf(M, redv[j]);
+  float s = 0.f;
+  for (int c = tid; c < V; c += 1024) {
+    float v = x[c];
+    if (use_mask) v += mask[c];
+    s += expf(v - M);
+  }
+  s = wave_sum(s);
+  __syncthreads();
+  if (lane == 0) redv[wave] = s;
+  __syncthreads();
+  if (tid == 0) {
+    float ss = 0.f;
+    for (int j = 0; j < 16; j++) ss += redv[j];
+    bc[0] = logf(ss);
+    row_stats[2 * r] = M; row_stats[2 * r + 1] = bc[0];
+  }
+  __syncthreads();
+  const float lse = bc[0];
+  for (int round = 0; round < k; round++) {
+    float bv = tv[0]; int bi = ti[0];
+    wave_argmax(bv, bi);
+    __syncthreads();
+    if (lane == 0) { redv[wave] = bv; redi[wave] = bi; }
+    __syncthreads();
+    float gv = redv[0]; int gi = redi[0];
+    for (int j = 1; j < 16; j++)
+      if (better(redv[j], redi[j], gv, gi)) { gv = redv[j]; gi = redi[j]; }
+    if (tid == 0) {
+      out_id[r * TOPK_MAX + round] = gi;
+      out_lp[r * TOPK_MAX + round] = (gv - M) - lse;
+      if (gctl && round == 0) chained_update(st, lay, gctl, gtok, Lmax, eot, r, gi);
+    }
+    if (ti[0] == gi) {
+#pragma unroll
+      for (int j = 0; j < TOPK_MAX - 1; j++) { tv[j] = tv[j + 1]; ti[j] = ti[j + 1]; }
+      tv[TOPK_MAX - 1] = -INFINITY; ti[TOPK_MAX - 1] = 0x7fffffff;
+    }
+  }
+}
+
 __global__ void dec_logprob_row_kernel(const float* __restrict__ x, int KS, int64_t plane, int V,
                                        const float* __restrict__ mask, int use_mask,
                                        const float* __restrict__ stats, float* __restrict__ out) {
@@ -717,6 +825,22 @@ void launch_dec_logprob_row(hipStream_t st, const float* x, int KS, int64_t plan
                             int use_mask, const float* stats, float* out) {
   hipLaunchKernelGGL(dec_logprob_row_kernel, dim3((V + 255) / 256), dim3(256), 0, st, x, KS, plane, V, mask, use_mask,
                      stats, out);
+}
+
+void launch_dec_gelu_fold(hipStream_t st, const int* state, int n_max, const float* P, int KS, int S, int K,
+                          const float* bias, float* out) {
+  hipLaunchKernelGGL(dec_gelu_fold_kernel, dim3((K + 255) / 256, n_max), dim3(256), 0, st, state, P, KS, S, K, bias, out);
+}
+void launch_dec_attn_combine(hipStream_t st, const int* state, int n_max, const float* ca, int n_head, int n_chunks,
+                             float* out) {
+  hipLaunchKernelGGL(dec_attn_combine_kernel, dim3((n_head * 64 + 255) / 256, n_max), dim3(256), 0, st, state, ca, n_head,
+                     n_chunks, out);
+}
+void launch_dec_topk_rows(hipStream_t st, const int* state, int n_max, const float* logits, int V, const float* mask,
+                          int use_mask, int k, int32_t* out_id, float* out_lp, float* row_stats, const StepLayout& lay,
+                          int* gctl, int* gtok, int Lmax, int eot) {
+  hipLaunchKernelGGL(dec_topk_rows_kernel, dim3(n_max), dim3(1024), 0, st, state, logits, V, mask, use_mask, k, out_id,
+                     out_lp, row_stats, lay, gctl, gtok, Lmax, eot);
 }
 
 int cross_attn_chunk() { return CA_CH; }

@@ -44,6 +44,10 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
   // XCD-aware block order is not needed here: neighbouring blocks share B panels through L2 either way
   const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
   const int M = g.M, N = g.N, K = g.K;
+  // split-K (decode batch mode): slice blockIdx.z of the K range, raw partial sums to C + z * c_split_stride
+  const int kchunk = g.ksplit > 1 ? ((K + g.ksplit - 1) / g.ksplit + BK - 1) / BK * BK : K;
+  const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
+  float* Cout = g.C + (int64_t)blockIdx.z * g.c_split_stride;
 
   // ---- A staging: per-thread rows are fixed over the k loop ----
   constexpr int A_F4 = (AMODE == AMODE_ROWS) ? (BM * 4 + NT - 1) / NT : 0;   // float4 loads / thread / tile
@@ -154,13 +158,15 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-  const int nk = K / BK;
-  load_tile(0);
-  store_tile(0);
+  const int nk = max(0, kend - kbeg) / BK;
+  if (nk > 0) {
+    load_tile(kbeg);
+    store_tile(0);
+  }
   __syncthreads();
   for (int t = 0; t < nk; t++) {
     const int buf = t & 1;
-    if (t + 1 < nk) load_tile((t + 1) * BK);
+    if (t + 1 < nk) load_tile(kbeg + (t + 1) * BK);
 #pragma unroll
     for (int kk = 0; kk < BK / 2; kk++) {
       const int kidx = 2 * kk + lh;
@@ -198,14 +204,14 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
         if (g.col_scale_period > 0) v *= cs;
         if (g.residual) v = g.residual[(int64_t)row * g.ldr + col] + v;
         if (g.aux) v = v + g.aux[(int64_t)g.aux_idx[row] * g.ld_aux + col];
-        g.C[(int64_t)row * g.ldc + col] = v;
+        Cout[(int64_t)row * g.ldc + col] = v;
       }
     }
 }
 
 template <int BM, int BN, int WGM, int WGN, int AMODE>
 void launch_cfg(hipStream_t st, const GemmArgs& a) {
-  dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM);
+  dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.ksplit > 1 ? a.ksplit : 1);
   hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, AMODE>), grid, dim3(NT), 0, st, a);
 }
 
@@ -214,6 +220,7 @@ void launch_cfg(hipStream_t st, const GemmArgs& a) {
 int launch_gemm_f32(hipStream_t st, const GemmArgs& a) {
   if (a.M <= 0 || a.N <= 0) return 0;
   if (a.K % BK != 0 || a.ldb % 4 != 0) return -1;
+  if (a.ksplit > 1 && (a.bias || a.residual || a.aux || a.act != ACT_NONE || a.col_scale_period > 0)) return -1;
   const bool conv1 = a.conv1_tstride > 0;
   // pick the largest tile that still gives the 256 CUs >= ~1.5 waves of blocks
   auto blocks = [&](int bm, int bn) { return (int64_t)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
@@ -223,6 +230,7 @@ int launch_gemm_f32(hipStream_t st, const GemmArgs& a) {
     return 0;
   }
   if (a.M <= 32) launch_cfg<32, 128, 1, 4, AMODE_ROWS>(st, a);
+  else if (a.ksplit > 1) launch_cfg<64, 64, 2, 2, AMODE_ROWS>(st, a);
   else if (blocks(128, 128) >= 384) launch_cfg<128, 128, 2, 2, AMODE_ROWS>(st, a);
   else launch_cfg<64, 64, 2, 2, AMODE_ROWS>(st, a);
   return 0;

@@ -55,6 +55,7 @@ struct GemmArgs {
   float col_scale = 1.f; int col_scale_period = 0, col_scale_width = 0;  // out *= col_scale where (n % period) < width
   int M = 0, N = 0, K = 0;                       // K % 16 == 0
   int act = ACT_NONE;
+  int ksplit = 1; int64_t c_split_stride = 0;    // split-K: raw partials of K-slice z go to C + z * c_split_stride
 };
 int launch_gemm_f32(hipStream_t st, const GemmArgs& a);   // exact-f32 MFMA (v_mfma_f32_32x32x2_f32)
 

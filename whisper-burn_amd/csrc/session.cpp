@@ -183,6 +183,7 @@ int session_reserve(wb_session* s, int max_len) {
   WB_TRY(s->x.ensure((size_t)2 * S * d * 4));   // residual stream, ping-pong
   WB_TRY(s->h.ensure((size_t)S * d * 4));
   WB_TRY(s->att.ensure((size_t)S * d * 4));
+  WB_TRY(s->hm.ensure((size_t)S * 4 * d * 4));
   WB_TRY(s->Pqkv.ensure((size_t)s->ks_qkv * S * 3 * d * 4));
   WB_TRY(s->Po.ensure((size_t)s->ks_o * S * d * 4));
   WB_TRY(s->Pq.ensure((size_t)s->ks_o * S * d * 4));
@@ -332,6 +333,62 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
       xi ^= 1;
     }
   };
+  if (!fuse_ln) {
+    // ---- batch mode (more than 8 live beams): rows are many enough for the matrix cores ----
+    // LayerNorm in its own launch, split-K exact-f32 MFMA GEMMs streaming each weight once into the
+    // same partial-sum planes the small-batch consumers fold
+    float* hm = s->hm.as<float>();
+    auto big = [&](const LinearW& w, int ks, const float* A, float* P) -> int {
+      GemmArgs g;
+      g.A = A; g.lda = w.k; g.B = w.w; g.ldb = w.n; g.C = P; g.ldc = w.n; g.M = n; g.N = w.n; g.K = w.k;
+      g.ksplit = ks; g.c_split_stride = (int64_t)S * w.n;
+      WB_REQUIRE(launch_gemm_f32(st, g) == 0, WB_ERR_SHAPE, "decode gemm: unsupported shape");
+      return WB_OK;
+    };
+    const float* pend = nullptr; int ks_pend = 0; const float* pbias = nullptr;
+    for (int l = 0; l < NL; l++) {
+      const DecBlockW& b = m->dec[l];
+      launch_dec_resolve_ln(st, dst, n, xb[xi], xb[xi ^ 1], pend, ks_pend, S, pbias, d, b.ln1, m->ln_eps_inside_sqrt, h);
+      xi ^= 1;
+      WB_TRY(big(b.qkv, s->ks_qkv, h, s->Pqkv.as<float>()));
+      launch_dec_self_attn(st, dst, L, n, H, s->Pqkv.as<float>(), s->ks_qkv, b.qkv.b, d,
+                           s->kc.as<float>() + (size_t)l * pool * d, s->vc.as<float>() + (size_t)l * pool * d, tabs,
+                           s->Lmax, m->qk_scale, att);
+      WB_TRY(big(b.out, s->ks_o, att, s->Po.as<float>()));
+      launch_dec_resolve_ln(st, dst, n, xb[xi], xb[xi ^ 1], s->Po.as<float>(), s->ks_o, S, b.out.b, d, b.ln2,
+                            m->ln_eps_inside_sqrt, h);
+      xi ^= 1;
+      WB_TRY(big(b.cq, s->ks_o, h, s->Pq.as<float>()));
+      launch_dec_cross_attn(st, dst, L, s->W, H, s->n_chunks, s->Pq.as<float>(), s->ks_o, b.cq.b, d, s->ckv.as<float>(),
+                            ldkv, l * 2 * d, win_row0, win_C, m->qk_scale, s->ca.as<float>(), max_nb);
+      launch_dec_attn_combine(st, dst, n, s->ca.as<float>(), H, s->n_chunks, att);
+      WB_TRY(big(b.cout, s->ks_o, att, s->Po.as<float>()));
+      launch_dec_resolve_ln(st, dst, n, xb[xi], xb[xi ^ 1], s->Po.as<float>(), s->ks_o, S, b.cout.b, d, b.ln3,
+                            m->ln_eps_inside_sqrt, h);
+      xi ^= 1;
+      WB_TRY(big(b.mlp1, s->ks_1, h, s->P1.as<float>()));
+      launch_dec_gelu_fold(st, dst, n, s->P1.as<float>(), s->ks_1, S, 4 * d, b.mlp1.b, hm);
+      WB_TRY(big(b.mlp2, s->ks_2, hm, s->P2.as<float>()));
+      pend = s->P2.as<float>(); ks_pend = s->ks_2; pbias = b.mlp2.b;
+    }
+    if (k > 0) {
+      launch_dec_resolve_ln(st, dst, n, xb[xi], xb[xi ^ 1], pend, ks_pend, S, pbias, d, m->ln_dec, m->ln_eps_inside_sqrt, h);
+      ScopedTimer tm_logits(st, 6);
+      GemmArgs g;
+      g.A = h; g.lda = d; g.B = m->tok_emb_t; g.ldb = m->vocab_ld; g.C = s->logits.as<float>(); g.ldc = V;
+      g.M = n; g.N = V; g.K = d;
+      WB_REQUIRE(launch_gemm_f32(st, g) == 0, WB_ERR_SHAPE, "logits gemm: unsupported shape");
+      tm_logits.stop();
+      launch_dec_topk_rows(st, dst, n, s->logits.as<float>(), V, s->mask.as<float>(), use_mask, k, out_id_dev,
+                           out_lp_dev, s->row_stats.as<float>(), L, gctl, s->gtok.as<int>(), s->Lmax, eot);
+      if (timed && tm_logits.on) {
+        WB_HIP(hipStreamSynchronize(st));
+        tm_logits.collect();
+        profile().ms[7] += 1;
+      }
+    }
+    return WB_OK;
+  }
   for (int l = 0; l < NL; l++) {   // ResidualDecoderAttentionBlock::forward, mod.rs:345-350
     const DecBlockW& b = m->dec[l];
     ln_gemv(gemv(b.qkv, s->ks_qkv, s->ksl_qkv, PRO_PLAIN, nullptr, d, s->Pqkv.as<float>()),
@@ -390,7 +447,7 @@ static int launch_step(wb_session* s, int n_launch, int k, int use_mask, bool fu
   auto mix = [&](uint64_t v) { sig = (sig ^ v) * 1099511628211ull; };
   for (const wb::DevMem* b : {&s->kc, &s->vc, &s->tabs, &s->state, &s->x, &s->h, &s->att, &s->Pqkv, &s->Po, &s->Pq,
                               &s->P1, &s->P2, &s->ca, &s->logits, &s->tstats, &s->row_stats, &s->mask, &s->ckv,
-                              &s->win_meta, &s->gctl, &s->gtok})
+                              &s->win_meta, &s->gctl, &s->gtok, &s->hm})
     mix((uint64_t)(uintptr_t)b->p);
   mix((uint64_t)(uintptr_t)s->host_block_dev);
   for (int v : {s->S, s->W, s->Lmax, s->n_chunks, s->max_beams, m->ln_eps_inside_sqrt, eot}) mix((uint64_t)(int64_t)v);
