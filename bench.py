@@ -122,12 +122,22 @@ def main() -> None:
         n_rows = (hi - lo) * args.beam
         # logits GEMV: streams E^T [d][V] once, reads n rows of d, writes n rows of V (f32)
         algo_bytes = 4.0 * (V * d + n_rows * d + n_rows * V)
+        # measured HBM bytes per launch of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+        # same command, corrected per MI355X_MICROARCH.md (profiles/summarize_pmc.py); only valid for the
+        # workload the counters were collected on
+        traffic = None
+        pmc_json = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic_tiny_en_30s.json")
+        if args.model in ("tiny.en", "tiny_en") and n_rows == 3 and os.path.exists(pmc_json):
+            for kname, nbytes in json.load(open(pmc_json)).items():
+                if "dec_gemv_kernel" in kname and "true, true" in kname:
+                    traffic = int(nbytes)
         if n_logit > 0 and logit_ms > 0:
             avg_s = logit_ms / n_logit * 1e-3
             ach = algo_bytes / avg_s / 1e9
-            roofline = {"kernel": "dec_gemv_kernel (tied-embedding logits, E^T [d][V] f32)", "bound": "hbm",
+            roofline = {"kernel": "dec_gemv_kernel<.., LN, STATS> (tied-embedding logits over E^T [d][V] f32 "
+                                  "+ per-tile log-softmax/top-k statistics)", "bound": "hbm",
                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "algorithmic_bytes_per_launch": int(algo_bytes),
                         "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": int(n_logit)}
         stages = {"mel_ms_per_step": round(mel_ms / n_prof, 4), "encoder_ms_per_step": round(enc_ms / n_prof, 4),

@@ -110,16 +110,15 @@ int wb_prep_audio(int device, const float* pcm, int64_t n, double sample_rate, f
   WB_TRY(d_pcm.alloc((size_t)n * 4));
   WB_TRY(d_out.alloc((size_t)80 * T * 4));
   WB_TRY(d_win.alloc(sizeof(MelWindow)));
-  WB_TRY(d_max.alloc(4));
+  WB_TRY(d_max.alloc((size_t)mel_bmax_stride(T) * 4));
   MelWindow w{0, (int32_t)n, T, T, 0};
   hipStream_t st = nullptr;
   WB_HIP(hipMemcpyAsync(d_pcm.p, pcm, (size_t)n * 4, hipMemcpyHostToDevice, st));
   WB_HIP(hipMemcpyAsync(d_win.p, &w, sizeof(w), hipMemcpyHostToDevice, st));
-  launch_fill_f32(st, d_max.as<float>(), 1, -INFINITY);
   launch_mel_spectrogram(st, d_pcm.as<float>(), d_win.as<MelWindow>(), 1, T, tabs, d_out.as<float>(),
                          (int64_t)80 * T, T, d_max.as<float>());
   launch_mel_finalize(st, d_win.as<MelWindow>(), 1, T, 0, d_out.as<float>(), (int64_t)80 * T, T,
-                      d_max.as<float>());
+                      d_max.as<float>(), T);
   WB_HIP(hipGetLastError());
   WB_HIP(hipMemcpyAsync(mel, d_out.p, (size_t)80 * T * 4, hipMemcpyDeviceToHost, st));
   WB_HIP(hipStreamSynchronize(st));

@@ -21,7 +21,6 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 16;
 constexpr int NT = 256;
 enum { AMODE_ROWS = 0, AMODE_CONV1 = 1 };
 
@@ -29,8 +28,9 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
-template <int BM, int BN, int WGM, int WGN, int AMODE>
+template <int BM, int BN, int WGM, int WGN, int AMODE, int BK>
 __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
+  constexpr int KQ = BK / 4;   // float4 quads per A row per k-tile
   constexpr int TM = BM / WGM, TN = BN / WGN;
   constexpr int RM = TM / 32, RN = TN / 32;
   constexpr int LDA_S = BM + 4, LDB_S = BN + 4;
@@ -45,12 +45,12 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
   const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
   const int M = g.M, N = g.N, K = g.K;
   // split-K (decode batch mode): slice blockIdx.z of the K range, raw partial sums to C + z * c_split_stride
-  const int kchunk = g.ksplit > 1 ? ((K + g.ksplit - 1) / g.ksplit + BK - 1) / BK * BK : K;
+  const int kchunk = g.ksplit > 1 ? ((K + g.ksplit - 1) / g.ksplit + 31) / 32 * 32 : K;   // launchers keep K-slices multiples of 32
   const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
   float* Cout = g.C + (int64_t)blockIdx.z * g.c_split_stride;
 
   // ---- A staging: per-thread rows are fixed over the k loop ----
-  constexpr int A_F4 = (AMODE == AMODE_ROWS) ? (BM * 4 + NT - 1) / NT : 0;   // float4 loads / thread / tile
+  constexpr int A_F4 = (AMODE == AMODE_ROWS) ? (BM * KQ + NT - 1) / NT : 0;   // float4 loads / thread / tile
   constexpr int A_EL = (AMODE == AMODE_CONV1) ? (BM * BK) / NT : 0;          // scalar loads / thread / tile
   const float* a_row[A_F4 > 0 ? A_F4 : 1];
   int a_klo[A_F4 > 0 ? A_F4 : 1], a_khi[A_F4 > 0 ? A_F4 : 1];
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
   if constexpr (AMODE == AMODE_ROWS) {
 #pragma unroll
     for (int i = 0; i < A_F4; i++) {
-      int idx = tid + i * NT, r = idx >> 2;
+      int idx = tid + i * NT, r = idx / KQ;
       int m = m0 + r;
       a_row[i] = nullptr; a_klo[i] = 0; a_khi[i] = 0;
       if (r < BM && m < M) {
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
     if constexpr (AMODE == AMODE_ROWS) {
 #pragma unroll
       for (int i = 0; i < A_F4; i++) {
-        int idx = tid + i * NT, kq = (idx & 3) * 4;
+        int idx = tid + i * NT, kq = (idx % KQ) * 4;
         int k = k0 + kq;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (a_row[i] != nullptr && k + 3 >= a_klo[i] && k < a_khi[i]) {
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
     if constexpr (AMODE == AMODE_ROWS) {
 #pragma unroll
       for (int i = 0; i < A_F4; i++) {
-        int idx = tid + i * NT, r = idx >> 2, kq = (idx & 3) * 4;
+        int idx = tid + i * NT, r = idx / KQ, kq = (idx % KQ) * 4;
         if (r < BM) {
           As[buf][kq + 0][r] = ra[i].x; As[buf][kq + 1][r] = ra[i].y;
           As[buf][kq + 2][r] = ra[i].z; As[buf][kq + 3][r] = ra[i].w;
@@ -209,17 +209,17 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int AMODE>
+template <int BM, int BN, int WGM, int WGN, int AMODE, int BK = 16>
 void launch_cfg(hipStream_t st, const GemmArgs& a) {
   dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.ksplit > 1 ? a.ksplit : 1);
-  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, AMODE>), grid, dim3(NT), 0, st, a);
+  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, AMODE, BK>), grid, dim3(NT), 0, st, a);
 }
 
 }  // namespace
 
 int launch_gemm_f32(hipStream_t st, const GemmArgs& a) {
   if (a.M <= 0 || a.N <= 0) return 0;
-  if (a.K % BK != 0 || a.ldb % 4 != 0) return -1;
+  if (a.K % 16 != 0 || a.ldb % 4 != 0) return -1;
   if (a.ksplit > 1 && (a.bias || a.residual || a.aux || a.act != ACT_NONE || a.col_scale_period > 0)) return -1;
   const bool conv1 = a.conv1_tstride > 0;
   // pick the largest tile that still gives the 256 CUs >= ~1.5 waves of blocks
@@ -229,8 +229,10 @@ int launch_gemm_f32(hipStream_t st, const GemmArgs& a) {
     else launch_cfg<64, 64, 2, 2, AMODE_CONV1>(st, a);
     return 0;
   }
-  if (a.M <= 32) launch_cfg<32, 128, 1, 4, AMODE_ROWS>(st, a);
-  else if (a.ksplit > 1) launch_cfg<64, 64, 2, 2, AMODE_ROWS>(st, a);
+  if (a.ksplit > 1 && a.K % 32 != 0) return -1;
+  if (a.M <= 32 && a.ksplit > 1) launch_cfg<32, 128, 1, 4, AMODE_ROWS, 32>(st, a);
+  else if (a.M <= 32) launch_cfg<32, 128, 1, 4, AMODE_ROWS>(st, a);
+  else if (a.ksplit > 1) launch_cfg<64, 64, 2, 2, AMODE_ROWS, 32>(st, a);
   else if (blocks(128, 128) >= 384) launch_cfg<128, 128, 2, 2, AMODE_ROWS>(st, a);
   else launch_cfg<64, 64, 2, 2, AMODE_ROWS>(st, a);
   return 0;

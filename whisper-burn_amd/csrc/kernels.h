@@ -14,6 +14,7 @@ struct MelTables {            // device-resident constants, built once per (devi
   int tap_start[80];          // sparse Slaney filterbank rows (audio.rs:67-143)
   int tap_len[80];
   float tap_w[80 * MEL_MAX_TAPS];
+  float tap_wt[MEL_MAX_TAPS * 80];   // the same weights tap-major (coalesced per-lane loads in the kernel)
 };
 // Host-side construction (f32 op order of the reference); returns 0 / -1 if a row has > MAX_TAPS taps.
 int mel_tables_build(double sample_rate, MelTables* host_out);
@@ -26,14 +27,16 @@ struct MelWindow {            // one window of PCM
   int32_t reserved;
 };
 
-// log10(max(mel,1e-10)) for every (window, mel row, frame) + per-window max (pass 1).
-// out[w][m][t] at out + w*win_stride + m*row_stride + t.  gmax[w] must be pre-set to -inf.
+// log10(max(mel,1e-10)) for every (window, mel row, frame) + per-block maxima (pass 1).
+// out[w][m][t] at out + w*win_stride + m*row_stride + t.  bmax: n_windows * mel_bmax_stride(max_frames) floats.
+int mel_bmax_stride(int max_frames);
 void launch_mel_spectrogram(hipStream_t st, const float* pcm, const MelWindow* wins_dev, int n_windows,
                             int max_frames, const MelTables* tabs_dev, float* out, int64_t win_stride,
-                            int row_stride, float* gmax_dev);
+                            int row_stride, float* bmax_dev);
 // pass 2: max(x, gmax-8), (x+4)/4 ; frames [n_frames, n_frames+pad) := 0   (audio.rs:52-53, transcribe.rs:171-177)
 void launch_mel_finalize(hipStream_t st, const MelWindow* wins_dev, int n_windows, int max_frames_padded,
-                         int pad, float* out, int64_t win_stride, int row_stride, const float* gmax_dev);
+                         int pad, float* out, int64_t win_stride, int row_stride, const float* bmax_dev,
+                         int max_frames);
 void launch_fill_f32(hipStream_t st, float* p, int64_t n, float v);
 
 // ---- GEMM (gemm.hip): C = act(A*B + bias) (+ residual) (+ aux[aux_idx[m]]) --------------

@@ -21,6 +21,10 @@
 #include "kernels.h"
 #include "wave_ops.h"
 
+#ifndef MEL_STAGE_LIMIT
+#define MEL_STAGE_LIMIT 99   // developer probe (tools/mel_probe.cpp): cut the kernel after stage N
+#endif
+
 namespace wb {
 
 namespace {
@@ -30,7 +34,7 @@ constexpr int PAIRS = FPB / 2;   // 16
 constexpr int MEL_THREADS = PAIRS * 20;   // 320
 constexpr int FROW = 426;        // LDS floats per frame row: 2*FROW = 852 >= 840 (U) and 852 % 32 == 20
 constexpr int UROW = 21;         // padded row (float2) of the 20x20 intermediate
-constexpr int OT_LD = FPB + 1;   // out tile leading dim
+constexpr int OT_OFF = 416;      // a pair's 2 x 80 outputs live behind its two 208-float power spectra
 
 struct cpx { float re, im; };
 
@@ -92,19 +96,12 @@ __device__ __forceinline__ void dft20(cpx (&x)[20]) {
   }
 }
 
-__device__ __forceinline__ void atomic_max_float(float* addr, float v) {
-  // monotone int punning: non-negative floats order as ints, negative ones reversed as uints
-  if (v >= 0.f)
-    atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
-  else
-    atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
-}
-
-__global__ __launch_bounds__(MEL_THREADS) void mel_spectrogram_kernel(
+__global__ __launch_bounds__(MEL_THREADS, 3) void mel_spectrogram_kernel(
     const float* __restrict__ pcm, const MelWindow* __restrict__ wins, const MelTables* __restrict__ tabs,
-    float* __restrict__ out, int64_t win_stride, int row_stride, float* __restrict__ gmax) {
-  __shared__ __attribute__((aligned(16))) float lds[PAIRS * 2 * FROW + MEL_N_MELS * OT_LD];
-  float* otile = lds + PAIRS * 2 * FROW;
+    float* __restrict__ out, int64_t win_stride, int row_stride, float* __restrict__ gmax, int bmax_stride) {
+  // 16 x 852 floats = 54 528 B: three blocks per CU (163 584 B of the 160 KiB); every stage aliases the same
+  // pair-private regions (frame rows -> U -> Z -> power spectra + this pair's 2 x 80 outputs)
+  __shared__ __attribute__((aligned(16))) float lds[PAIRS * 2 * FROW];
 
   const MelWindow w = wins[blockIdx.y];
   const int f0 = blockIdx.x * FPB;
@@ -113,33 +110,64 @@ __global__ __launch_bounds__(MEL_THREADS) void mel_spectrogram_kernel(
   const int N = w.n_samples;
   const float* x = pcm + w.pcm_off;
 
-  // ---- stage 0: frames -> LDS rows, reflect indexing (audio.rs:297-306), Hann applied ----
-  for (int e = tid; e < FPB * MEL_N_FFT; e += MEL_THREADS) {
-    int fr = e / MEL_N_FFT, n = e - fr * MEL_N_FFT;
-    int j = (f0 + fr) * MEL_HOP + n - MEL_N_FFT / 2;
-    if (j < 0) j = -j;
-    if (j >= N) j = 2 * (N - 1) - j;
-    j = max(0, min(j, N - 1));   // frames past the window's last frame are never emitted
-    lds[fr * FROW + n] = x[j] * tabs->hann[n];
+  // ---- stage 0: the block's contiguous PCM span (31 hops + 400 = 5360 samples) is read ONCE, coalesced,
+  // with reflect indexing at the window edges (audio.rs:297-306); every sample is scattered to the <= 3
+  // frame rows that contain it.  The Hann window is applied in stage 1 from per-lane registers.
+  constexpr int SPAN = (FPB - 1) * MEL_HOP + MEL_N_FFT;   // 5360
+  constexpr int S0_ITERS = (SPAN + MEL_THREADS - 1) / MEL_THREADS;   // 17
+  {
+    float xv[S0_ITERS];
+    const int g0 = f0 * MEL_HOP - MEL_N_FFT / 2;
+#pragma unroll
+    for (int i = 0; i < S0_ITERS; i++) {
+      const int g = tid + i * MEL_THREADS;
+      int j = g0 + g;
+      if (j < 0) j = -j;
+      if (j >= N) j = 2 * (N - 1) - j;
+      j = max(0, min(j, N - 1));   // frames past the window's last frame are never emitted
+      xv[i] = g < SPAN ? x[j] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < S0_ITERS; i++) {
+      const int g = tid + i * MEL_THREADS;
+      if (g < SPAN) {
+        const int fhi = min(g / MEL_HOP, FPB - 1);          // last frame that starts at or before g
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const int fr = fhi - k, n = g - fr * MEL_HOP;
+          if (fr >= 0 && n < MEL_N_FFT) lds[fr * FROW + n] = xv[i];
+        }
+      }
+    }
   }
   __syncthreads();
 
+  if constexpr (MEL_STAGE_LIMIT <= 0) { if (lds[tid] == 123.456f) out[0] = 1.f; return; }
   const int p = tid / 20, q = tid - p * 20;
   float* reg = lds + p * 2 * FROW;   // this pair's private region
+  // this lane's constants (twiddles W400^{q k1}, filterbank rows q, q+20, q+40, q+60): one batch of loads
+  // whose latency hides under the first DFT
+  float2 twv[20];
+#pragma unroll
+  for (int k1 = 0; k1 < 20; k1++) twv[k1] = tabs->tw[q * 20 + k1];
   cpx z[20];
   // ---- stage 1: 20-point DFT over n1 of z[n1] = xa[20 n1 + q] + i xb[20 n1 + q] ----
 #pragma unroll
-  for (int n1 = 0; n1 < 20; n1++) z[n1] = {reg[20 * n1 + q], reg[FROW + 20 * n1 + q]};
+  for (int n1 = 0; n1 < 20; n1++) {
+    const float hw = tabs->hann[20 * n1 + q];   // periodic Hann (audio.rs:272-278); L1-resident, same for every block
+    z[n1] = {reg[20 * n1 + q] * hw, reg[FROW + 20 * n1 + q] * hw};
+  }
   dft20(z);
   __syncthreads();   // everyone has consumed the frame rows; region becomes U[k1][n2]
   float2* U = reinterpret_cast<float2*>(reg);
 #pragma unroll
   for (int k1 = 0; k1 < 20; k1++) {
-    float2 t = tabs->tw[q * 20 + k1];
+    const float2 t = twv[k1];
     cpx v = cmul(z[k1], t.x, t.y);
     U[k1 * UROW + q] = make_float2(v.re, v.im);
   }
   __syncthreads();
+  if constexpr (MEL_STAGE_LIMIT <= 1) { if (lds[tid] == 123.456f) out[0] = 1.f; return; }
   // ---- stage 2: 20-point DFT over n2 for k1 = q: Z[q + 20 k2] ----
 #pragma unroll
   for (int n2 = 0; n2 < 20; n2++) {
@@ -152,6 +180,7 @@ __global__ __launch_bounds__(MEL_THREADS) void mel_spectrogram_kernel(
 #pragma unroll
   for (int k2 = 0; k2 < 20; k2++) Z[q + 20 * k2] = make_float2(z[k2].re, z[k2].im);
   __syncthreads();
+  if constexpr (MEL_STAGE_LIMIT <= 2) { if (lds[tid] == 123.456f) out[0] = 1.f; return; }
   // ---- stage 3: split the packed transform, power spectrum of both frames ----
   // A[k] = (Z[k] + conj Z[400-k]) / 2,  B[k] = (Z[k] - conj Z[400-k]) / (2i)
   float pa[11], pb[11];
@@ -174,50 +203,81 @@ __global__ __launch_bounds__(MEL_THREADS) void mel_spectrogram_kernel(
     if (k <= 200) { P[k] = pa[i]; P[208 + k] = pb[i]; }
   }
   __syncthreads();
+  if constexpr (MEL_STAGE_LIMIT <= 3) { if (lds[tid] == 123.456f) out[0] = 1.f; return; }
   // ---- stage 4: sparse mel filterbank, log10, local max ----
+  // lane = frame, half-wave = group of 8 mel rows: the filter taps are uniform over each half-wave
+  // (broadcast loads), only the power spectra come from LDS
   const float LN10 = 2.30258509299404568402f;   // (f32) ln 10, helper.rs:25
   float lmax = -INFINITY;
+  {
+    const int f = tid & (FPB - 1), grp = tid >> 5;            // 10 groups x 8 rows
+    float* fr_reg = lds + (f >> 1) * 2 * FROW;
+    const float* Pf = fr_reg + (f & 1) * 208;
+    const bool live = f0 + f < w.n_frames;
+    int s0v[8], lenv[8];
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
-    int m = q + 20 * r;
-    int s = tabs->tap_start[m], len = tabs->tap_len[m];
-    float sa = 0.f, sb = 0.f;
-    for (int t = 0; t < len; t++) {
-      float wv = tabs->tap_w[m * MEL_MAX_TAPS + t];
-      sa += wv * P[s + t];
-      sb += wv * P[208 + s + t];
+    for (int r = 0; r < 8; r++) { s0v[r] = tabs->tap_start[grp * 8 + r]; lenv[r] = tabs->tap_len[grp * 8 + r]; }
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const int m = grp * 8 + r;
+      const int s0 = s0v[r], len = lenv[r];
+      float acc = 0.f;
+#if !defined(MEL_DBG_NOTAPS)
+      for (int t = 0; t < len; t++) acc += tabs->tap_w[m * MEL_MAX_TAPS + t] * Pf[s0 + t];
+#else
+      acc = Pf[s0] + (float)len;
+#endif
+      // tensor_max_scalar(x, 1e-10) = relu(x - 1e-10) + 1e-10 (helper.rs:8-10); log10 = ln/ln10 (:24-27)
+#if !defined(MEL_DBG_NOLOG)
+      const float v = logf(fmaxf(acc - 1.0e-10f, 0.f) + 1.0e-10f) / LN10;
+#else
+      const float v = acc;
+#endif
+      fr_reg[OT_OFF + 2 * m + (f & 1)] = v;
+      if (live) lmax = fmaxf(lmax, v);
     }
-    // tensor_max_scalar(x, 1e-10) = relu(x - 1e-10) + 1e-10 (helper.rs:8-10); log10 = ln/ln10 (:24-27)
-    float va = logf(fmaxf(sa - 1.0e-10f, 0.f) + 1.0e-10f) / LN10;
-    float vb = logf(fmaxf(sb - 1.0e-10f, 0.f) + 1.0e-10f) / LN10;
-    otile[m * OT_LD + 2 * p] = va;
-    otile[m * OT_LD + 2 * p + 1] = vb;
-    if (f0 + 2 * p < w.n_frames) lmax = fmaxf(lmax, va);
-    if (f0 + 2 * p + 1 < w.n_frames) lmax = fmaxf(lmax, vb);
   }
   lmax = wave_max(lmax);
-  if ((tid & 63) == 0 && lmax > -INFINITY) atomic_max_float(&gmax[blockIdx.y], lmax);
+  if ((tid & 63) == 0) lds[OT_OFF + 200 + (tid >> 6)] = lmax;   // free tail of pair 0's region
   __syncthreads();
+  // one value per block, reduced by the finalize pass: no atomics (235 of them per window would
+  // serialise on one L2 word)
+  if (tid == 0) {
+    float bm = lds[OT_OFF + 200];
+#pragma unroll
+    for (int i = 1; i < MEL_THREADS / 64; i++) bm = fmaxf(bm, lds[OT_OFF + 200 + i]);
+    gmax[(int64_t)blockIdx.y * bmax_stride + blockIdx.x] = bm;
+  }
+  if constexpr (MEL_STAGE_LIMIT <= 4) { if (lds[tid] == 123.456f) out[0] = 1.f; return; }
   // ---- stage 5: coalesced store of the [80][32] tile ----
   float* o = out + (int64_t)blockIdx.y * win_stride + f0;
   const int nf = min(FPB, w.n_emit - f0);
   for (int e = tid; e < MEL_N_MELS * FPB; e += MEL_THREADS) {
     int m = e / FPB, f = e - m * FPB;
-    if (f < nf) o[(int64_t)m * row_stride + f] = otile[m * OT_LD + f];
+    if (f < nf) o[(int64_t)m * row_stride + f] = lds[(f >> 1) * 2 * FROW + OT_OFF + 2 * m + (f & 1)];
   }
 }
 
 __global__ void mel_finalize_kernel(const MelWindow* __restrict__ wins, int max_frames_padded, int pad,
                                     float* __restrict__ out, int64_t win_stride, int row_stride,
-                                    const float* __restrict__ gmax) {
+                                    const float* __restrict__ bmax, int bmax_stride) {
+  __shared__ float wmax;
   const int w = blockIdx.z, m = blockIdx.y;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (threadIdx.x < 64) {   // global max of the window (audio.rs:50) = max over its blocks' maxima
+    const int nblk = (wins[w].n_frames + FPB - 1) / FPB;
+    float v = -INFINITY;
+    for (int i = threadIdx.x; i < nblk; i += 64) v = fmaxf(v, bmax[(int64_t)w * bmax_stride + i]);
+    v = wave_max(v);
+    if (threadIdx.x == 0) wmax = v;
+  }
+  __syncthreads();
   if (t >= max_frames_padded) return;
   const int nf = wins[w].n_emit;
   float* p = out + (int64_t)w * win_stride + (int64_t)m * row_stride + t;
   if (t < nf) {
     // audio.rs:50-53: max computed as f64 from the f32 max, (max - 8.0) handed back as f32
-    const float m8 = (float)((double)gmax[w] - 8.0);
+    const float m8 = (float)((double)wmax - 8.0);
     float v = fmaxf(*p - m8, 0.f) + m8;
     *p = (v + 4.0f) / 4.0f;
   } else if (t < nf + pad) {
@@ -232,19 +292,22 @@ __global__ void fill_f32_kernel(float* p, int64_t n, float v) {
 
 }  // namespace
 
+int mel_bmax_stride(int max_frames) { return (max_frames + FPB - 1) / FPB; }
+
 void launch_mel_spectrogram(hipStream_t st, const float* pcm, const MelWindow* wins_dev, int n_windows,
                             int max_frames, const MelTables* tabs_dev, float* out, int64_t win_stride,
-                            int row_stride, float* gmax_dev) {
+                            int row_stride, float* bmax_dev) {
   dim3 grid((max_frames + FPB - 1) / FPB, n_windows);
   hipLaunchKernelGGL(mel_spectrogram_kernel, grid, dim3(MEL_THREADS), 0, st, pcm, wins_dev, tabs_dev, out,
-                     win_stride, row_stride, gmax_dev);
+                     win_stride, row_stride, bmax_dev, mel_bmax_stride(max_frames));
 }
 
 void launch_mel_finalize(hipStream_t st, const MelWindow* wins_dev, int n_windows, int max_frames_padded,
-                         int pad, float* out, int64_t win_stride, int row_stride, const float* gmax_dev) {
+                         int pad, float* out, int64_t win_stride, int row_stride, const float* bmax_dev,
+                         int max_frames) {
   dim3 grid((max_frames_padded + 255) / 256, MEL_N_MELS, n_windows);
   hipLaunchKernelGGL(mel_finalize_kernel, grid, dim3(256), 0, st, wins_dev, max_frames_padded, pad, out,
-                     win_stride, row_stride, gmax_dev);
+                     win_stride, row_stride, bmax_dev, mel_bmax_stride(max_frames));
 }
 
 void launch_fill_f32(hipStream_t st, float* p, int64_t n, float v) {
@@ -314,7 +377,10 @@ int mel_tables_build(double sample_rate, MelTables* t) {
     if (len > MEL_MAX_TAPS) return -1;
     t->tap_start[i] = s;
     t->tap_len[i] = len;
-    for (int k = 0; k < len; k++) t->tap_w[i * MEL_MAX_TAPS + k] = W[i][s + k];
+    for (int k = 0; k < len; k++) {
+      t->tap_w[i * MEL_MAX_TAPS + k] = W[i][s + k];
+      t->tap_wt[k * MEL_N_MELS + i] = W[i][s + k];   // tap-major copy: lanes of a pair read consecutive rows
+    }
   }
   return 0;
 }

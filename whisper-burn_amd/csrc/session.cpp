@@ -127,7 +127,7 @@ int session_encode_pcm(wb_session* s, const float* pcm, int64_t n_pcm, const int
   WB_TRY(get_mel_tables(m->device, s->sample_rate, &tabs));
   if (!pcm_on_device) WB_TRY(s->pcm.ensure((size_t)(hi - lo) * 4));
   WB_TRY(s->wins.ensure(wins.size() * sizeof(MelWindow)));
-  WB_TRY(s->gmax.ensure((size_t)s->W * 4));
+  WB_TRY(s->gmax.ensure((size_t)s->W * mel_bmax_stride(maxF) * 4));
   WB_TRY(s->mel.ensure((size_t)s->W * 80 * Ts * 4));
   if (!pcm_on_device) WB_HIP(hipMemcpyAsync(s->pcm.p, pcm + lo, (size_t)(hi - lo) * 4, hipMemcpyHostToDevice, s->st));
   const float* pcm_dev = pcm_on_device ? pcm : s->pcm.as<float>();
@@ -135,11 +135,10 @@ int session_encode_pcm(wb_session* s, const float* pcm, int64_t n_pcm, const int
   WB_HIP(hipStreamSynchronize(s->st));   // `wins` is a stack vector
   {
     ScopedTimer tm(s->st, 0);
-    launch_fill_f32(s->st, s->gmax.as<float>(), s->W, -INFINITY);
     launch_mel_spectrogram(s->st, pcm_dev, s->wins.as<MelWindow>(), s->W, maxF, tabs, s->mel.as<float>(),
                            (int64_t)80 * Ts, Ts, s->gmax.as<float>());
     launch_mel_finalize(s->st, s->wins.as<MelWindow>(), s->W, Ts, s->padding, s->mel.as<float>(), (int64_t)80 * Ts,
-                        Ts, s->gmax.as<float>());
+                        Ts, s->gmax.as<float>(), maxF);
     tm.stop();
     if (tm.on) { WB_HIP(hipStreamSynchronize(s->st)); tm.collect(); profile().ms[5] += 1; }
   }
@@ -263,7 +262,7 @@ void wb_session_free(wb_session* s) {
   if (!s) return;
   std::lock_guard<std::mutex> lk(g_pool_mu);
   auto& v = g_pool[s->m];
-  if (v.size() < 2) { v.push_back(s); return; }   // keep the allocations for the next batch
+  if (v.size() < 8) { v.push_back(s); return; }   // keep the allocations (and captured graphs) for the next batch
   (void)hipSetDevice(s->m->device);
   delete s;
 }
@@ -458,7 +457,9 @@ static int launch_step(wb_session* s, int n_launch, int k, int use_mask, bool fu
   if (it == s->graphs.end()) {
     hipGraph_t g = nullptr;
     hipGraphExec_t ge = nullptr;
-    WB_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    static std::mutex capture_mu;                      // captures are rare; keep them off each other's toes
+    std::lock_guard<std::mutex> lk(capture_mu);
+    WB_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
     int rc = enqueue_step(s, n_launch, k, use_mask, fuse_ln, max_nb, false, chained, eot);
     hipError_t e = hipStreamEndCapture(st, &g);
     WB_TRY(rc);
