@@ -52,6 +52,7 @@ struct GemvArgs {
   // STATS epilogue (logits): + mask, per-tile max / sum-exp / top-k -> tstats [row][n_tiles][TS_STRIDE]
   const float* mask = nullptr; int use_mask = 0, topk = 0; float* tstats = nullptr;
   const int* st = nullptr; int S = 0;
+  int ct = 0;                               // columns per block (0 = 128); multiple of 4
 };
 
 void gemv_plan(int K, int N, int* KS, int* KSL);

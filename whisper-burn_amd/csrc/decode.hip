@@ -149,12 +149,13 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(GemvArgs a) {
   static_assert(MR * XLD >= 4 * MR * GV_CT, "reduction buffer must fit");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, c4 = (lane & 31) * 4;
-  const int n0 = blockIdx.x * GV_CT, ks = blockIdx.y;
+  const int ct = a.ct > 0 ? a.ct : GV_CT;          // columns per block (<= 128): chosen for an even split over the CUs
+  const int n0 = blockIdx.x * ct, ks = blockIdx.y;
   const int k0 = ks * a.KSL;
   const int kn = min(a.KSL, a.K - k0);          // rows of this slice (multiple of 32)
   const int n_rows = a.st[ST_N];
   const int unit = wave * 2 + half;
-  const bool col_ok = (n0 + c4) < a.ldw;
+  const bool col_ok = (n0 + c4) < a.ldw && c4 < ct;
   const float* Wp = a.W + (int64_t)k0 * a.ldw + n0 + c4;
   const int64_t ldw = a.ldw;
 
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(GemvArgs a) {
       const int r = e / GV_CT, c = e - r * GV_CT;
       const int row = r0 + r, col = n0 + c;
       float v = -INFINITY;
-      if (row < n_rows && col < a.N) {
+      if (row < n_rows && col < a.N && c < ct) {
         v = (xbuf[(0 * MR + r) * GV_CT + c] + xbuf[(1 * MR + r) * GV_CT + c]) +
             (xbuf[(2 * MR + r) * GV_CT + c] + xbuf[(3 * MR + r) * GV_CT + c]);
         a.P[((int64_t)ks * a.S + row) * a.N + col] = v;
@@ -778,7 +779,8 @@ static void launch_gemv_dpl(hipStream_t st, dim3 grid, const GemvArgs& a) {
 }
 
 void launch_dec_gemv(hipStream_t st, const GemvArgs& a, int n_rows_hint, bool stats) {
-  dim3 grid((a.N + GV_CT - 1) / GV_CT, a.KS);
+  const int ct = a.ct > 0 ? a.ct : GV_CT;
+  dim3 grid((a.N + ct - 1) / ct, a.KS);
   const bool ln = a.pro == PRO_LN;
   if (stats) {   // logits: LN prologue over whole rows + tile statistics; rows chunked by <= 8
     if (n_rows_hint <= 4) launch_gemv_dpl<4, DMAX, true, true>(st, grid, a);
