@@ -38,6 +38,8 @@ def main() -> None:
     ap.add_argument("--beam", type=int, default=1)
     ap.add_argument("--max-depth", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32 = exact-f32 MFMA parity path (the judged configuration); bf16 = speed path")
     args = ap.parse_args()
 
     import torch
@@ -62,7 +64,8 @@ def main() -> None:
 
     lib = _lib.load()
     weights = synth.synth_preset(args.model)
-    eng = wb.Whisper.from_tensors(weights, device=local_rank)
+    eng = wb.Whisper.from_tensors(weights, device=local_rank,
+                                  compute_dtype=wb.WB_BF16 if args.dtype == "bf16" else wb.WB_F32)
     V = eng.dims["n_vocab"]
     st = wb.SpecialTokens.for_vocab(V)
     params = wb.decode_params(st, beam_size=args.beam, max_depth=args.max_depth)
@@ -121,13 +124,13 @@ def main() -> None:
         lo, hi = shard.partition_windows(n_win, rank, world)
         n_rows = (hi - lo) * args.beam
         # logits GEMV: streams E^T [d][V] once, reads n rows of d, writes n rows of V (f32)
-        algo_bytes = 4.0 * (V * d + n_rows * d + n_rows * V)
+        algo_bytes = (2.0 if args.dtype == "bf16" else 4.0) * V * d + 4.0 * (n_rows * d + n_rows * V)
         # measured HBM bytes per launch of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
         # same command, corrected per MI355X_MICROARCH.md (profiles/summarize_pmc.py); only valid for the
         # workload the counters were collected on
         traffic = None
         pmc_json = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic_tiny_en_30s.json")
-        if args.model in ("tiny.en", "tiny_en") and n_rows == 3 and os.path.exists(pmc_json):
+        if args.model in ("tiny.en", "tiny_en") and n_rows == 3 and args.dtype == "f32" and os.path.exists(pmc_json):
             for kname, nbytes in json.load(open(pmc_json)).items():
                 if "dec_gemv_kernel" in kname and "true, true" in kname:
                     traffic = int(nbytes)
@@ -181,7 +184,7 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic (seeded synthetic weights at the real shapes; seeded synthetic 16 kHz audio)",
             "config": {"workload": f"{args.model}, {args.seconds:g} s of 16 kHz audio per GPU per step, reference "
                                    f"windowing ({n_win} windows <= 14.9 s, 3 s overlap), HIP mel + encoder + "

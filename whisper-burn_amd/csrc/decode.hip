@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void dec_resolve_ln_kernel(const int* __restri
 // 32-deep step, two steps (8 x 16 B per lane) in flight; input rows staged in LDS with the
 // prologue applied.  LN prologue: one wave per row folds x + pending partials, takes the
 // LayerNorm statistics with shuffles only, and stages the block's K-slice.
-template <int MR, int XLD, int DPL, bool LN, bool STATS>
+template <int MR, int XLD, int DPL, bool LN, bool STATS, bool WBF>
 __global__ __launch_bounds__(256) void dec_gemv_kernel(GemvArgs a) {
   __shared__ __attribute__((aligned(16))) float xbuf[MR * XLD];   // input rows; later the cross-wave reduction buffer
   __shared__ float tilev[STATS ? MR : 1][GV_CT];
@@ -160,11 +160,19 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(GemvArgs a) {
   const int64_t ldw = a.ldw;
 
   float4 w[8];
+  const uint16_t* Wpb = a.Wb + (int64_t)k0 * a.ldw + n0 + c4;   // speed path: the same [K][ldw] matrix in bf16
   auto load_pair = [&](int kb) {
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const int k = kb + (j >> 2) * 32 + (j & 3);
-      w[j] = (col_ok && k < kn) ? *reinterpret_cast<const float4*>(Wp + k * ldw) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (WBF) {
+        uint2 u = make_uint2(0u, 0u);
+        if (col_ok && k < kn) u = *reinterpret_cast<const uint2*>(Wpb + k * ldw);
+        w[j] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                           __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+      } else {
+        w[j] = (col_ok && k < kn) ? *reinterpret_cast<const float4*>(Wp + k * ldw) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
   };
   load_pair(unit * 4);   // first weight tiles in flight before the prologue touches memory
@@ -768,14 +776,20 @@ void gemv_plan(int K, int N, int* KS, int* KSL) {
   *KS = ks; *KSL = ksl;
 }
 
+struct GemmvDummy;
+template <int MR, int XLD, bool LN, bool STATS, bool WBF>
+static void launch_gemv_dpl2(hipStream_t st, dim3 grid, const GemmvDummy*, const GemvArgs& a) {
+  if (!LN) { hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, 1, LN, STATS, WBF>), grid, dim3(256), 0, st, a); return; }
+  if (a.K <= 384) hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, LN ? 6 : 1, LN, STATS, WBF>), grid, dim3(256), 0, st, a);
+  else if (a.K <= 512) hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, LN ? 8 : 1, LN, STATS, WBF>), grid, dim3(256), 0, st, a);
+  else if (a.K <= 768) hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, LN ? 12 : 1, LN, STATS, WBF>), grid, dim3(256), 0, st, a);
+  else if (a.K <= 1024) hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, LN ? 16 : 1, LN, STATS, WBF>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, LN ? 20 : 1, LN, STATS, WBF>), grid, dim3(256), 0, st, a);
+}
 template <int MR, int XLD, bool LN, bool STATS>
 static void launch_gemv_dpl(hipStream_t st, dim3 grid, const GemvArgs& a) {
-  if (!LN) { hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, 1, LN, STATS>), grid, dim3(256), 0, st, a); return; }
-  if (a.K <= 384) hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, LN ? 6 : 1, LN, STATS>), grid, dim3(256), 0, st, a);
-  else if (a.K <= 512) hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, LN ? 8 : 1, LN, STATS>), grid, dim3(256), 0, st, a);
-  else if (a.K <= 768) hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, LN ? 12 : 1, LN, STATS>), grid, dim3(256), 0, st, a);
-  else if (a.K <= 1024) hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, LN ? 16 : 1, LN, STATS>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, LN ? 20 : 1, LN, STATS>), grid, dim3(256), 0, st, a);
+  if (a.Wb) launch_gemv_dpl2<MR, XLD, LN, STATS, true>(st, grid, nullptr, a);
+  else launch_gemv_dpl2<MR, XLD, LN, STATS, false>(st, grid, nullptr, a);
 }
 
 void launch_dec_gemv(hipStream_t st, const GemvArgs& a, int n_rows_hint, bool stats) {

@@ -32,16 +32,32 @@ static int upload(hipStream_t st, DevMem& dst, const void* src, size_t bytes) {
   return WB_OK;
 }
 
-static int gemm(hipStream_t st, const GemmArgs& a) {
+// Dispatch on the model's compute dtype: exact-f32 MFMA (parity path) or bf16 MFMA (speed path) when the
+// weight has a bf16 copy and the shape fits that kernel (the conv1 gather stays on the f32 kernel).
+int gemm_dispatch(const wb_model* m, hipStream_t st, const GemmArgs& a, const uint16_t* wt, int ldwt) {
+  if (m->compute_dtype == WB_BF16 && wt && a.conv1_tstride == 0 && a.K % 32 == 0 && ldwt % 8 == 0) {
+    WB_REQUIRE(launch_gemm_bf16(st, a, wt, ldwt) == 0, WB_ERR_SHAPE, "bf16 gemm: unsupported shape M=%d N=%d K=%d", a.M,
+               a.N, a.K);
+    return WB_OK;
+  }
   WB_REQUIRE(launch_gemm_f32(st, a) == 0, WB_ERR_SHAPE, "gemm: unsupported shape M=%d N=%d K=%d ldb=%d", a.M,
              a.N, a.K, a.ldb);
   return WB_OK;
+}
+
+// The LinearW a GemmArgs was built from travels in a side slot so call sites stay one-liners.
+static thread_local const LinearW* g_cur_w = nullptr;
+static int gemm(const wb_model* m, hipStream_t st, const GemmArgs& a) {
+  const LinearW* w = g_cur_w;
+  g_cur_w = nullptr;
+  return gemm_dispatch(m, st, a, w ? w->wt : nullptr, w ? w->k : 0);
 }
 
 static GemmArgs linear_args(const float* A, int M, const LinearW& w, float* C) {
   GemmArgs g;
   g.A = A; g.lda = w.k; g.B = w.w; g.ldb = w.n; g.C = C; g.ldc = w.n; g.bias = w.b;
   g.M = M; g.N = w.n; g.K = w.k;
+  g_cur_w = &w;
   return g;
 }
 
@@ -103,7 +119,7 @@ int run_encoder(wb_model* m, hipStream_t st, Workspace& ws, const MelBatch& mb, 
     g.A = mb.mel; g.a_desc = ws.desc1.as<RowDesc>(); g.conv1_tstride = mb.row_stride;
     g.B = m->conv1.w; g.ldb = d; g.C = x1; g.ldc = d; g.bias = m->conv1.b;
     g.M = rows1; g.N = d; g.K = 240; g.act = ACT_GELU;
-    WB_TRY(gemm(st, g));
+    WB_TRY(gemm(m, st, g));
   }
   // conv2 (stride 2) + GELU + transpose + positional add (mod.rs:244-252): rows 2c-1..2c+1 of x1 form one A row
   {
@@ -112,26 +128,27 @@ int run_encoder(wb_model* m, hipStream_t st, Workspace& ws, const MelBatch& mb, 
     g.B = m->conv2.w; g.ldb = d; g.C = x; g.ldc = d; g.bias = m->conv2.b;
     g.M = rows2; g.N = d; g.K = 3 * d; g.act = ACT_GELU;
     g.aux = m->enc_pos; g.aux_idx = ws.auxidx.as<int32_t>(); g.ld_aux = d;
-    WB_TRY(gemm(st, g));
+    g_cur_w = &m->conv2;
+    WB_TRY(gemm(m, st, g));
   }
   for (int i = 0; i < D.n_audio_layer; i++) {   // ResidualEncoderAttentionBlock::forward, mod.rs:299-303
     const EncBlockW& b = m->enc[i];
     launch_layernorm(st, x, h, rows2, d, b.ln1.g, b.ln1.b, b.ln1.eps, m->ln_eps_inside_sqrt);
     GemmArgs g = linear_args(h, rows2, b.qkv, qkv);
     g.col_scale = m->qk_scale; g.col_scale_period = 3 * d; g.col_scale_width = 2 * d;   // q*s, k*s (mod.rs:506-514)
-    WB_TRY(gemm(st, g));
+    WB_TRY(gemm(m, st, g));
     launch_attention_f32(st, qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, att, d, ws.segs.as<AttnSeg>(), nw, maxC, H,
                          1.0f, 0);
     g = linear_args(att, rows2, b.out, x);
     g.residual = x; g.ldr = d;
-    WB_TRY(gemm(st, g));
+    WB_TRY(gemm(m, st, g));
     launch_layernorm(st, x, h, rows2, d, b.ln2.g, b.ln2.b, b.ln2.eps, m->ln_eps_inside_sqrt);
     g = linear_args(h, rows2, b.mlp1, hm);
     g.act = ACT_GELU;
-    WB_TRY(gemm(st, g));
+    WB_TRY(gemm(m, st, g));
     g = linear_args(hm, rows2, b.mlp2, x);
     g.residual = x; g.ldr = d;
-    WB_TRY(gemm(st, g));
+    WB_TRY(gemm(m, st, g));
   }
   launch_layernorm(st, x, out_dev, rows2, d, m->ln_post.g, m->ln_post.b, m->ln_post.eps, m->ln_eps_inside_sqrt);
   WB_HIP(hipGetLastError());
@@ -164,40 +181,40 @@ int run_decoder_stateless(wb_model* m, hipStream_t st, Workspace& ws, const int3
   // cross-attention K/V (mod.rs:484-485) for all layers in one GEMM; K columns pre-scaled (mod.rs:510-514)
   GemmArgs g = linear_args(enc_dev, krows, m->ckv_all, ckv);
   g.col_scale = m->qk_scale; g.col_scale_period = 2 * d; g.col_scale_width = d;
-  WB_TRY(gemm(st, g));
+  WB_TRY(gemm(m, st, g));
   for (int i = 0; i < NL; i++) {   // ResidualDecoderAttentionBlock::forward, mod.rs:345-350
     const DecBlockW& b = m->dec[i];
     launch_layernorm(st, x, h, rows, d, b.ln1.g, b.ln1.b, b.ln1.eps, m->ln_eps_inside_sqrt);
     g = linear_args(h, rows, b.qkv, qkv);
     g.col_scale = m->qk_scale; g.col_scale_period = 3 * d; g.col_scale_width = 2 * d;
-    WB_TRY(gemm(st, g));
+    WB_TRY(gemm(m, st, g));
     launch_attention_f32(st, qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, att, d, sg, n, L, H, 1.0f, 1);
     g = linear_args(att, rows, b.out, x);
     g.residual = x; g.ldr = d;
-    WB_TRY(gemm(st, g));
+    WB_TRY(gemm(m, st, g));
     launch_layernorm(st, x, h, rows, d, b.ln2.g, b.ln2.b, b.ln2.eps, m->ln_eps_inside_sqrt);
     g = linear_args(h, rows, b.cq, qkv);
     g.col_scale = m->qk_scale; g.col_scale_period = d; g.col_scale_width = d;
-    WB_TRY(gemm(st, g));
+    WB_TRY(gemm(m, st, g));
     launch_attention_f32(st, qkv, d, ckv + (size_t)i * 2 * d, ckv + (size_t)i * 2 * d + d, ldkv, att, d, sg + n, n,
                          L, H, 1.0f, 0);
     g = linear_args(att, rows, b.cout, x);
     g.residual = x; g.ldr = d;
-    WB_TRY(gemm(st, g));
+    WB_TRY(gemm(m, st, g));
     launch_layernorm(st, x, h, rows, d, b.ln3.g, b.ln3.b, b.ln3.eps, m->ln_eps_inside_sqrt);
     g = linear_args(h, rows, b.mlp1, hm);
     g.act = ACT_GELU;
-    WB_TRY(gemm(st, g));
+    WB_TRY(gemm(m, st, g));
     g = linear_args(hm, rows, b.mlp2, x);
     g.residual = x; g.ldr = d;
-    WB_TRY(gemm(st, g));
+    WB_TRY(gemm(m, st, g));
   }
   launch_layernorm(st, x, h, rows, d, m->ln_dec.g, m->ln_dec.b, m->ln_dec.eps, m->ln_eps_inside_sqrt);
   // logits = x . token_embedding^T (mod.rs:156), streamed from the [d][Vp] transposed copy
   GemmArgs lg;
   lg.A = h; lg.lda = d; lg.B = m->tok_emb_t; lg.ldb = m->vocab_ld; lg.C = logits_dev; lg.ldc = V;
   lg.M = rows; lg.N = V; lg.K = d;
-  WB_TRY(gemm(st, lg));
+  WB_TRY(gemm_dispatch(m, st, lg, m->tok_emb_bf, m->dims.n_text_state));
   WB_HIP(hipGetLastError());
   return WB_OK;
 }

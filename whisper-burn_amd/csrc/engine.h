@@ -28,6 +28,9 @@ int run_encoder(wb_model* m, hipStream_t st, Workspace& ws, const MelBatch& mb, 
 int run_decoder_stateless(wb_model* m, hipStream_t st, Workspace& ws, const int32_t* tokens_dev, int n, int L,
                           const float* enc_dev, int C, float* logits_dev);
 
+// f32 (parity) or bf16 (speed) MFMA GEMM according to the model's compute dtype; wt = bf16 [N][ldwt] copy or null.
+int gemm_dispatch(const wb_model* m, hipStream_t st, const GemmArgs& a, const uint16_t* wt, int ldwt);
+
 // Process-wide mel constant tables for (device, sample_rate).
 int get_mel_tables(int device, double sample_rate, const MelTables** out_dev);
 

@@ -1,0 +1,189 @@
+// Speed path: bf16 MFMA GEMM (f32 accumulate) with the same fused epilogues as gemm.hip.
+//
+//   C[M,N] = epilogue( bf16(A[M,K]) * Wt[N,K]^T )      Wt = the weight stored bf16, K-contiguous
+//
+// v_mfma_f32_32x32x16_bf16 (16x the rate of the exact-f32 MFMA the parity path uses).  Both
+// operands are K-contiguous, so every fragment is one ds_read_b128 of 8 consecutive bf16; the
+// activations stay f32 in HBM and are rounded to bf16 (RNE) once, on their way into LDS.
+// Rows of the LDS tiles are 80 B apart (32 bf16 + 8 pad): the 16-lane groups of ds_read_b128
+// then land on 16 distinct 16-B slots (conflict-free).
+//
+// Not bit-compatible with the reference's f32 arithmetic: this path is gated on token-exactness
+// tests, never on the 1e-3 logit tolerance.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace wb {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+constexpr int NT = 256;
+constexpr int BK = 32;
+constexpr int LDS_LD = BK + 8;   // bf16 elements per LDS row
+
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ u16 f2bf(float f) {   // round to nearest even
+  unsigned u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (u16)(u >> 16);
+}
+__device__ __forceinline__ uint4 pack8(const float4& a, const float4& b) {
+  uint4 r;
+  r.x = (unsigned)f2bf(a.x) | ((unsigned)f2bf(a.y) << 16);
+  r.y = (unsigned)f2bf(a.z) | ((unsigned)f2bf(a.w) << 16);
+  r.z = (unsigned)f2bf(b.x) | ((unsigned)f2bf(b.y) << 16);
+  r.w = (unsigned)f2bf(b.z) | ((unsigned)f2bf(b.w) << 16);
+  return r;
+}
+
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs g, const u16* __restrict__ Wt, int ldwt) {
+  constexpr int TM = BM / WGM, TN = BN / WGN;
+  constexpr int RM = TM / 32, RN = TN / 32;
+  static_assert(WGM * WGN == 4 && TM % 32 == 0 && TN % 32 == 0, "bad tiling");
+  __shared__ __attribute__((aligned(16))) u16 As[2][BM][LDS_LD];
+  __shared__ __attribute__((aligned(16))) u16 Bs[2][BN][LDS_LD];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+  const int M = g.M, N = g.N, K = g.K;
+  const int kchunk = g.ksplit > 1 ? ((K + g.ksplit - 1) / g.ksplit + BK - 1) / BK * BK : K;
+  const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
+  float* Cout = g.C + (int64_t)blockIdx.z * g.c_split_stride;
+
+  // A: (row, k-octet) items, 8 f32 -> 8 bf16; B: (n, k-octet) items, 16 B each
+  constexpr int A_IT = (BM * (BK / 8) + NT - 1) / NT, B_IT = (BN * (BK / 8) + NT - 1) / NT;
+  const float* a_row[A_IT];
+  int a_klo[A_IT], a_khi[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; i++) {
+    const int idx = tid + i * NT, r = idx / (BK / 8), m = m0 + r;
+    a_row[i] = nullptr; a_klo[i] = 0; a_khi[i] = 0;
+    if (r < BM && m < M) {
+      if (g.a_desc) {
+        const RowDesc d = g.a_desc[m];
+        a_row[i] = g.A + d.off; a_klo[i] = d.klo; a_khi[i] = d.khi;
+      } else {
+        a_row[i] = g.A + (int64_t)m * g.lda; a_khi[i] = K;
+      }
+    }
+  }
+  uint4 ra[A_IT], rb[B_IT];
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < A_IT; i++) {
+      const int idx = tid + i * NT, k = k0 + (idx % (BK / 8)) * 8;
+      float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+      if (a_row[i] != nullptr && k >= a_klo[i] && k + 7 < a_khi[i]) {   // masks are multiples of 8 for every caller
+        lo = *reinterpret_cast<const float4*>(a_row[i] + k);
+        hi = *reinterpret_cast<const float4*>(a_row[i] + k + 4);
+      }
+      ra[i] = pack8(lo, hi);
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; i++) {
+      const int idx = tid + i * NT, r = idx / (BK / 8), k = k0 + (idx % (BK / 8)) * 8, n = n0 + r;
+      rb[i] = (r < BN && n < N) ? *reinterpret_cast<const uint4*>(Wt + (int64_t)n * ldwt + k) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_IT; i++) {
+      const int idx = tid + i * NT, r = idx / (BK / 8), ko = (idx % (BK / 8)) * 8;
+      if (r < BM) *reinterpret_cast<uint4*>(&As[buf][r][ko]) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; i++) {
+      const int idx = tid + i * NT, r = idx / (BK / 8), ko = (idx % (BK / 8)) * 8;
+      if (r < BN) *reinterpret_cast<uint4*>(&Bs[buf][r][ko]) = rb[i];
+    }
+  };
+
+  f32x16 acc[RM][RN];
+#pragma unroll
+  for (int i = 0; i < RM; i++)
+#pragma unroll
+    for (int j = 0; j < RN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  const int nk = max(0, kend - kbeg) / BK;
+  if (nk > 0) {
+    load_tile(kbeg);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int t = 0; t < nk; t++) {
+    const int buf = t & 1;
+    if (t + 1 < nk) load_tile(kbeg + (t + 1) * BK);
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ks++) {
+      bf16x8 a[RM], b[RN];
+#pragma unroll
+      for (int i = 0; i < RM; i++)
+        a[i] = *reinterpret_cast<const bf16x8*>(&As[buf][wm * TM + i * 32 + li][ks * 16 + lh * 8]);
+#pragma unroll
+      for (int j = 0; j < RN; j++)
+        b[j] = *reinterpret_cast<const bf16x8*>(&Bs[buf][wn * TN + j * 32 + li][ks * 16 + lh * 8]);
+#pragma unroll
+      for (int i = 0; i < RM; i++)
+#pragma unroll
+        for (int j = 0; j < RN; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < RM; i++)
+#pragma unroll
+    for (int j = 0; j < RN; j++) {
+      const int col = n0 + wn * TN + j * 32 + li;
+      if (col >= N) continue;
+      const float bias = g.bias ? g.bias[col] : 0.f;
+      float cs = 1.f;
+      if (g.col_scale_period > 0 && (col % g.col_scale_period) < g.col_scale_width) cs = g.col_scale;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row >= M) continue;
+        float v = acc[i][j][r] + bias;
+        if (g.act == ACT_GELU) v = gelu_erf(v);
+        if (g.col_scale_period > 0) v *= cs;
+        if (g.residual) v = g.residual[(int64_t)row * g.ldr + col] + v;
+        if (g.aux) v = v + g.aux[(int64_t)g.aux_idx[row] * g.ld_aux + col];
+        Cout[(int64_t)row * g.ldc + col] = v;
+      }
+    }
+}
+
+template <int BM, int BN, int WGM, int WGN>
+void launch_cfg(hipStream_t st, const GemmArgs& a, const u16* Wt, int ldwt) {
+  dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.ksplit > 1 ? a.ksplit : 1);
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN>), grid, dim3(NT), 0, st, a, Wt, ldwt);
+}
+
+}  // namespace
+
+// a.B / a.ldb are ignored: the weight comes as Wt [N][ldwt] bf16 (K-contiguous).
+int launch_gemm_bf16(hipStream_t st, const GemmArgs& a, const uint16_t* Wt, int ldwt) {
+  if (a.M <= 0 || a.N <= 0) return 0;
+  if (a.K % BK != 0 || ldwt % 8 != 0 || a.conv1_tstride > 0) return -1;
+  if (a.ksplit > 1 && (a.bias || a.residual || a.aux || a.act != ACT_NONE || a.col_scale_period > 0)) return -1;
+  auto blocks = [&](int bm, int bn) { return (int64_t)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
+  if (a.M <= 32) launch_cfg<32, 128, 1, 4>(st, a, Wt, ldwt);
+  else if (a.ksplit > 1 || blocks(128, 128) < 384) launch_cfg<64, 64, 2, 2>(st, a, Wt, ldwt);
+  else launch_cfg<128, 128, 2, 2>(st, a, Wt, ldwt);
+  return 0;
+}
+
+}  // namespace wb

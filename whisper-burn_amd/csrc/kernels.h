@@ -61,6 +61,8 @@ struct GemmArgs {
   int ksplit = 1; int64_t c_split_stride = 0;    // split-K: raw partials of K-slice z go to C + z * c_split_stride
 };
 int launch_gemm_f32(hipStream_t st, const GemmArgs& a);   // exact-f32 MFMA (v_mfma_f32_32x32x2_f32)
+// speed path (gemm_bf16.hip): same contract, weight given as Wt [N][ldwt] bf16 (K-contiguous); a.B ignored
+int launch_gemm_bf16(hipStream_t st, const GemmArgs& a, const uint16_t* Wt, int ldwt);
 
 // ---- elementwise / normalisation (ops.hip) ----------------------------------------
 // y[m] = LN(x[m]) * g + b, biased variance; eps placement per variant (see whisper_hip.h)

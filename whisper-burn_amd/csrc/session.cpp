@@ -88,7 +88,7 @@ static int session_finish_encode(wb_session* s, const MelBatch& mb) {
     g.A = s->enc_out.as<float>(); g.lda = d; g.B = m->ckv_all.w; g.ldb = ldkv; g.C = s->ckv.as<float>(); g.ldc = ldkv;
     g.bias = m->ckv_all.b; g.M = rows; g.N = ldkv; g.K = d;
     g.col_scale = m->qk_scale; g.col_scale_period = 2 * d; g.col_scale_width = d;   // K * s (mod.rs:510-514)
-    WB_REQUIRE(launch_gemm_f32(s->st, g) == 0, WB_ERR_SHAPE, "cross-KV gemm: unsupported shape");
+    WB_TRY(gemm_dispatch(m, s->st, g, m->ckv_all.wt, m->ckv_all.k));
     tm.stop();
     if (tm.on) { WB_HIP(hipStreamSynchronize(s->st)); tm.collect(); }
   }
@@ -310,6 +310,7 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
   auto gemv = [&](const LinearW& w, int ks, int ksl, int pro, const float* src, int ld_src, float* P) {
     GemvArgs a;
     a.W = w.w; a.ldw = w.n; a.K = w.k; a.N = w.n; a.KS = ks; a.KSL = ksl; a.pro = pro; a.src = src; a.ld_src = ld_src;
+    a.Wb = m->compute_dtype == WB_BF16 ? w.wkn : nullptr;
     a.P = P; a.st = dst; a.S = S;
     return a;
   };
@@ -342,8 +343,7 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
       GemmArgs g;
       g.A = A; g.lda = w.k; g.B = w.w; g.ldb = w.n; g.C = P; g.ldc = w.n; g.M = n; g.N = w.n; g.K = w.k;
       g.ksplit = ks; g.c_split_stride = (int64_t)S * w.n;
-      WB_REQUIRE(launch_gemm_f32(st, g) == 0, WB_ERR_SHAPE, "decode gemm: unsupported shape");
-      return WB_OK;
+      return gemm_dispatch(m, st, g, w.wt, w.k);
     };
     const float* pend = nullptr; int ks_pend = 0; const float* pbias = nullptr;
     for (int l = 0; l < NL; l++) {
@@ -377,7 +377,7 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
       GemmArgs g;
       g.A = h; g.lda = d; g.B = m->tok_emb_t; g.ldb = m->vocab_ld; g.C = s->logits.as<float>(); g.ldc = V;
       g.M = n; g.N = V; g.K = d;
-      WB_REQUIRE(launch_gemm_f32(st, g) == 0, WB_ERR_SHAPE, "logits gemm: unsupported shape");
+      WB_TRY(gemm_dispatch(m, st, g, m->tok_emb_bf, d));
       tm_logits.stop();
       launch_dec_topk_rows(st, dst, n, s->logits.as<float>(), V, s->mask.as<float>(), use_mask, k, out_id_dev,
                            out_lp_dev, s->row_stats.as<float>(), L, gctl, s->gtok.as<int>(), s->Lmax, eot);
@@ -420,6 +420,7 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
     ScopedTimer tm_logits(st, 6);
     GemvArgs a;
     a.W = m->tok_emb_t; a.ldw = m->vocab_ld; a.K = d; a.N = V; a.KS = 1; a.KSL = d;
+    a.Wb = m->compute_dtype == WB_BF16 ? m->tok_emb_t_bf : nullptr;
     a.P = s->logits.as<float>(); a.st = dst; a.S = S;
     a.mask = s->mask.as<float>(); a.use_mask = use_mask; a.topk = k; a.tstats = s->tstats.as<float>(); a.ct = s->ct_v;
     ln_gemv(a, s->P2.as<float>(), s->ks_2, m->dec[NL - 1].mlp2.b, m->ln_dec, true);

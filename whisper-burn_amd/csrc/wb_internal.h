@@ -79,7 +79,11 @@ int build_model(TensorMap& tm, int device, int compute_dtype, wb_model** out);
 
 // ---- model ----------------------------------------------------------------------
 struct LayerNormW { float* g = nullptr; float* b = nullptr; float eps = 1e-5f; };
-struct LinearW { float* w = nullptr; float* b = nullptr; int k = 0, n = 0; };  // w: [k][n] row-major
+struct LinearW {
+  float* w = nullptr; float* b = nullptr; int k = 0, n = 0;   // w: [k][n] row-major f32
+  uint16_t* wt = nullptr;    // speed path: bf16 [n][k] (K-contiguous, MFMA GEMM operand)
+  uint16_t* wkn = nullptr;   // speed path: bf16 [k][n] (decode GEMV streams N contiguously); decoder weights only
+};
 
 struct EncBlockW {
   LayerNormW ln1, ln2;
@@ -109,6 +113,9 @@ struct wb_model {
   int ln_eps_inside_sqrt = 0;
   // all weights live in one arena allocation
   wb::DevMem arena;
+  wb::DevMem arena_bf16;      // WB_BF16: bf16 copies of the GEMM weights
+  uint16_t* tok_emb_bf = nullptr;     // E   [V][d] bf16 (already K-contiguous for logits = x E^T)
+  uint16_t* tok_emb_t_bf = nullptr;   // E^T [d][vocab_ld] bf16
   // encoder
   wb::LinearW conv1;   // repacked [240 = ci*3+kk][d]
   wb::LinearW conv2;   // repacked [3d = kk*d+ci][d]
