@@ -4,6 +4,7 @@
 #include <mutex>
 
 #include "engine.h"
+#include "session.h"
 
 namespace wb {
 
@@ -89,6 +90,7 @@ int wb_model_set_ln_variant(wb_model* m, int eps_inside_sqrt) {
 void wb_model_free(wb_model* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
+  session_pool_purge(m);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
 }

@@ -36,6 +36,17 @@ ScopedTimer::~ScopedTimer() {
 static std::mutex g_pool_mu;
 static std::unordered_map<wb_model*, std::vector<wb_session*>> g_pool;
 
+// wb_model_free: pooled sessions of that model die with it
+void session_pool_purge(wb_model* m) {
+  std::vector<wb_session*> dead;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = g_pool.find(m);
+    if (it != g_pool.end()) { dead.swap(it->second); g_pool.erase(it); }
+  }
+  for (wb_session* s : dead) delete s;
+}
+
 int session_create(wb_model* m, int n_windows, int max_beams, int padding, wb_session** out) {
   WB_REQUIRE(m && out, WB_ERR_ARG, "session: null argument");
   WB_REQUIRE(n_windows >= 1, WB_ERR_ARG, "session: n_windows must be >= 1");

@@ -52,6 +52,7 @@ struct ScopedTimer {
   ~ScopedTimer();
 };
 
+void session_pool_purge(wb_model* m);
 int session_create(wb_model* m, int n_windows, int max_beams, int padding, wb_session** out);
 int session_encode_pcm(wb_session* s, const float* pcm, int64_t n_pcm, const int64_t* starts, const int64_t* lens,
                        bool pcm_on_device);
