@@ -14,7 +14,6 @@ struct MelTables {            // device-resident constants, built once per (devi
   int tap_start[80];          // sparse Slaney filterbank rows (audio.rs:67-143)
   int tap_len[80];
   float tap_w[80 * MEL_MAX_TAPS];
-  float tap_wt[MEL_MAX_TAPS * 80];   // the same weights tap-major (coalesced per-lane loads in the kernel)
 };
 // Host-side construction (f32 op order of the reference); returns 0 / -1 if a row has > MAX_TAPS taps.
 int mel_tables_build(double sample_rate, MelTables* host_out);

@@ -2,17 +2,25 @@
 //
 // Replaces /root/reference/src/audio.rs:34-56 (prep_audio) + :284-367 (stfft: dense DFT by
 // two [201x400]x[400xT] f32 matmuls, ~60 tiny launches and 3 blocking D2H reads per window)
-// with one launch per batch of windows plus a tiny finalize pass:
-//   reflect-padded frame loads (no materialised padded copy, audio.rs:297-306)
-//   -> Hann (audio.rs:272-278) -> 400-point DFT as an LDS-staged 20x20 Cooley-Tukey FFT,
-//   two real frames packed into one complex transform -> |X|^2 for bins 0..200
-//   -> sparse Slaney filterbank (<= 14 taps per row, audio.rs:67-143)
-//   -> relu(x-1e-10)+1e-10, ln(x)/ln10 (helper.rs:8-10, :24-27) -> per-window max (audio.rs:50).
+// with one launch per batch of windows plus a small finalize pass:
+//   stage 0  the block's contiguous PCM span (5360 samples) is read once, coalesced, with reflect
+//            indexing at the window edges (audio.rs:297-306; no materialised padded copy), and each
+//            sample is scattered to the <= 3 frame rows that contain it
+//   stage 1  Hann (audio.rs:272-278, per-lane registers) + 20-point DFTs over n1   } 400-point DFT as an
+//   stage 2  twiddles W400^{n2 k1}, transpose through LDS, 20-point DFTs over n2   } LDS-staged 20x20
+//            Cooley-Tukey FFT, two real frames packed into one complex transform
+//   stage 3  unpack the two spectra, |X|^2 for bins 0..200
+//   stage 4  sparse Slaney filterbank (<= 14 taps per row, audio.rs:67-143; lane = frame, half-wave = 8
+//            mel rows so the taps are broadcast loads), relu(x-1e-10)+1e-10, ln(x)/ln10
+//            (helper.rs:8-10, :24-27), block maximum (no atomics)
+//   stage 5  coalesced store of the [80][32] tile
+// finalize: window max over the block maxima (audio.rs:50), max(x, max-8), (x+4)/4, zero padding frames.
 // Bound: HBM (640 B PCM in + 320 B mel out per frame); ~11 kFLOP per frame of f32 VALU.
 //
-// Geometry: block = 320 threads = 16 pairs x 20 lanes; a pair transforms frames (2p, 2p+1)
-// of the block's 32 consecutive frames.  Lane q of a pair runs one 20-point complex DFT per
-// stage in registers (stage 1: over n1 for n2 = q; stage 2: over n2 for k1 = q).
+// Geometry: block = 320 threads = 16 pairs x 20 lanes; a pair transforms frames (2p, 2p+1) of the
+// block's 32 consecutive frames; lane q of a pair runs one 20-point complex DFT per stage in
+// registers.  Every stage aliases the same 16 x 852-float pair-private LDS regions (54.5 KB: three
+// blocks per CU); row strides are chosen from the bank maps (2 x 426 = 852 = 20 mod 32 -> bank = tid).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -377,10 +385,7 @@ int mel_tables_build(double sample_rate, MelTables* t) {
     if (len > MEL_MAX_TAPS) return -1;
     t->tap_start[i] = s;
     t->tap_len[i] = len;
-    for (int k = 0; k < len; k++) {
-      t->tap_w[i * MEL_MAX_TAPS + k] = W[i][s + k];
-      t->tap_wt[k * MEL_N_MELS + i] = W[i][s + k];   // tap-major copy: lanes of a pair read consecutive rows
-    }
+    for (int k = 0; k < len; k++) t->tap_w[i * MEL_MAX_TAPS + k] = W[i][s + k];
   }
   return 0;
 }
