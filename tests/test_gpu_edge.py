@@ -1,0 +1,141 @@
+"""GPU: the edge cases of the decode driver that the ordinary fixtures never reach.
+
+  * beams / greedy rows that FINISH on end-of-text at different depths (transcribe.rs:312-318,
+    beam.rs:22-31): finished beams leave the live set, the step batch shrinks, parent slots are
+    remapped, the device-chained greedy loop raises per-window done flags;
+  * sequences longer than one self-attention tile (> 112 cached positions) and the paged cache tables;
+  * the context limit (mod.rs:134-139 panics -> WB_ERR_SHAPE), empty / minimal audio.
+
+Everything is compared token-for-token with the oracle on the same seeded inputs.
+"""
+import numpy as np
+import pytest
+
+import whisper_burn_amd as wb
+from oracle import transcribe as otr
+from oracle.model import OracleWhisper
+from whisper_burn_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _special(st: wb.SpecialTokens) -> otr.SpecialTokens:
+    return otr.SpecialTokens(st.start_of_transcript, st.language, st.transcribe, st.no_timestamps,
+                             st.end_of_text, st.is_special.astype(bool))
+
+
+def eot_prone_weights(alpha: float = 3.7, seed: int = 4242, n_vocab: int = 1031, **dims_kw):
+    """Micro weights whose final LayerNorm bias leans towards the end-of-text embedding: once the special
+    mask lifts (len > 5) end-of-text wins in SOME contexts, so windows finish at different depths."""
+    dims = synth.micro_dims(n_state=128, n_head=2, n_layer=2, n_vocab=n_vocab, **dims_kw)
+    w = synth.synth_weights(dims, seed=seed)
+    st = wb.SpecialTokens.for_vocab(n_vocab)
+    e = w["decoder/token_embedding/weight"][st.end_of_text]
+    w["decoder/ln/bias"] = w["decoder/ln/bias"] + (alpha * e / np.linalg.norm(e)).astype(np.float32)
+    return w, st
+
+
+@pytest.fixture(scope="module")
+def eot_micro():
+    w, st = eot_prone_weights()
+    return OracleWhisper(w), wb.Whisper.from_tensors(w), st
+
+
+@pytest.fixture(scope="module")
+def eot_micro_strong():
+    w, st = eot_prone_weights(alpha=4.2)                         # about half of the windows finish early
+    return OracleWhisper(w), wb.Whisper.from_tensors(w), st
+
+
+@pytest.fixture(scope="module")
+def micro():
+    dims = synth.micro_dims(n_state=128, n_head=2, n_layer=2, n_vocab=1031)
+    w = synth.synth_weights(dims, seed=4242)
+    return OracleWhisper(w), wb.Whisper.from_tensors(w), wb.SpecialTokens.for_vocab(1031)
+
+
+@pytest.mark.parametrize("beam_size", [1, 3, 5])
+def test_windows_finish_on_end_of_text_at_different_depths(eot_micro, beam_size):
+    oracle, eng, st = eot_micro
+    audio = synth.synth_audio(16000 * 60, 1236)                  # 60 s -> 6 reference windows
+    depth = 24
+    ref, ref_win = otr.waveform_to_tokens(oracle, _special(st), audio, 16000, beam_size, depth, return_windows=True)
+    ended = [w[-1] == st.end_of_text for w in ref_win]
+    assert any(ended) and not all(ended), "fixture no longer mixes finished and unfinished windows"
+    got, got_win = wb.waveform_to_tokens(eng, st, audio, 16000, beam_size, depth)
+    assert got_win == ref_win
+    assert got == ref
+
+
+@pytest.mark.parametrize("beam_size", [1, 3])
+def test_batch_mode_with_finishing_windows(eot_micro_strong, beam_size):
+    """> 8 live rows (batch-mode kernels) while rows drop out on end-of-text."""
+    oracle, eng, st = eot_micro_strong
+    audio = synth.synth_audio(16000 * 150, 777)                  # 13 windows
+    depth = 16
+    ref, ref_win = otr.waveform_to_tokens(oracle, _special(st), audio, 16000, beam_size, depth, return_windows=True)
+    ended = [w[-1] == st.end_of_text for w in ref_win]
+    assert sum(ended) >= 4 and not all(ended)
+    got, got_win = wb.waveform_to_tokens(eng, st, audio, 16000, beam_size, depth)
+    assert got_win == ref_win
+    assert got == ref
+
+
+def test_finishing_windows_are_batch_composition_invariant(eot_micro_strong):
+    _, eng, st = eot_micro_strong
+    audio = synth.synth_audio(16000 * 150, 777)
+    _, wins = wb.waveform_to_tokens(eng, st, audio, 16000, 3, 16)
+    p = wb.decode_params(st, beam_size=3, max_depth=16, max_batch_windows=2)
+    _, wins2 = wb.waveform_to_tokens(eng, st, audio, 16000, params=p)
+    assert wins2 == wins
+
+
+@pytest.mark.parametrize("beam_size,depth", [(1, 150), (3, 124)])
+def test_long_sequences_cross_the_self_attention_tile(micro, beam_size, depth):
+    """More than 112 cached positions: the second self-attention key tile and the position tables."""
+    oracle, eng, st = micro
+    audio = synth.synth_audio(16000 * 3, 31)
+    ref = otr.waveform_to_tokens(oracle, _special(st), audio, 16000, beam_size, depth)
+    got, _ = wb.waveform_to_tokens(eng, st, audio, 16000, beam_size, depth)
+    assert len(ref) == 4 + depth
+    assert got == ref
+
+
+@pytest.mark.parametrize("beam_size", [1, 2])
+def test_context_limit_is_an_error_not_a_truncation(beam_size):
+    """mod.rs:134-139: the decoder panics when the token sequence outgrows n_text_ctx."""
+    dims = synth.micro_dims(n_state=128, n_head=2, n_layer=2, n_vocab=1031, n_text_ctx=16)
+    w = synth.synth_weights(dims, seed=7)
+    eng, st = wb.Whisper.from_tensors(w), wb.SpecialTokens.for_vocab(1031)
+    audio = synth.synth_audio(16000 * 2, 32)
+    # depth 13: the decoder sees prefixes of 4 .. 16 tokens (the 17th token is produced, never fed back)
+    oracle = OracleWhisper(w)
+    ref = otr.waveform_to_tokens(oracle, _special(st), audio, 16000, beam_size, 13)
+    got, _ = wb.waveform_to_tokens(eng, st, audio, 16000, beam_size, 13)
+    assert got == ref and len(got) == 17
+    with pytest.raises(AssertionError):
+        otr.waveform_to_tokens(oracle, _special(st), audio, 16000, beam_size, 14)
+    with pytest.raises(wb.WbError) as e:
+        wb.waveform_to_tokens(eng, st, audio, 16000, beam_size, 14)
+    assert e.value.status == -2
+    eng.close()
+
+
+def test_minimal_and_empty_audio(micro):
+    oracle, eng, st = micro
+    audio = synth.synth_audio(400, 33)                           # exactly n_fft samples -> 1 STFT frame + padding
+    ref = otr.waveform_to_tokens(oracle, _special(st), audio, 16000, 1, 6)
+    got, wins = wb.waveform_to_tokens(eng, st, audio, 16000, 1, 6)
+    assert len(wins) == 1 and got == ref
+    for n in (0, 399):                                           # audio.rs:292 panics below n_fft samples
+        with pytest.raises(wb.WbError) as e:
+            wb.waveform_to_tokens(eng, st, np.zeros(n, np.float32), 16000, 1, 6)
+        assert e.value.status == -2, n
+
+
+def test_max_depth_zero_returns_the_prompt(micro):
+    _, eng, st = micro
+    audio = synth.synth_audio(16000 * 2, 34)
+    for beam in (1, 3):
+        got, wins = wb.waveform_to_tokens(eng, st, audio, 16000, beam, 0)
+        assert got == [st.start_of_transcript, st.language, st.transcribe, st.no_timestamps]

@@ -504,7 +504,9 @@ int session_greedy_chain(wb_session* s, int first_token, int eot, int max_depth,
   hipStream_t st = s->st;
   const size_t ctl_ints = GC_HDR + 3 * (size_t)S;
   WB_TRY(s->gctl.ensure(ctl_ints * 4));
-  WB_TRY(s->gtok.ensure((size_t)S * s->Lmax * 4));
+  // token rows [S][Lmax]; the last generated token of a row that fills the context lands at index Lmax
+  // (= slot 0 of the next row, a prompt position nobody reads), so the buffer carries one extra slot
+  WB_TRY(s->gtok.ensure(((size_t)S * s->Lmax + 1) * 4));
   std::vector<int> ctl(ctl_ints, 0);
   ctl[GC_STEP] = s->step;
   for (int i = 0; i < W; i++) ctl[GC_HDR + i] = first_token;
@@ -531,7 +533,7 @@ int session_greedy_chain(wb_session* s, int first_token, int eot, int max_depth,
     if (all_done) break;
   }
   tm.stop();
-  std::vector<int> toks((size_t)S * s->Lmax);
+  std::vector<int> toks((size_t)S * s->Lmax + 1);
   WB_HIP(hipMemcpyAsync(toks.data(), s->gtok.p, toks.size() * 4, hipMemcpyDeviceToHost, st));
   WB_HIP(hipStreamSynchronize(st));
   tm.collect();
