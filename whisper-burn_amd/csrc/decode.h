@@ -12,8 +12,10 @@ namespace wb {
 constexpr int MAX_BEAMS = 8;     // live beams per window (reference: beam_size 5, transcribe.rs:232)
 constexpr int TOPK_MAX = 8;
 constexpr int CA_STRIDE = 66;    // cross-attention chunk partial: m, l, o[64]
+constexpr int CA_NCH_MAX = 12;   // most key chunks a (row, head) is split into: ceil(1500 / 128)
 constexpr int TS_STRIDE = 2 + 2 * TOPK_MAX;   // logits tile partial: max, sum-exp, k x (value, id)
 constexpr int GV_CT = 128;       // columns per GEMV block tile
+constexpr int GV_CT_LOGITS = 128; // logits tile (64 = twice the blocks measured slower: 17.7 vs 16.3 us, merge 6.3 vs 4.4 us)
 constexpr int KS_MAX = 16;       // most K-split partials any consumer folds
 
 // Per-step state block (ints): header, per-slot arrays, per-window lists.  The host writes it into
@@ -71,9 +73,17 @@ void launch_dec_self_attn(hipStream_t st, const int* state, const StepLayout& la
 void launch_dec_cross_attn(hipStream_t st, const int* state, const StepLayout& lay, int n_windows, int n_head,
                            int n_chunks, const float* Pq, int KS, const float* bq, int d, const float* ckv, int ldkv,
                            int koff, const int* win_row0, const int* win_C, float scale, float* ca, int max_nb);
-void launch_dec_topk_merge(hipStream_t st, const int* state, int n_max, const float* tstats, int n_tiles, int k,
+// what the merge kernel needs to prepare the NEXT chained step (x == nullptr: it does not)
+struct NextPrep {
+  float* x = nullptr;        // residual-stream rows [S][d] the next step starts from
+  const float* E = nullptr;  // token embedding [V][d]
+  const float* pos = nullptr;   // decoder positional embedding [n_text_ctx][d]
+  int* tabs = nullptr;       // position tables, double-buffered by step parity
+  int d = 0;
+};
+void launch_dec_topk_merge(hipStream_t st, int* state, int n_max, const float* tstats, int n_tiles, int k,
                            int32_t* out_id, float* out_lp, float* row_stats, const StepLayout& lay, int* gctl, int* gtok,
-                           int Lmax, int eot);
+                           int Lmax, int eot, const NextPrep& nx);
 void launch_dec_gelu_fold(hipStream_t st, const int* state, int n_max, const float* P, int KS, int S, int K,
                           const float* bias, float* out);
 void launch_dec_attn_combine(hipStream_t st, const int* state, int n_max, const float* ca, int n_head, int n_chunks,

@@ -34,13 +34,36 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // bias[c] + sum_s P[s][row][c] with the loads issued together (fixed summation order)
 __device__ __forceinline__ float fold_partials(const float* __restrict__ P, int KS, int64_t plane, int64_t off,
                                                float init) {
-  float v[KS_MAX];
+  float v[KS_MAX];     // (uniform predicate: scalar branches, the loads stay in flight together)
 #pragma unroll
   for (int s = 0; s < KS_MAX; s++) v[s] = (s < KS) ? P[(int64_t)s * plane + off] : 0.f;
   float acc = init;
 #pragma unroll
   for (int s = 0; s < KS_MAX; s++) acc += v[s];
   return acc;
+}
+
+// flash-decoding combine of the cross-attention key-chunk partials {m, l, o[64]} of one (row, head):
+// every load is issued before the first use (n_chunks is uniform: scalar branches around the loads)
+__device__ __forceinline__ float combine_chunks(const float* __restrict__ ca, int n_chunks, int dh) {
+  float m[CA_NCH_MAX], l[CA_NCH_MAX], o[CA_NCH_MAX];
+#pragma unroll
+  for (int c = 0; c < CA_NCH_MAX; c++) {
+    const float* p = ca + c * CA_STRIDE;
+    m[c] = -1.0e30f; l[c] = 0.f; o[c] = 0.f;
+    if (c < n_chunks) { m[c] = p[0]; l[c] = p[1]; o[c] = p[2 + dh]; }
+  }
+  float M = -1.0e30f;
+#pragma unroll
+  for (int c = 0; c < CA_NCH_MAX; c++) M = fmaxf(M, m[c]);
+  float num = 0.f, den = 0.f;
+#pragma unroll
+  for (int c = 0; c < CA_NCH_MAX; c++) {
+    const float wgt = c < n_chunks ? expf(m[c] - M) : 0.f;
+    num += wgt * o[c];
+    den += wgt * l[c];
+  }
+  return num / den;
 }
 
 // ---- step prepare: state host->device, position tables, token/position embedding (mod.rs:141-146) ----
@@ -138,94 +161,104 @@ __global__ __launch_bounds__(256) void dec_resolve_ln_kernel(const int* __restri
 }
 
 // ---- skinny GEMM: P[ks][r][n] = sum_{k in slice ks} in[r][k] * W[k][n],  r < n_rows <= S -------
-// block = 4 waves, column tile 128 (32 lanes x float4), each half-wave owns 4 consecutive k per
-// 32-deep step, two steps (8 x 16 B per lane) in flight; input rows staged in LDS with the
-// prologue applied.  LN prologue: one wave per row folds x + pending partials, takes the
-// LayerNorm statistics with shuffles only, and stages the block's K-slice.
-template <int MR, int XLD, int DPL, bool LN, bool STATS, bool WBF>
-__global__ __launch_bounds__(256) void dec_gemv_kernel(GemvArgs a) {
+// block = 4 waves, column tile CT = 128 or 64 (LPR = CT / 4 lanes x float4 per weight row); a wave holds
+// G = 64 / LPR lane groups, each owning 4 consecutive k per KH-deep step (KH = 16 G), two steps
+// (8 x 16 B per lane) per round; input rows staged in LDS with the prologue applied.  LN prologue: one
+// wave per row folds x + pending partials, takes the LayerNorm statistics with shuffles only, and stages
+// the block's K-slice.  CT = 64 (logits) doubles the blocks per CU so that one block's prologue and
+// statistics epilogue overlap another block's weight stream.
+template <int MR, int XLD, int DPL, bool LN, bool STATS, bool WBF, int CT>
+__global__ __launch_bounds__(256, (MR >= 8 && DPL >= 16) ? 1 : 2) void dec_gemv_kernel(GemvArgs a) {
+  constexpr int LPR = CT / 4, G = 64 / LPR, KH = 16 * G;
   __shared__ __attribute__((aligned(16))) float xbuf[MR * XLD];   // input rows; later the cross-wave reduction buffer
-  __shared__ float tilev[STATS ? MR : 1][GV_CT];
-  static_assert(MR * XLD >= 4 * MR * GV_CT, "reduction buffer must fit");
+  __shared__ float tilev[STATS ? MR : 1][CT];
+  static_assert(MR * XLD >= 4 * MR * CT, "reduction buffer must fit");
+  static_assert(CT == 128 || CT == 64, "column tile");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int half = lane >> 5, c4 = (lane & 31) * 4;
-  const int ct = a.ct > 0 ? a.ct : GV_CT;          // columns per block (<= 128): chosen for an even split over the CUs
+  const int half = lane / LPR, c4 = (lane % LPR) * 4;     // `half` = lane group inside the wave (0 .. G-1)
+  const int ct = a.ct > 0 ? a.ct : CT;             // columns per block (<= CT)
   const int n0 = blockIdx.x * ct, ks = blockIdx.y;
   const int k0 = ks * a.KSL;
-  const int kn = min(a.KSL, a.K - k0);          // rows of this slice (multiple of 32)
+  const int kn = min(a.KSL, a.K - k0);          // rows of this slice (a multiple of KH)
   const int n_rows = a.st[ST_N];
-  const int unit = wave * 2 + half;
+  const int unit = wave * G + half;
   const bool col_ok = (n0 + c4) < a.ldw && c4 < ct;
-  const float* Wp = a.W + (int64_t)k0 * a.ldw + n0 + c4;
   const int64_t ldw = a.ldw;
+  // weight addressing: wave-uniform base (scalar registers) + one 32-bit per-lane offset, so a round's 8
+  // loads share their address registers.  Lanes past the tile edge re-read the tile's first column
+  // (always in range); their sums are discarded by the epilogue.
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const uint32_t voff = (uint32_t)(half * 4 * a.ldw + (col_ok ? c4 : 0));
+  const int64_t wbase = (int64_t)(k0 + wave_u * G * 4) * ldw + n0;
 
-  float4 w[8];
-  const uint16_t* Wpb = a.Wb + (int64_t)k0 * a.ldw + n0 + c4;   // speed path: the same [K][ldw] matrix in bf16
-  auto load_pair = [&](int kb) {
+  // weight tiles: NBUF register sets of 8 x 16 B per lane, software-pipelined -- set b is refilled for
+  // round it + NBUF as soon as round it has consumed it, so (NBUF - 1) .. NBUF x 32 KB per block stay in flight
+  constexpr int NBUF = STATS ? 3 : 2;
+  float4 w[NBUF][8];
+  auto load_round = [&](float4 (&wr)[8], int it) {   // rows k0 + unit * 4 + 2 KH it + {0..3, KH..KH+3}
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      const int k = kb + (j >> 2) * 32 + (j & 3);
-      if constexpr (WBF) {
-        uint2 u = make_uint2(0u, 0u);
-        if (col_ok && k < kn) u = *reinterpret_cast<const uint2*>(Wpb + k * ldw);
-        w[j] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
-                           __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
-      } else {
-        w[j] = (col_ok && k < kn) ? *reinterpret_cast<const float4*>(Wp + k * ldw) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int ku = 2 * KH * it + (j >> 2) * KH;      // block-uniform; kn is a multiple of KH
+      if (ku < kn) {
+        const int64_t off = wbase + (int64_t)(ku + (j & 3)) * ldw;
+        if constexpr (WBF) {                           // speed path: the same [K][ldw] matrix in bf16
+          const uint2 u = *reinterpret_cast<const uint2*>(a.Wb + off + voff);
+          wr[j] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                              __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+        } else {
+          wr[j] = *reinterpret_cast<const float4*>(a.W + off + voff);
+        }
       }
     }
   };
-  load_pair(unit * 4);   // first weight tiles in flight before the prologue touches memory
+  const int nit = (kn + 2 * KH - 1) / (2 * KH);   // rounds of 2 KH rows
+  load_round(w[0], 0);   // first weight tiles in flight before the prologue touches memory
 
-  for (int r0 = 0; r0 < n_rows; r0 += MR) {
-    // ---- prologue: stage in[r0..r0+MR)[k0..k0+kn) ----
+  {
+    constexpr int r0 = 0;     // the host picks MR >= the live row count: one pass over the rows
+    // ---- prologue: stage in[0..MR)[k0..k0+kn) ----
     if constexpr (LN) {
-      const int d = a.K;
+      const int d = a.K;      // a multiple of 64 (session_reserve): lane + 64 i < d is wave-uniform
       const bool writer = (blockIdx.x == 0 && blockIdx.y == 0);
+#pragma unroll 1
       for (int r = wave; r < MR; r += 4) {
-        const int row = r0 + r;
-        if (row >= n_rows) {   // padding row of the chunk (wave-uniform)
+        const int row = r;
+        if (row >= n_rows) {   // padding row (wave-uniform)
           for (int c = lane; c < kn; c += 64) xbuf[r * XLD + c] = 0.f;
           continue;
         }
-        // LayerNorm scale/shift of this block's K-slice: in flight together with the row itself
-        float gv[DPL], bv[DPL];
+        // every load below is unconditional (columns past d alias column `lane`, planes past KSp alias the
+        // last plane; both are masked after the load), so the whole prologue is one batch of loads in flight
+        int co[DPL];
 #pragma unroll
-        for (int i = 0; i < DPL; i++) {
-          const int c = lane + 64 * i;
-          const bool in = c >= k0 && c < k0 + kn;
-          gv[i] = in ? a.ln_g[c] : 0.f;
-          bv[i] = in ? a.ln_b[c] : 0.f;
-        }
-        float v[DPL];
+        for (int i = 0; i < DPL; i++) co[i] = lane + (64 * i < d ? 64 * i : 0);
+        float gv[DPL], bv[DPL], v[DPL];
         const float* xr = a.src + (int64_t)row * d;
 #pragma unroll
-        for (int i = 0; i < DPL; i++) {
-          const int c = lane + 64 * i;
-          v[i] = c < d ? xr[c] : 0.f;
-        }
+        for (int i = 0; i < DPL; i++) { gv[i] = a.ln_g[co[i]]; bv[i] = a.ln_b[co[i]]; v[i] = xr[co[i]]; }
         if (a.KSp > 0) {       // x + (attn/mlp output) = x + bias + sum_s partial_s, s ascending  (mod.rs:346-348)
           float acc[DPL];
 #pragma unroll
-          for (int i = 0; i < DPL; i++) { const int c = lane + 64 * i; acc[i] = c < d ? a.pbias[c] : 0.f; }
+          for (int i = 0; i < DPL; i++) acc[i] = a.pbias[co[i]];
           const float* pp = a.pend + (int64_t)row * d;
           const int64_t plane = (int64_t)a.S * d;
           // all loads of a chunk of partial planes are issued before the first add (memory-level
           // parallelism is what bounds this prologue); the summation order stays s ascending
-          constexpr int CH = 8;
+          constexpr int CH = DPL <= 6 ? 8 : DPL <= 8 ? 4 : 2;   // <= 48 registers of partials in flight
           for (int sp = 0; sp < a.KSp; sp += CH) {
             float t[CH][DPL];
 #pragma unroll
-            for (int j = 0; j < CH; j++)
+            for (int j = 0; j < CH; j++) {
+              const float* pj = pp + (int64_t)min(sp + j, a.KSp - 1) * plane;
 #pragma unroll
-              for (int i = 0; i < DPL; i++) {
-                const int c = lane + 64 * i;
-                t[j][i] = (sp + j < a.KSp && c < d) ? pp[(int64_t)(sp + j) * plane + c] : 0.f;
-              }
+              for (int i = 0; i < DPL; i++) t[j][i] = pj[co[i]];
+            }
 #pragma unroll
-            for (int j = 0; j < CH; j++)
+            for (int j = 0; j < CH; j++) {
+              const bool live = sp + j < a.KSp;
 #pragma unroll
-              for (int i = 0; i < DPL; i++) acc[i] += t[j][i];
+              for (int i = 0; i < DPL; i++) acc[i] += live ? t[j][i] : 0.f;
+            }
           }
 #pragma unroll
           for (int i = 0; i < DPL; i++) v[i] = v[i] + acc[i];
@@ -233,15 +266,13 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(GemvArgs a) {
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < DPL; i++) {
-          const int c = lane + 64 * i;
-          if (c < d) { s += v[i]; if (writer) a.x_out[(int64_t)row * d + c] = v[i]; }
+          if (64 * i < d) { s += v[i]; if (writer) a.x_out[(int64_t)row * d + co[i]] = v[i]; }
         }
         const float mean = wave_sum(s) / (float)d;          // Burn nn::LayerNorm: biased variance, two passes
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < DPL; i++) {
-          const int c = lane + 64 * i;
-          if (c < d) { const float t = v[i] - mean; q += t * t; }
+          if (64 * i < d) { const float t = v[i] - mean; q += t * t; }
         }
         const float var = wave_sum(q) / (float)d;
         const float denom = a.ln_inside ? sqrtf(var + a.ln_eps) : (sqrtf(var) + a.ln_eps);
@@ -263,62 +294,68 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(GemvArgs a) {
             v = gelu_erf(fold_partials(a.src, a.KSp, (int64_t)a.S * a.ld_src, (int64_t)row * a.ld_src + k, a.pbias[k]));
           } else {                                  // PRO_ATTN: combine the key-chunk partials of cross-attention
             const int hh = k >> 6, dh = k & 63;
-            const float* ca = a.src + ((int64_t)(row * a.n_head + hh) * a.n_chunks) * CA_STRIDE;
-            float M = -1.0e30f;
-            for (int c = 0; c < a.n_chunks; c++) M = fmaxf(M, ca[c * CA_STRIDE]);
-            float num = 0.f, den = 0.f;
-            for (int c = 0; c < a.n_chunks; c++) {
-              const float wgt = expf(ca[c * CA_STRIDE] - M);
-              num += wgt * ca[c * CA_STRIDE + 2 + dh];
-              den += wgt * ca[c * CA_STRIDE + 1];
-            }
-            v = num / den;
+            v = combine_chunks(a.src + ((int64_t)(row * a.n_head + hh) * a.n_chunks) * CA_STRIDE, a.n_chunks, dh);
           }
         }
         xbuf[r * XLD + kk] = v;
       }
     }
+    // the remaining register sets fill while the staged rows settle (they are dead during the prologue,
+    // so the prologue's registers are reused)
+#pragma unroll
+    for (int b = 1; b < NBUF; b++)
+      if (b < nit) load_round(w[b], b);
     __syncthreads();
     // ---- main loop ----
     float acc[MR][4];
 #pragma unroll
     for (int r = 0; r < MR; r++) { acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.f; }
-    for (int kb = unit * 4; kb < kn; kb += 64) {
-      if (kb != unit * 4 || r0 != 0) load_pair(kb);   // (the first pair of the first row chunk was prefetched)
+#pragma unroll 1
+    for (int it = 0; it < nit; it += NBUF) {
 #pragma unroll
-      for (int hstep = 0; hstep < 2; hstep++) {
-        if (kb + hstep * 32 < kn) {
+      for (int b = 0; b < NBUF; b++) {
+        if (it + b < nit) {                      // block-uniform
+          const int kb = unit * 4 + 2 * KH * (it + b);
 #pragma unroll
-          for (int r = 0; r < MR; r++) {
-            const float4 xv = *reinterpret_cast<const float4*>(&xbuf[r * XLD + kb + hstep * 32]);
-            const float4 wa = w[hstep * 4 + 0], wb_ = w[hstep * 4 + 1], wc = w[hstep * 4 + 2], wd = w[hstep * 4 + 3];
-            acc[r][0] += xv.x * wa.x; acc[r][1] += xv.x * wa.y; acc[r][2] += xv.x * wa.z; acc[r][3] += xv.x * wa.w;
-            acc[r][0] += xv.y * wb_.x; acc[r][1] += xv.y * wb_.y; acc[r][2] += xv.y * wb_.z; acc[r][3] += xv.y * wb_.w;
-            acc[r][0] += xv.z * wc.x; acc[r][1] += xv.z * wc.y; acc[r][2] += xv.z * wc.z; acc[r][3] += xv.z * wc.w;
-            acc[r][0] += xv.w * wd.x; acc[r][1] += xv.w * wd.y; acc[r][2] += xv.w * wd.z; acc[r][3] += xv.w * wd.w;
+          for (int hstep = 0; hstep < 2; hstep++) {
+            if (kb + hstep * KH < kn) {
+#pragma unroll
+              for (int r = 0; r < MR; r++) {
+                const float4 xv = *reinterpret_cast<const float4*>(&xbuf[r * XLD + kb + hstep * KH]);
+                const float4 wa = w[b][hstep * 4 + 0], wb_ = w[b][hstep * 4 + 1], wc = w[b][hstep * 4 + 2], wd = w[b][hstep * 4 + 3];
+                acc[r][0] += xv.x * wa.x; acc[r][1] += xv.x * wa.y; acc[r][2] += xv.x * wa.z; acc[r][3] += xv.x * wa.w;
+                acc[r][0] += xv.y * wb_.x; acc[r][1] += xv.y * wb_.y; acc[r][2] += xv.y * wb_.z; acc[r][3] += xv.y * wb_.w;
+                acc[r][0] += xv.z * wc.x; acc[r][1] += xv.z * wc.y; acc[r][2] += xv.z * wc.z; acc[r][3] += xv.z * wc.w;
+                acc[r][0] += xv.w * wd.x; acc[r][1] += xv.w * wd.y; acc[r][2] += xv.w * wd.z; acc[r][3] += xv.w * wd.w;
+              }
+            }
           }
+          if (it + b + NBUF < nit) load_round(w[b], it + b + NBUF);
         }
       }
     }
-    __syncthreads();   // everyone is done reading the input rows: reuse the buffer as red[4][MR][128]
+    __syncthreads();   // everyone is done reading the input rows: reuse the buffer as red[4][MR][CT]
 #pragma unroll
     for (int r = 0; r < MR; r++)
 #pragma unroll
-      for (int c = 0; c < 4; c++) acc[r][c] = xor32_sum(acc[r][c]);
+      for (int c = 0; c < 4; c++) {
+        if constexpr (G == 4) acc[r][c] = xor16_sum(acc[r][c]);
+        acc[r][c] = xor32_sum(acc[r][c]);
+      }
     if (half == 0) {
 #pragma unroll
       for (int r = 0; r < MR; r++)
-        *reinterpret_cast<float4*>(&xbuf[(wave * MR + r) * GV_CT + c4]) =
+        *reinterpret_cast<float4*>(&xbuf[(wave * MR + r) * CT + c4]) =
             make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
     }
     __syncthreads();
-    for (int e = tid; e < MR * GV_CT; e += 256) {
-      const int r = e / GV_CT, c = e - r * GV_CT;
+    for (int e = tid; e < MR * CT; e += 256) {
+      const int r = e / CT, c = e - r * CT;
       const int row = r0 + r, col = n0 + c;
       float v = -INFINITY;
       if (row < n_rows && col < a.N && c < ct) {
-        v = (xbuf[(0 * MR + r) * GV_CT + c] + xbuf[(1 * MR + r) * GV_CT + c]) +
-            (xbuf[(2 * MR + r) * GV_CT + c] + xbuf[(3 * MR + r) * GV_CT + c]);
+        v = (xbuf[(0 * MR + r) * CT + c] + xbuf[(1 * MR + r) * CT + c]) +
+            (xbuf[(2 * MR + r) * CT + c] + xbuf[(3 * MR + r) * CT + c]);
         a.P[((int64_t)ks * a.S + row) * a.N + col] = v;
         if constexpr (STATS) { if (a.use_mask) v += a.mask[col]; }   // transcribe.rs:271-275
       }
@@ -330,7 +367,7 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(GemvArgs a) {
       for (int r = wave; r < MR; r += 4) {
         const int row = r0 + r;
         if (row >= n_rows) continue;
-        float v0 = tilev[r][lane], v1 = tilev[r][lane + 64];
+        float v0 = tilev[r][lane], v1 = CT > 64 ? tilev[r][(lane + 64) % CT] : -INFINITY;
         const float m = wave_max(fmaxf(v0, v1));
         const float se = m > -INFINITY ? wave_sum(expf(v0 - m) + expf(v1 - m)) : 0.f;
         float* ts = a.tstats + ((int64_t)row * gridDim.x + blockIdx.x) * TS_STRIDE;
@@ -363,11 +400,15 @@ __device__ __forceinline__ void chained_update(const int* st, const StepLayout& 
 }
 
 // ---- merge the per-tile statistics of one beam's logits row: log_softmax + top-k ------------------
-__global__ __launch_bounds__(256) void dec_topk_merge_kernel(const int* __restrict__ st, const float* __restrict__ tstats,
+// Device-chained greedy decode (gctl != nullptr) with `nx.x` set: the block of row r also PREPARES row r of the
+// next step (token + position embedding, position table, step state), which saves the prepare launch.
+// Cross-block hazards: every block only reads and writes its own row's state; ST_N never changes in a
+// chain; ST_STEP is read and written by block 0 only.
+__global__ __launch_bounds__(256) void dec_topk_merge_kernel(int* __restrict__ st, const float* __restrict__ tstats,
                                                              int n_tiles, int k, int32_t* __restrict__ out_id,
                                                              float* __restrict__ out_lp, float* __restrict__ row_stats,
                                                              StepLayout lay, int* __restrict__ gctl,
-                                                             int* __restrict__ gtok, int Lmax, int eot) {
+                                                             int* __restrict__ gtok, int Lmax, int eot, NextPrep nx) {
   __shared__ float redv[4];
   __shared__ int redi[4];
   __shared__ float bc[2];
@@ -408,6 +449,8 @@ __global__ __launch_bounds__(256) void dec_topk_merge_kernel(const int* __restri
   }
   __syncthreads();
   const float lse = bc[0];
+  const int len_now = st[lay.len + r];
+  int first = 0;
   for (int round = 0; round < k; round++) {
     float bv = tv[0]; int bi = ti[0];
     wave_argmax(bv, bi);
@@ -422,10 +465,32 @@ __global__ __launch_bounds__(256) void dec_topk_merge_kernel(const int* __restri
       out_lp[r * TOPK_MAX + round] = (gv - M) - lse;   // log_softmax, transcribe.rs:276
       if (gctl && round == 0) chained_update(st, lay, gctl, gtok, Lmax, eot, r, gi);
     }
+    if (round == 0) first = gi;
     if (ti[0] == gi) {   // the winner pops its head
 #pragma unroll
       for (int j = 0; j < TOPK_MAX - 1; j++) { tv[j] = tv[j + 1]; ti[j] = ti[j + 1]; }
       tv[TOPK_MAX - 1] = -INFINITY; ti[TOPK_MAX - 1] = 0x7fffffff;
+    }
+  }
+  if (gctl && nx.x && len_now < Lmax) {
+    // next step of the chain: position len_now (0-based) holds token `first`
+    __syncthreads();                       // chained_update (thread 0) has read this row's state
+    const int step = len_now - 1, nstep = step + 1;
+    if (tid == 0) {
+      st[lay.tok + r] = first;
+      st[lay.len + r] = len_now + 1;
+      if (r == 0) st[ST_STEP] = nstep;
+    }
+    int* tab_new = nx.tabs + (size_t)(nstep & 1) * lay.S * Lmax;
+    const int* tab_old = nx.tabs + (size_t)((nstep & 1) ^ 1) * lay.S * Lmax;
+    for (int p = tid; p < len_now; p += 256) tab_new[r * Lmax + p] = tab_old[r * Lmax + p];
+    if (tid == 0) tab_new[r * Lmax + len_now] = nstep * lay.S + r;
+    const float4* e = reinterpret_cast<const float4*>(nx.E + (int64_t)first * nx.d);
+    const float4* pp = reinterpret_cast<const float4*>(nx.pos + (int64_t)len_now * nx.d);
+    float4* o = reinterpret_cast<float4*>(nx.x + (int64_t)r * nx.d);
+    for (int c = tid; c < (nx.d >> 2); c += 256) {
+      float4 a = e[c], b = pp[c];
+      o[c] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
     }
   }
 }
@@ -649,16 +714,7 @@ __global__ void dec_attn_combine_kernel(const int* __restrict__ st, const float*
   const int k = blockIdx.x * blockDim.x + threadIdx.x, d = n_head * 64;
   if (k >= d) return;
   const int hh = k >> 6, dh = k & 63;
-  const float* c0 = ca + ((int64_t)(r * n_head + hh) * n_chunks) * CA_STRIDE;
-  float M = -1.0e30f;
-  for (int c = 0; c < n_chunks; c++) M = fmaxf(M, c0[c * CA_STRIDE]);
-  float num = 0.f, den = 0.f;
-  for (int c = 0; c < n_chunks; c++) {
-    const float w = expf(c0[c * CA_STRIDE] - M);
-    num += w * c0[c * CA_STRIDE + 2 + dh];
-    den += w * c0[c * CA_STRIDE + 1];
-  }
-  out[(int64_t)r * d + k] = num / den;
+  out[(int64_t)r * d + k] = combine_chunks(ca + ((int64_t)(r * n_head + hh) * n_chunks) * CA_STRIDE, n_chunks, dh);
 }
 
 // mask + log_softmax + top-k of one beam's full logits row (batch mode; transcribe.rs:271-304)
@@ -779,12 +835,13 @@ void gemv_plan(int K, int N, int* KS, int* KSL) {
 struct GemmvDummy;
 template <int MR, int XLD, bool LN, bool STATS, bool WBF>
 static void launch_gemv_dpl2(hipStream_t st, dim3 grid, const GemmvDummy*, const GemvArgs& a) {
-  if (!LN) { hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, 1, LN, STATS, WBF>), grid, dim3(256), 0, st, a); return; }
-  if (a.K <= 384) hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, LN ? 6 : 1, LN, STATS, WBF>), grid, dim3(256), 0, st, a);
-  else if (a.K <= 512) hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, LN ? 8 : 1, LN, STATS, WBF>), grid, dim3(256), 0, st, a);
-  else if (a.K <= 768) hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, LN ? 12 : 1, LN, STATS, WBF>), grid, dim3(256), 0, st, a);
-  else if (a.K <= 1024) hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, LN ? 16 : 1, LN, STATS, WBF>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, LN ? 20 : 1, LN, STATS, WBF>), grid, dim3(256), 0, st, a);
+  constexpr int CT = STATS ? GV_CT_LOGITS : GV_CT;
+  if (!LN) { hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, 1, LN, STATS, WBF, CT>), grid, dim3(256), 0, st, a); return; }
+  if (a.K <= 384) hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, LN ? 6 : 1, LN, STATS, WBF, CT>), grid, dim3(256), 0, st, a);
+  else if (a.K <= 512) hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, LN ? 8 : 1, LN, STATS, WBF, CT>), grid, dim3(256), 0, st, a);
+  else if (a.K <= 768) hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, LN ? 12 : 1, LN, STATS, WBF, CT>), grid, dim3(256), 0, st, a);
+  else if (a.K <= 1024) hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, LN ? 16 : 1, LN, STATS, WBF, CT>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, LN ? 20 : 1, LN, STATS, WBF, CT>), grid, dim3(256), 0, st, a);
 }
 template <int MR, int XLD, bool LN, bool STATS>
 static void launch_gemv_dpl(hipStream_t st, dim3 grid, const GemvArgs& a) {
@@ -793,7 +850,7 @@ static void launch_gemv_dpl(hipStream_t st, dim3 grid, const GemvArgs& a) {
 }
 
 void launch_dec_gemv(hipStream_t st, const GemvArgs& a, int n_rows_hint, bool stats) {
-  const int ct = a.ct > 0 ? a.ct : GV_CT;
+  const int ct = a.ct > 0 ? a.ct : (stats ? GV_CT_LOGITS : GV_CT);
   dim3 grid((a.N + ct - 1) / ct, a.KS);
   const bool ln = a.pro == PRO_LN;
   if (stats) {   // logits: LN prologue over whole rows + tile statistics; rows chunked by <= 8
@@ -830,11 +887,11 @@ void launch_dec_cross_attn(hipStream_t st, const int* state, const StepLayout& l
 #undef WB_CA
 }
 
-void launch_dec_topk_merge(hipStream_t st, const int* state, int n_max, const float* tstats, int n_tiles, int k,
+void launch_dec_topk_merge(hipStream_t st, int* state, int n_max, const float* tstats, int n_tiles, int k,
                            int32_t* out_id, float* out_lp, float* row_stats, const StepLayout& lay, int* gctl, int* gtok,
-                           int Lmax, int eot) {
+                           int Lmax, int eot, const NextPrep& nx) {
   hipLaunchKernelGGL(dec_topk_merge_kernel, dim3(n_max), dim3(256), 0, st, state, tstats, n_tiles, k, out_id, out_lp,
-                     row_stats, lay, gctl, gtok, Lmax, eot);
+                     row_stats, lay, gctl, gtok, Lmax, eot, nx);
 }
 
 void launch_dec_logprob_row(hipStream_t st, const float* x, int KS, int64_t plane, int V, const float* mask,

@@ -90,6 +90,7 @@ static int session_finish_encode(wb_session* s, const MelBatch& mb) {
   s->maxC = 0;
   for (int c : s->C) s->maxC = std::max(s->maxC, c);
   s->n_chunks = (s->maxC + cross_attn_chunk() - 1) / cross_attn_chunk();
+  WB_REQUIRE(s->n_chunks <= CA_NCH_MAX, WB_ERR_SHAPE, "encoder context %d too long for the decode kernels", s->maxC);
   // cross-attention K|V of every decoder layer, once per window (mod.rs:484-485 does it per layer/beam/step)
   const int ldkv = NL * 2 * d;
   WB_TRY(s->ckv.ensure((size_t)rows * ldkv * 4));
@@ -164,6 +165,7 @@ int session_reserve(wb_session* s, int max_len) {
   const wb_dims& D = m->dims;
   const int d = D.n_text_state, NL = D.n_text_layer, V = D.n_vocab, S = s->S;
   WB_REQUIRE(d <= 1280, WB_ERR_SHAPE, "decode kernels keep whole rows in LDS: n_state %d > 1280", d);
+  WB_REQUIRE(d % 64 == 0, WB_ERR_SHAPE, "decode kernels need n_state %% 64 == 0 (head size 64), got %d", d);
   max_len = std::max(8, std::min(max_len, std::min(D.n_text_ctx, 448)));
   s->Lmax = max_len;
   const size_t pool = (size_t)max_len * S;
@@ -189,7 +191,7 @@ int session_reserve(wb_session* s, int max_len) {
   gemv_plan(d, 4 * d, &s->ks_1, &s->ksl_1);
   gemv_plan(4 * d, d, &s->ks_2, &s->ksl_2);
   s->ks_v = 1; s->ksl_v = d;                    // logits: whole rows per block (tile statistics need complete sums)
-  s->ct_v = GV_CT;   // (narrower, CU-balanced tiles measured slower: 23.9 vs 21.3 us at V = 51864)
+  s->ct_v = GV_CT_LOGITS;
   s->n_tiles_v = (V + s->ct_v - 1) / s->ct_v;
   WB_TRY(s->x.ensure((size_t)2 * S * d * 4));   // residual stream, ping-pong
   WB_TRY(s->h.ensure((size_t)S * d * 4));
@@ -317,7 +319,11 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
   const int n = n_launch;
 
   int* gctl = chained ? s->gctl.as<int>() : nullptr;
-  launch_dec_prepare(st, hst, s->state.as<int>(), L, n, tabs, s->Lmax, m->tok_emb, m->dec_pos, d, xb[0], gctl);
+  // chained small-batch steps: the previous step's merge kernel already prepared this one (the chain's
+  // first step is prepared by session_greedy_chain)
+  const bool merge_prepares = chained && fuse_ln;
+  if (!merge_prepares)
+    launch_dec_prepare(st, hst, s->state.as<int>(), L, n, tabs, s->Lmax, m->tok_emb, m->dec_pos, d, xb[0], gctl);
   auto gemv = [&](const LinearW& w, int ks, int ksl, int pro, const float* src, int ld_src, float* P) {
     GemvArgs a;
     a.W = w.w; a.ldw = w.n; a.K = w.k; a.N = w.n; a.KS = ks; a.KSL = ksl; a.pro = pro; a.src = src; a.ld_src = ld_src;
@@ -436,8 +442,10 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
     a.mask = s->mask.as<float>(); a.use_mask = use_mask; a.topk = k; a.tstats = s->tstats.as<float>(); a.ct = s->ct_v;
     ln_gemv(a, s->P2.as<float>(), s->ks_2, m->dec[NL - 1].mlp2.b, m->ln_dec, true);
     tm_logits.stop();
-    launch_dec_topk_merge(st, dst, n, s->tstats.as<float>(), s->n_tiles_v, k, out_id_dev, out_lp_dev,
-                          s->row_stats.as<float>(), L, gctl, s->gtok.as<int>(), s->Lmax, eot);
+    NextPrep nx;
+    if (merge_prepares) { nx.x = xb[0]; nx.E = m->tok_emb; nx.pos = m->dec_pos; nx.tabs = tabs; nx.d = d; }
+    launch_dec_topk_merge(st, s->state.as<int>(), n, s->tstats.as<float>(), s->n_tiles_v, k, out_id_dev, out_lp_dev,
+                          s->row_stats.as<float>(), L, gctl, s->gtok.as<int>(), s->Lmax, eot, nx);
     if (timed && tm_logits.on) {
       WB_HIP(hipStreamSynchronize(st));
       tm_logits.collect();
@@ -450,10 +458,13 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
 // Launch one decode step: replay the captured graph for this launch shape (capturing it on first use),
 // or enqueue the kernels eagerly.
 static int launch_step(wb_session* s, int n_launch, int k, int use_mask, bool fuse_ln, int max_nb, bool use_graph,
-                       bool chained, int eot) {
+                       bool chained, int eot, int reps = 1) {
   wb_model* m = s->m;
   hipStream_t st = s->st;
-  if (!use_graph) return enqueue_step(s, n_launch, k, use_mask, fuse_ln, max_nb, true, chained, eot);
+  if (!use_graph) {
+    for (int i = 0; i < reps; i++) WB_TRY(enqueue_step(s, n_launch, k, use_mask, fuse_ln, max_nb, true, chained, eot));
+    return WB_OK;
+  }
   // graphs bake in buffer addresses and launch geometry: drop them if anything moved since capture
   uint64_t sig = 1469598103934665603ull;
   auto mix = [&](uint64_t v) { sig = (sig ^ v) * 1099511628211ull; };
@@ -464,8 +475,10 @@ static int launch_step(wb_session* s, int n_launch, int k, int use_mask, bool fu
   mix((uint64_t)(uintptr_t)s->host_block_dev);
   for (int v : {s->S, s->W, s->Lmax, s->n_chunks, s->max_beams, m->ln_eps_inside_sqrt, eot}) mix((uint64_t)(int64_t)v);
   if (sig != s->buf_sig) { s->clear_graphs(); s->buf_sig = sig; }
-  const uint64_t key = ((uint64_t)n_launch << 32) | ((uint64_t)k << 8) | (chained ? 4u : 0u) | ((uint64_t)use_mask << 1) |
-                       (fuse_ln ? 1u : 0u);
+  // (reps > 1: device-chained steps read their position from the control block, so one graph can hold
+  // several consecutive steps and the host launches once per run)
+  const uint64_t key = ((uint64_t)reps << 48) | ((uint64_t)n_launch << 32) | ((uint64_t)k << 8) | (chained ? 4u : 0u) |
+                       ((uint64_t)use_mask << 1) | (fuse_ln ? 1u : 0u);
   auto it = s->graphs.find(key);
   if (it == s->graphs.end()) {
     hipGraph_t g = nullptr;
@@ -473,7 +486,8 @@ static int launch_step(wb_session* s, int n_launch, int k, int use_mask, bool fu
     static std::mutex capture_mu;                      // captures are rare; keep them off each other's toes
     std::lock_guard<std::mutex> lk(capture_mu);
     WB_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
-    int rc = enqueue_step(s, n_launch, k, use_mask, fuse_ln, max_nb, false, chained, eot);
+    int rc = WB_OK;
+    for (int i = 0; i < reps && rc == WB_OK; i++) rc = enqueue_step(s, n_launch, k, use_mask, fuse_ln, max_nb, false, chained, eot);
     hipError_t e = hipStreamEndCapture(st, &g);
     WB_TRY(rc);
     WB_HIP(e);
@@ -519,18 +533,29 @@ int session_greedy_chain(wb_session* s, int first_token, int eot, int max_depth,
   const int chunk = 16;
   int depth = 0;
   ScopedTimer tm(st, 3);
+  if (fuse_ln)   // first step of the chain; every later one is prepared by its predecessor's merge kernel
+    launch_dec_prepare(st, reinterpret_cast<const int*>(s->host_block_dev), s->state.as<int>(), s->lay, n_launch,
+                       s->tabs.as<int>(), s->Lmax, m->tok_emb, m->dec_pos, m->dims.n_text_state, s->x.as<float>(),
+                       s->gctl.as<int>());
+  // masked steps (the first two, transcribe.rs:271-275) and the tail shorter than a chunk go one step per
+  // graph launch; in between, a whole chunk of steps is ONE graph launch (two multi-step shapes are never
+  // needed: only {1 step masked, 1 step, chunk steps} are captured).  Finished flags are read after each chunk.
+  int since_check = 0;
   while (depth < max_depth) {
-    const int end = std::min(max_depth, depth + chunk);
-    for (; depth < end; depth++) {
-      const int use_mask = (prompt_len + depth) <= mask_until_len ? 1 : 0;   // transcribe.rs:271-275
-      WB_TRY(launch_step(s, n_launch, 1, use_mask, fuse_ln, 1, use_graph, true, eot));
-      if (profile().on) profile().ms[4] += 1;
+    const int use_mask = (prompt_len + depth) <= mask_until_len ? 1 : 0;
+    const int run = (!use_mask && max_depth - depth >= chunk) ? chunk : 1;
+    WB_TRY(launch_step(s, n_launch, 1, use_mask, fuse_ln, 1, use_graph, true, eot, run));
+    if (profile().on) profile().ms[4] += run;
+    depth += run;
+    since_check += run;
+    if (since_check >= chunk || depth >= max_depth) {
+      since_check = 0;
+      WB_HIP(hipMemcpyAsync(ctl.data(), s->gctl.p, ctl_ints * 4, hipMemcpyDeviceToHost, st));
+      WB_HIP(hipStreamSynchronize(st));
+      bool all_done = true;
+      for (int i = 0; i < W; i++) all_done = all_done && ctl[GC_HDR + S + i] != 0;
+      if (all_done) break;
     }
-    WB_HIP(hipMemcpyAsync(ctl.data(), s->gctl.p, ctl_ints * 4, hipMemcpyDeviceToHost, st));
-    WB_HIP(hipStreamSynchronize(st));
-    bool all_done = true;
-    for (int i = 0; i < W; i++) all_done = all_done && ctl[GC_HDR + S + i] != 0;
-    if (all_done) break;
   }
   tm.stop();
   std::vector<int> toks((size_t)S * s->Lmax + 1);

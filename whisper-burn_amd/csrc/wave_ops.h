@@ -84,6 +84,12 @@ __device__ __forceinline__ float xor32_sum(float v) {
   auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+// v[lane] + v[lane ^ 16] in every lane (v_permlane16_swap: the rows of each row pair trade places).
+__device__ __forceinline__ float xor16_sum(float v) {
+  const unsigned u = __float_as_uint(v);
+  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 __device__ __forceinline__ float xor32_max(float v) {
   const unsigned u = __float_as_uint(v);
   auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);

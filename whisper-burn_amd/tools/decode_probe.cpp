@@ -49,7 +49,7 @@ int main(int argc, char** argv) {
   float* bias = (float*)dmalloc(4 * d * 4);
   float* g = (float*)dmalloc(d * 4); float* b = (float*)dmalloc(d * 4);
   float* logits = (float*)dmalloc((size_t)S * V * 4);
-  float* tstats = (float*)dmalloc((size_t)S * 512 * TS_STRIDE * 4);
+  float* tstats = (float*)dmalloc((size_t)S * 1024 * TS_STRIDE * 4);
   float* mask = (float*)dmalloc(V * 4);
   StepLayout L = make_step_layout(S, S);
   std::vector<int> hs(L.total, 0);
@@ -99,7 +99,7 @@ int main(int argc, char** argv) {
     GemvArgs a = base(Et, d, V, 1, d); a.ldw = Vp; a.P = logits; a.pro = PRO_LN; a.src = x; a.ld_src = d; a.pend = P; a.KSp = ks_o; a.pbias = bias;
     a.x_out = x + (size_t)S * d; a.ln_g = g; a.ln_b = b; a.ln_eps = 1e-5f; a.mask = mask; a.topk = 1; a.tstats = tstats;
     launch_dec_gemv(st, a, n, true); }});
-  cases.push_back({"topk merge", [&](int) { launch_dec_topk_merge(st, stdev, n, tstats, (V + 127) / 128, 1, (int32_t*)att, att + 64, att + 128); }});
+  cases.push_back({"topk merge", [&](int) { launch_dec_topk_merge(st, stdev, n, tstats, (V + GV_CT_LOGITS - 1) / GV_CT_LOGITS, 1, (int32_t*)att, att + 64, att + 128, L, nullptr, nullptr, Lmax, -1, NextPrep()); }});
   for (auto& c : cases) {
     double e = bench(1000, c.f, false), gph = bench(1000, c.f, true);
     printf("%-28s eager %6.2f us   graph %6.2f us\n", c.name, e, gph);
