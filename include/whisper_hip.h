@@ -86,6 +86,18 @@ int64_t wb_max_waveform_samples(int64_t n_frame_max);
 int wb_prep_audio(int device, const float* pcm, int64_t n, double sample_rate, float* mel,
                   int64_t* n_frames);
 
+/* The frontend alone, batched and device-resident: the window iterator of waveform_to_mel_tensor
+ * (src/transcribe.rs:114-138: window w = pcm[starts[w], +lens[w]) -> prep_audio) followed by the clip /
+ * zero-pad of mels_to_text (src/transcribe.rs:171-177: keep clip_frames frames, append `padding` zero
+ * frames), for all windows in one launch pair.  pcm_dev / mel_dev are DEVICE pointers; window w is written
+ * to mel_dev + w * win_stride as [80][row_stride] (row_stride % 4 == 0, >= frames_out[w]); frames_out[w]
+ * = min(lens[w] / 160, clip_frames) + padding.  iters >= 1 repeats the pass; elapsed_ms (optional)
+ * receives the HIP-event time of all passes on the launch stream (the mel-frames/s measurement). */
+int wb_waveform_to_mels_dev(int device, const float* pcm_dev, int64_t n_samples, double sample_rate,
+                            const int64_t* starts, const int64_t* lens, int32_t n_windows, int32_t clip_frames,
+                            int32_t padding, float* mel_dev, int64_t win_stride, int32_t row_stride,
+                            int32_t* frames_out, int32_t iters, double* elapsed_ms);
+
 /* Whisper::forward_encoder(mel [B,80,T]) -> [B,C,d], C=(T-1)/2+1, src/model/mod.rs:52-54,
  * :228-260.  T > n_audio_ctx -> WB_ERR_SHAPE (mod.rs:236-241). */
 int wb_forward_encoder(wb_model* m, const float* mel, int B, int T, float* out);

@@ -47,6 +47,30 @@ def test_prep_audio_matches_oracle(n, seed):
     assert np.abs(got - ref).max() < MEL_TOL_VS_ORACLE, np.abs(got - ref).max()
 
 
+def test_batched_device_frontend_matches_oracle():
+    """wb_waveform_to_mels_dev: reference windowing (transcribe.rs:114-138) + clip / zero-pad (:171-177),
+    device pointers in and out, equal to prep_audio on every window."""
+    n = 238559 + 2 * 190559 + 5000                     # 4 reference windows, the last one short
+    x = synth.synth_audio(n, 77)
+    starts, lens = wb.window_extents(n, 16000, 238559)
+    assert len(starts) == 4
+    Ts = 1500
+    pcm = torch.from_numpy(x).cuda()
+    out = torch.full((4, 80, Ts), 7.0, dtype=torch.float32, device="cuda")
+    frames, ms = wb.waveform_to_mels_dev(pcm.data_ptr(), n, starts, lens, out.data_ptr(), 80 * Ts, Ts)
+    got = out.cpu().numpy()
+    assert ms > 0
+    for w in range(4):
+        exact = omel.prep_audio_f64(x[starts[w]:starts[w] + lens[w]])
+        keep = min(exact.shape[1], 1490)
+        assert frames[w] == keep + 10
+        assert np.abs(got[w, :, :keep] - exact[:, :keep]).max() < MEL_TOL_VS_EXACT
+        assert (got[w, :, keep:keep + 10] == 0).all()              # padding frames are zeros in log-mel space
+    with pytest.raises(wb.WbError) as e:                            # row stride too small for 1500 frames
+        wb.waveform_to_mels_dev(pcm.data_ptr(), n, starts, lens, out.data_ptr(), 80 * Ts, 1496)
+    assert e.value.status == -1
+
+
 def test_prep_audio_tone_and_digital_silence():
     # bins on the 1e-10 floor: the reference's f32 recipe itself is only ~1e-3 accurate there
     t = np.arange(48000) / 16000.0

@@ -128,6 +128,57 @@ int wb_prep_audio(int device, const float* pcm, int64_t n, double sample_rate, f
   return WB_OK;
 }
 
+int wb_waveform_to_mels_dev(int device, const float* pcm_dev, int64_t n_samples, double sample_rate,
+                            const int64_t* starts, const int64_t* lens, int32_t n_windows, int32_t clip_frames,
+                            int32_t padding, float* mel_dev, int64_t win_stride, int32_t row_stride,
+                            int32_t* frames_out, int32_t iters, double* elapsed_ms) {
+  WB_REQUIRE(pcm_dev && starts && lens && mel_dev && n_windows > 0, WB_ERR_ARG, "wb_waveform_to_mels_dev: bad argument");
+  WB_REQUIRE(clip_frames > 0 && padding >= 0 && iters >= 1, WB_ERR_ARG, "wb_waveform_to_mels_dev: bad clip/padding/iters");
+  std::vector<MelWindow> wins(n_windows);
+  int maxF = 0, maxT = 0;
+  for (int w = 0; w < n_windows; w++) {
+    WB_REQUIRE(starts[w] >= 0 && lens[w] >= 0 && starts[w] + lens[w] <= n_samples, WB_ERR_ARG,
+               "window %d [%lld, +%lld) outside the waveform (%lld samples)", w, (long long)starts[w],
+               (long long)lens[w], (long long)n_samples);
+    WB_REQUIRE(lens[w] >= MEL_N_FFT, WB_ERR_SHAPE, "window %d has %lld samples < n_fft = 400 (audio.rs:292)", w,
+               (long long)lens[w]);
+    WB_REQUIRE(lens[w] < ((int64_t)1 << 30), WB_ERR_SHAPE, "window %d too long", w);
+    const int nf = (int)(lens[w] / MEL_HOP);
+    wins[w] = MelWindow{starts[w], (int32_t)lens[w], nf, std::min(nf, (int)clip_frames), 0};   // transcribe.rs:171-177
+    const int T = wins[w].n_emit + padding;
+    if (frames_out) frames_out[w] = T;
+    maxF = std::max(maxF, nf); maxT = std::max(maxT, T);
+  }
+  WB_REQUIRE(row_stride >= maxT && row_stride % 4 == 0 && win_stride >= (int64_t)80 * row_stride, WB_ERR_ARG,
+             "wb_waveform_to_mels_dev: row_stride %d must be a multiple of 4 and >= %d frames", row_stride, maxT);
+  WB_HIP(hipSetDevice(device));
+  const MelTables* tabs;
+  WB_TRY(get_mel_tables(device, sample_rate, &tabs));
+  DevMem d_win, d_max;
+  WB_TRY(d_win.alloc(wins.size() * sizeof(MelWindow)));
+  WB_TRY(d_max.alloc((size_t)n_windows * mel_bmax_stride(maxF) * 4));
+  hipStream_t st = nullptr;
+  WB_HIP(hipMemcpyAsync(d_win.p, wins.data(), wins.size() * sizeof(MelWindow), hipMemcpyHostToDevice, st));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (elapsed_ms) { WB_HIP(hipEventCreate(&e0)); WB_HIP(hipEventCreate(&e1)); WB_HIP(hipEventRecord(e0, st)); }
+  for (int it = 0; it < iters; it++) {
+    launch_mel_spectrogram(st, pcm_dev, d_win.as<MelWindow>(), n_windows, maxF, tabs, mel_dev, win_stride, row_stride,
+                           d_max.as<float>());
+    launch_mel_finalize(st, d_win.as<MelWindow>(), n_windows, row_stride, padding, mel_dev, win_stride, row_stride,
+                        d_max.as<float>(), maxF);
+  }
+  if (elapsed_ms) WB_HIP(hipEventRecord(e1, st));
+  WB_HIP(hipGetLastError());
+  WB_HIP(hipStreamSynchronize(st));
+  if (elapsed_ms) {
+    float ms = 0.f;
+    WB_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *elapsed_ms = ms;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  }
+  return WB_OK;
+}
+
 int wb_forward_encoder(wb_model* m, const float* mel, int B, int T, float* out) {
   WB_REQUIRE(m && mel && out && B > 0, WB_ERR_ARG, "wb_forward_encoder: bad argument");
   // mod.rs:236-241

@@ -73,6 +73,8 @@ void launch_dec_self_attn(hipStream_t st, const int* state, const StepLayout& la
 void launch_dec_cross_attn(hipStream_t st, const int* state, const StepLayout& lay, int n_windows, int n_head,
                            int n_chunks, const float* Pq, int KS, const float* bq, int d, const float* ckv, int ldkv,
                            int koff, const int* win_row0, const int* win_C, float scale, float* ca, int max_nb);
+// profiling: attach start / stop events to the NEXT launch_dec_gemv of this thread (kernel begin -> end)
+void set_launch_events(hipEvent_t start, hipEvent_t stop);
 // what the merge kernel needs to prepare the NEXT chained step (x == nullptr: it does not)
 struct NextPrep {
   float* x = nullptr;        // residual-stream rows [S][d] the next step starts from

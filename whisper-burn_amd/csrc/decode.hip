@@ -17,6 +17,7 @@
 //   max / sum-exp / top-k, merged by one small block per beam that writes the k (id, log-prob)
 //   pairs straight into mapped host memory.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "decode.h"
 #include "wave_ops.h"
@@ -832,16 +833,29 @@ void gemv_plan(int K, int N, int* KS, int* KSL) {
   *KS = ks; *KSL = ksl;
 }
 
+static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+void set_launch_events(hipEvent_t start, hipEvent_t stop) { g_ev_start = start; g_ev_stop = stop; }
+
+template <typename K>
+static void launch_gemv_k(K kernel, hipStream_t st, dim3 grid, const GemvArgs& a) {
+  if (g_ev_start) {   // profiled launch: events on the dispatch itself
+    hipExtLaunchKernelGGL(kernel, grid, dim3(256), 0, st, g_ev_start, g_ev_stop, 0, a);
+    g_ev_start = g_ev_stop = nullptr;
+  } else {
+    hipLaunchKernelGGL(kernel, grid, dim3(256), 0, st, a);
+  }
+}
+
 struct GemmvDummy;
 template <int MR, int XLD, bool LN, bool STATS, bool WBF>
 static void launch_gemv_dpl2(hipStream_t st, dim3 grid, const GemmvDummy*, const GemvArgs& a) {
   constexpr int CT = STATS ? GV_CT_LOGITS : GV_CT;
-  if (!LN) { hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, 1, LN, STATS, WBF, CT>), grid, dim3(256), 0, st, a); return; }
-  if (a.K <= 384) hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, LN ? 6 : 1, LN, STATS, WBF, CT>), grid, dim3(256), 0, st, a);
-  else if (a.K <= 512) hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, LN ? 8 : 1, LN, STATS, WBF, CT>), grid, dim3(256), 0, st, a);
-  else if (a.K <= 768) hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, LN ? 12 : 1, LN, STATS, WBF, CT>), grid, dim3(256), 0, st, a);
-  else if (a.K <= 1024) hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, LN ? 16 : 1, LN, STATS, WBF, CT>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((dec_gemv_kernel<MR, XLD, LN ? 20 : 1, LN, STATS, WBF, CT>), grid, dim3(256), 0, st, a);
+  if (!LN) { launch_gemv_k(dec_gemv_kernel<MR, XLD, 1, LN, STATS, WBF, CT>, st, grid, a); return; }
+  if (a.K <= 384) launch_gemv_k(dec_gemv_kernel<MR, XLD, LN ? 6 : 1, LN, STATS, WBF, CT>, st, grid, a);
+  else if (a.K <= 512) launch_gemv_k(dec_gemv_kernel<MR, XLD, LN ? 8 : 1, LN, STATS, WBF, CT>, st, grid, a);
+  else if (a.K <= 768) launch_gemv_k(dec_gemv_kernel<MR, XLD, LN ? 12 : 1, LN, STATS, WBF, CT>, st, grid, a);
+  else if (a.K <= 1024) launch_gemv_k(dec_gemv_kernel<MR, XLD, LN ? 16 : 1, LN, STATS, WBF, CT>, st, grid, a);
+  else launch_gemv_k(dec_gemv_kernel<MR, XLD, LN ? 20 : 1, LN, STATS, WBF, CT>, st, grid, a);
 }
 template <int MR, int XLD, bool LN, bool STATS>
 static void launch_gemv_dpl(hipStream_t st, dim3 grid, const GemvArgs& a) {

@@ -14,13 +14,14 @@ Profile& profile() {
   return p;
 }
 
-ScopedTimer::ScopedTimer(hipStream_t s, int slot_) : st(s), slot(slot_), on(profile().on) {
+ScopedTimer::ScopedTimer(hipStream_t s, int slot_, bool attach_) : st(s), slot(slot_), on(profile().on), attach(attach_) {
   if (!on) return;
   if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
-  (void)hipEventRecord(a, st);
+  if (attach) set_launch_events(a, b);        // consumed by the next GEMV launch
+  else (void)hipEventRecord(a, st);
 }
 void ScopedTimer::stop() {
-  if (on) (void)hipEventRecord(b, st);
+  if (on && !attach) (void)hipEventRecord(b, st);
 }
 void ScopedTimer::collect() {
   if (!on) return;
@@ -434,7 +435,7 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
   }
   if (k > 0) {
     // logits = ln(x) . token_embedding^T (mod.rs:155-156), last position only; + mask, tile statistics
-    ScopedTimer tm_logits(st, 6);
+    ScopedTimer tm_logits(st, 6, /*attach=*/true);   // profiled passes: the kernel's own begin -> end
     GemvArgs a;
     a.W = m->tok_emb_t; a.ldw = m->vocab_ld; a.K = d; a.N = V; a.KS = 1; a.KSL = d;
     a.Wb = m->compute_dtype == WB_BF16 ? m->tok_emb_t_bf : nullptr;

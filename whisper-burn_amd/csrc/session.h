@@ -44,9 +44,11 @@ struct Profile {
 };
 Profile& profile();
 // Timed region helper: records two events on `st` and adds the elapsed ms to slot `i` (when profiling is on).
+// `attach` = the events are not recorded on the stream but handed to ONE kernel launch (hipExtLaunchKernelGGL
+// start / stop events): the elapsed time is that kernel's own begin -> end, what rocprofv3 --kernel-trace reports.
 struct ScopedTimer {
-  hipStream_t st; int slot; hipEvent_t a = nullptr, b = nullptr; bool on;
-  ScopedTimer(hipStream_t s, int slot_);
+  hipStream_t st; int slot; hipEvent_t a = nullptr, b = nullptr; bool on; bool attach;
+  ScopedTimer(hipStream_t s, int slot_, bool attach_ = false);
   void stop();          // records the end event
   void collect();       // after the stream was synchronised: accumulate
   ~ScopedTimer();

@@ -2,6 +2,7 @@
 whisper-burn tensor seams.  All compute lives in lib/libwhisper_hip.so (csrc/, gfx950 HIP);
 this package is the thin host-side mirror of the reference interface."""
 from .model import (WB_BF16, WB_F32, Session, Whisper, decode_params, find_chunk_overlap, max_waveform_samples,  # noqa: F401
-                    prep_audio, stitch_windows, waveform_to_text, waveform_to_tokens, window_extents)
+                    prep_audio, stitch_windows, waveform_to_mels_dev, waveform_to_text, waveform_to_tokens,
+                    window_extents)
 from .tokens import SpecialTokens  # noqa: F401
 from ._lib import WbError  # noqa: F401

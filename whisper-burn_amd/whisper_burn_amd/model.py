@@ -60,6 +60,23 @@ def prep_audio(waveform, sample_rate: float = 16000.0, device: int = 0) -> np.nd
     return np.stack(out)
 
 
+def waveform_to_mels_dev(pcm_ptr: int, n_samples: int, starts, lens, mel_ptr: int, win_stride: int, row_stride: int,
+                         sample_rate: float = 16000.0, clip_frames: int = 1490, padding: int = 10, device: int = 0,
+                         iters: int = 1):
+    """transcribe.rs:114-138 + :171-177 for a batch of windows, device pointers in and out.
+    Returns (frames per window, HIP-event milliseconds of all `iters` passes)."""
+    lib = _lib.load()
+    st = np.ascontiguousarray(starts, dtype=np.int64)
+    ln = np.ascontiguousarray(lens, dtype=np.int64)
+    frames = np.zeros(len(st), dtype=np.int32)
+    ms = C.c_double(0.0)
+    check(lib.wb_waveform_to_mels_dev(device, C.c_void_p(pcm_ptr), n_samples, float(sample_rate),
+                                      st.ctypes.data_as(_lib.c_int64_p), ln.ctypes.data_as(_lib.c_int64_p), len(st),
+                                      clip_frames, padding, C.c_void_p(mel_ptr), win_stride, row_stride,
+                                      frames.ctypes.data_as(_lib.c_int32_p), iters, C.byref(ms)))
+    return frames, float(ms.value)
+
+
 class Whisper:
     """mod.rs:41-71 `Whisper<B>` on one MI355X."""
 
