@@ -86,6 +86,20 @@ int64_t wb_max_waveform_samples(int64_t n_frame_max);
 int wb_prep_audio(int device, const float* pcm, int64_t n, double sample_rate, float* mel,
                   int64_t* n_frames);
 
+/* ---- WAV ingest with the reference's sample scaling (next to the hot path) ---------- */
+
+/* load_audio_waveform, src/bin/transcribe/main.rs:31-55 (hound): header of a RIFF/WAVE file.
+ * n_samples is per channel.  Any out pointer may be NULL. */
+int wb_wav_info(const char* path, int64_t* n_samples, int32_t* sample_rate, int32_t* channels,
+                int32_t* bits, int32_t* is_float);
+/* The samples as f32: integer PCM (8 / 16 / 24 / 32 bit) as s / (2^(bits-1) - 1) (main.rs:45-52), IEEE
+ * float as stored (main.rs:48).  A sample rate other than 16 000 Hz or more than one channel ->
+ * WB_ERR_SHAPE (the asserts of main.rs:42-43); capacity < samples -> WB_ERR_ARG. */
+int wb_wav_read_f32(const char* path, float* out, int64_t capacity, int64_t* n_samples);
+/* The same scaling for 16-bit PCM already resident in HBM: dst_dev[i] = src_dev[i] / 32767 (correctly
+ * rounded, bit-identical to the host path); halves the host->device bytes of wb_waveform_to_tokens_dev. */
+int wb_pcm_s16_to_f32_dev(int device, const int16_t* src_dev, int64_t n, float* dst_dev);
+
 /* The frontend alone, batched and device-resident: the window iterator of waveform_to_mel_tensor
  * (src/transcribe.rs:114-138: window w = pcm[starts[w], +lens[w]) -> prep_audio) followed by the clip /
  * zero-pad of mels_to_text (src/transcribe.rs:171-177: keep clip_frames frames, append `padding` zero

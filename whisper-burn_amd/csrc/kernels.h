@@ -37,6 +37,8 @@ void launch_mel_finalize(hipStream_t st, const MelWindow* wins_dev, int n_window
                          int pad, float* out, int64_t win_stride, int row_stride, const float* bmax_dev,
                          int max_frames);
 void launch_fill_f32(hipStream_t st, float* p, int64_t n, float v);
+// 16-bit PCM -> f32 with the reference's scale s / 32767 (bin/transcribe/main.rs:45-52), correctly rounded division
+void launch_pcm_s16_to_f32(hipStream_t st, const int16_t* src, int64_t n, float* dst);
 
 // ---- GEMM (gemm.hip): C = act(A*B + bias) (+ residual) (+ aux[aux_idx[m]]) --------------
 enum { ACT_NONE = 0, ACT_GELU = 1 };

@@ -293,6 +293,26 @@ __global__ void mel_finalize_kernel(const MelWindow* __restrict__ wins, int max_
   }
 }
 
+// 16-bit PCM -> f32, s / 32767 (the reference divides by 2^(b-1) - 1, bin/transcribe/main.rs:45-52); 8 samples per
+// lane: one 16-byte load, two 16-byte stores; IEEE division, so equal to the host loop bit for bit
+__global__ void pcm_s16_to_f32_kernel(const int16_t* __restrict__ src, int64_t n, float* __restrict__ dst) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i + 8 <= n && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+    const uint4 v = *reinterpret_cast<const uint4*>(src + i);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      o[2 * j] = __fdiv_rn((float)(int16_t)(w[j] & 0xffffu), 32767.0f);
+      o[2 * j + 1] = __fdiv_rn((float)(int16_t)(w[j] >> 16), 32767.0f);
+    }
+    *reinterpret_cast<float4*>(dst + i) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(dst + i + 4) = make_float4(o[4], o[5], o[6], o[7]);
+  } else {
+    for (int64_t k = i; k < n && k < i + 8; k++) dst[k] = __fdiv_rn((float)src[k], 32767.0f);
+  }
+}
+
 __global__ void fill_f32_kernel(float* p, int64_t n, float v) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -316,6 +336,12 @@ void launch_mel_finalize(hipStream_t st, const MelWindow* wins_dev, int n_window
   dim3 grid((max_frames_padded + 255) / 256, MEL_N_MELS, n_windows);
   hipLaunchKernelGGL(mel_finalize_kernel, grid, dim3(256), 0, st, wins_dev, max_frames_padded, pad, out,
                      win_stride, row_stride, bmax_dev, mel_bmax_stride(max_frames));
+}
+
+void launch_pcm_s16_to_f32(hipStream_t st, const int16_t* src, int64_t n, float* dst) {
+  if (n <= 0) return;
+  const int64_t threads = (n + 7) / 8;
+  hipLaunchKernelGGL(pcm_s16_to_f32_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, src, n, dst);
 }
 
 void launch_fill_f32(hipStream_t st, float* p, int64_t n, float v) {

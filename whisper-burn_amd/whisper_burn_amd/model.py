@@ -60,6 +60,30 @@ def prep_audio(waveform, sample_rate: float = 16000.0, device: int = 0) -> np.nd
     return np.stack(out)
 
 
+def load_audio_waveform(path: str):
+    """bin/transcribe/main.rs:31-55: (f32 samples, sample_rate); 16 kHz mono only, like the reference."""
+    lib = _lib.load()
+    n, sr = C.c_int64(0), C.c_int32(0)
+    check(lib.wb_wav_info(path.encode(), C.byref(n), C.byref(sr), None, None, None))
+    out = np.empty(int(n.value), dtype=np.float32)
+    got = C.c_int64(0)
+    check(lib.wb_wav_read_f32(path.encode(), _fp(out), int(n.value), C.byref(got)))
+    return out[:int(got.value)], int(sr.value)
+
+
+def wav_info(path: str) -> dict:
+    lib = _lib.load()
+    n, sr, ch, bits, fl = C.c_int64(0), C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    check(lib.wb_wav_info(path.encode(), C.byref(n), C.byref(sr), C.byref(ch), C.byref(bits), C.byref(fl)))
+    return dict(n_samples=int(n.value), sample_rate=int(sr.value), channels=int(ch.value), bits=int(bits.value),
+                is_float=bool(fl.value))
+
+
+def pcm_s16_to_f32_dev(src_ptr: int, n: int, dst_ptr: int, device: int = 0) -> None:
+    """main.rs:45-52 on the device: dst[i] = src[i] / 32767."""
+    check(_lib.load().wb_pcm_s16_to_f32_dev(device, C.c_void_p(src_ptr), n, C.c_void_p(dst_ptr)))
+
+
 def waveform_to_mels_dev(pcm_ptr: int, n_samples: int, starts, lens, mel_ptr: int, win_stride: int, row_stride: int,
                          sample_rate: float = 16000.0, clip_frames: int = 1490, padding: int = 10, device: int = 0,
                          iters: int = 1):
