@@ -67,6 +67,18 @@ int wb_model_load_tensors(const char* const* names, const float* const* data,
                           const int64_t* const* shapes, const int32_t* ranks, int n,
                           int device, int compute_dtype, wb_model** out);
 
+/* load_whisper_model_file, src/bin/transcribe/main.rs:63-70 (+ WhisperConfig::load of `<name>.cfg`, :116-123):
+ * the converter's output (src/bin/convert/main.rs:17-19, :51), NamedMpkGzFileRecorder<FullPrecisionSettings> =
+ * gzip(MessagePack with field names) of the Whisper module record.  cfg_path may be NULL (head counts then
+ * follow from n_state / 64).  Burn 0.9.0 is not vendored with the reference: the reader walks the record
+ * structurally (any map with "value" + "shape" is a tensor named by its key path) -- format parity unpinned. */
+int wb_model_load_burn_record(const char* mpk_gz_path, const char* cfg_path, int device, int compute_dtype,
+                              wb_model** out);
+/* The same reader without a device: calls fn(user, dump-style name, data, shape, rank) per tensor (host logic,
+ * testable without a GPU); a non-zero return of fn stops the walk and is returned. */
+typedef int (*wb_tensor_fn)(void* user, const char* name, const float* data, const int64_t* shape, int32_t rank);
+int wb_burn_record_read(const char* mpk_gz_path, const char* cfg_path, wb_tensor_fn fn, void* user);
+
 /* Whisper::encoder_ctx_size / decoder_ctx_size (mod.rs:64-70) and the rest of the config. */
 int wb_model_dims(const wb_model* m, wb_dims* out);
 void wb_model_free(wb_model* m);

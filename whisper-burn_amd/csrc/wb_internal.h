@@ -72,6 +72,7 @@ struct HostTensor {
 using TensorMap = std::unordered_map<std::string, HostTensor>;
 
 int read_dump_dir(const char* dir, TensorMap* out);   // model_load.cpp
+int read_burn_record(const char* mpk_gz_path, const char* cfg_path, TensorMap* out);   // record_load.cpp
 }  // namespace wb
 struct wb_model;
 namespace wb {

@@ -37,6 +37,8 @@ STEP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, c_int32_p, c_int32_p, c_int32_p, C.c_
                       c_int32_p, c_float_p)
 
 # every symbol include/whisper_hip.h declares: name -> (restype, argtypes)
+TENSOR_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, c_float_p, c_int64_p, C.c_int32)
+
 SIGNATURES = {
     "wb_model_load_dump_dir": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "wb_model_load_tensors": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(c_float_p), C.POINTER(c_int64_p),
@@ -46,6 +48,8 @@ SIGNATURES = {
     "wb_model_set_ln_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "wb_max_waveform_samples": (C.c_int64, [C.c_int64]),
     "wb_prep_audio": (C.c_int, [C.c_int, c_float_p, C.c_int64, C.c_double, c_float_p, c_int64_p]),
+    "wb_model_load_burn_record": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "wb_burn_record_read": (C.c_int, [C.c_char_p, C.c_char_p, TENSOR_FN, C.c_void_p]),
     "wb_wav_info": (C.c_int, [C.c_char_p, c_int64_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p]),
     "wb_wav_read_f32": (C.c_int, [C.c_char_p, c_float_p, C.c_int64, c_int64_p]),
     "wb_pcm_s16_to_f32_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -60,6 +60,21 @@ def prep_audio(waveform, sample_rate: float = 16000.0, device: int = 0) -> np.nd
     return np.stack(out)
 
 
+def burn_record_tensors(mpk_gz_path: str, cfg_path: Optional[str] = None) -> Dict[str, np.ndarray]:
+    """The tensors of a converted model file under their dump-directory names (host only, no GPU)."""
+    out: Dict[str, np.ndarray] = {}
+
+    def cb(_user, name, data, shape, rank):
+        shp = tuple(int(shape[i]) for i in range(rank))
+        n = int(np.prod(shp)) if shp else 1
+        out[name.decode()] = np.ctypeslib.as_array(data, shape=(n,)).copy().reshape(shp)
+        return 0
+
+    fn = _lib.TENSOR_FN(cb)
+    check(_lib.load().wb_burn_record_read(mpk_gz_path.encode(), cfg_path.encode() if cfg_path else None, fn, None))
+    return out
+
+
 def load_audio_waveform(path: str):
     """bin/transcribe/main.rs:31-55: (f32 samples, sample_rate); 16 kHz mono only, like the reference."""
     lib = _lib.load()
@@ -117,6 +132,15 @@ class Whisper:
         """load_whisper(path), load.rs:295-310."""
         h = C.c_void_p()
         check(_lib.load().wb_model_load_dump_dir(path.encode(), device, compute_dtype, C.byref(h)))
+        return Whisper(h, device)
+
+    @staticmethod
+    def load_burn_record(mpk_gz_path: str, cfg_path: Optional[str] = None, device: int = 0,
+                         compute_dtype: int = WB_F32) -> "Whisper":
+        """load_whisper_model_file, bin/transcribe/main.rs:63-70 (+ the .cfg of :116-123)."""
+        h = C.c_void_p()
+        check(_lib.load().wb_model_load_burn_record(mpk_gz_path.encode(), cfg_path.encode() if cfg_path else None,
+                                                    device, compute_dtype, C.byref(h)))
         return Whisper(h, device)
 
     @staticmethod
