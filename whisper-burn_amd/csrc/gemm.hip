@@ -28,7 +28,11 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
-template <int BM, int BN, int WGM, int WGN, int AMODE, int BK>
+// PF = register prefetch depth in k-tiles.  1: the next tile loads while the current one multiplies (the big
+// encoder GEMMs: the grid alone keeps HBM busy).  3: the split-K decode GEMMs -- their grids are a few hundred
+// blocks of 3-10 tiles, so bytes in flight per CU, not tile latency, bound them: each block keeps three tiles
+// (60 KB) in flight.
+template <int BM, int BN, int WGM, int WGN, int AMODE, int BK, int PF = 1>
 __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
   constexpr int KQ = BK / 4;   // float4 quads per A row per k-tile
   constexpr int TM = BM / WGM, TN = BN / WGN;
@@ -85,11 +89,11 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
   constexpr int B_F4 = (BK * BN / 4) / NT;   // float4 loads / thread / tile
   static_assert((BK * BN / 4) % NT == 0, "B tile must divide over the block");
 
-  float4 ra[A_F4 > 0 ? A_F4 : 1];
-  float rc1[A_EL > 0 ? A_EL : 1];
-  float4 rb[B_F4];
+  float4 ra_[PF][A_F4 > 0 ? A_F4 : 1];
+  float rc1_[PF][A_EL > 0 ? A_EL : 1];
+  float4 rb_[PF][B_F4];
 
-  auto load_tile = [&](int k0) {
+  auto load_tile = [&](int k0, auto& ra, auto& rc1, auto& rb) {
     if constexpr (AMODE == AMODE_ROWS) {
 #pragma unroll
       for (int i = 0; i < A_F4; i++) {
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
       rb[i] = v;
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, auto& ra, auto& rc1, auto& rb) {
     if constexpr (AMODE == AMODE_ROWS) {
 #pragma unroll
       for (int i = 0; i < A_F4; i++) {
@@ -159,14 +163,22 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
   const int nk = max(0, kend - kbeg) / BK;
+  // register slot of tile t: t % PF.  Tiles 0 .. PF-1 are requested up front; tile t + PF is requested as
+  // soon as tile t has left its slot for LDS.
+#pragma unroll
+  for (int u = 0; u < PF; u++)
+    if (u < nk) load_tile(kbeg + u * BK, ra_[u], rc1_[u], rb_[u]);
   if (nk > 0) {
-    load_tile(kbeg);
-    store_tile(0);
+    store_tile(0, ra_[0], rc1_[0], rb_[0]);
+    if (PF < nk) load_tile(kbeg + PF * BK, ra_[0], rc1_[0], rb_[0]);
   }
   __syncthreads();
-  for (int t = 0; t < nk; t++) {
+  for (int t0 = 0; t0 < nk; t0 += PF) {
+#pragma unroll
+   for (int u = 0; u < PF; u++) {
+    const int t = t0 + u;
+    if (t >= nk) break;
     const int buf = t & 1;
-    if (t + 1 < nk) load_tile(kbeg + (t + 1) * BK);
 #pragma unroll
     for (int kk = 0; kk < BK / 2; kk++) {
       const int kidx = 2 * kk + lh;
@@ -181,8 +193,12 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
         for (int j = 0; j < RN; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (t + 1 < nk) store_tile(buf ^ 1);
+    if (t + 1 < nk) {
+      store_tile(buf ^ 1, ra_[(u + 1) % PF], rc1_[(u + 1) % PF], rb_[(u + 1) % PF]);
+      if (t + 1 + PF < nk) load_tile(kbeg + (t + 1 + PF) * BK, ra_[(u + 1) % PF], rc1_[(u + 1) % PF], rb_[(u + 1) % PF]);
+    }
     __syncthreads();
+   }
   }
 
   // ---- epilogue ----
@@ -209,10 +225,10 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int AMODE, int BK = 16>
+template <int BM, int BN, int WGM, int WGN, int AMODE, int BK = 16, int PF = 1>
 void launch_cfg(hipStream_t st, const GemmArgs& a) {
   dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.ksplit > 1 ? a.ksplit : 1);
-  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, AMODE, BK>), grid, dim3(NT), 0, st, a);
+  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, AMODE, BK, PF>), grid, dim3(NT), 0, st, a);
 }
 
 }  // namespace
@@ -230,9 +246,9 @@ int launch_gemm_f32(hipStream_t st, const GemmArgs& a) {
     return 0;
   }
   if (a.ksplit > 1 && a.K % 32 != 0) return -1;
-  if (a.M <= 32 && a.ksplit > 1) launch_cfg<32, 128, 1, 4, AMODE_ROWS, 32>(st, a);
+  if (a.M <= 32 && a.ksplit > 1) launch_cfg<32, 128, 1, 4, AMODE_ROWS, 32, 3>(st, a);
   else if (a.M <= 32) launch_cfg<32, 128, 1, 4, AMODE_ROWS>(st, a);
-  else if (a.ksplit > 1) launch_cfg<64, 64, 2, 2, AMODE_ROWS, 32>(st, a);
+  else if (a.ksplit > 1) launch_cfg<64, 64, 2, 2, AMODE_ROWS, 32, 3>(st, a);
   else if (blocks(128, 128) >= 384) launch_cfg<128, 128, 2, 2, AMODE_ROWS>(st, a);
   else launch_cfg<64, 64, 2, 2, AMODE_ROWS>(st, a);
   return 0;
