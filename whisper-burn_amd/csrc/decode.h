@@ -70,9 +70,19 @@ void launch_dec_gemv(hipStream_t st, const GemvArgs& a, int n_rows_hint, bool st
 void launch_dec_self_attn(hipStream_t st, const int* state, const StepLayout& lay, int n_max, int n_head,
                           const float* Pqkv, int KS, const float* bqkv, int d, float* Kc, float* Vc, const int* tab,
                           int Lmax, float scale, float* att);
+// fused query projection of the cross-attention kernel (small models; see dec_cross_attn_kernel)
+struct CaFuse {
+  const float* x_in = nullptr;    // residual stream [S][d]
+  const float* pend = nullptr; int KSp = 0; const float* pbias = nullptr;   // pending out-projection partials + bias
+  float* x_out = nullptr;         // folded residual stream (written by block chunk 0 / head 0 of each window)
+  const float* ln_g = nullptr; const float* ln_b = nullptr; float ln_eps = 0.f; int ln_inside = 0;
+  const float* Wq = nullptr;      // [d][d] row-major
+};
+bool cross_attn_can_fuse_q(int d);
 void launch_dec_cross_attn(hipStream_t st, const int* state, const StepLayout& lay, int n_windows, int n_head,
                            int n_chunks, const float* Pq, int KS, const float* bq, int d, const float* ckv, int ldkv,
-                           int koff, const int* win_row0, const int* win_C, float scale, float* ca, int max_nb);
+                           int koff, const int* win_row0, const int* win_C, float scale, float* ca, int max_nb,
+                           const CaFuse* fuse = nullptr);
 // profiling: attach start / stop events to the NEXT launch_dec_gemv of this thread (kernel begin -> end)
 void set_launch_events(hipEvent_t start, hipEvent_t stop);
 // what the merge kernel needs to prepare the NEXT chained step (x == nullptr: it does not)

@@ -591,20 +591,27 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const int* __restric
 
 // ---- cross-attention over one key chunk of one window's cached K/V, all of its beams -----
 constexpr int CA_CH = 128;   // keys per chunk
-template <int NB>            // register-resident beams per window (>= the largest live count this step)
+// KQ > 0 (= d / 4, small models): the query projection is FUSED -- the block folds the residual stream and the
+// pending out-projection partials of its window's beams, applies cross_attn_ln, and multiplies by the 64 columns
+// of Wq that belong to its head (thread = output column x quarter of K, the weight slice prefetched into
+// registers at kernel start); block (chunk 0, head 0) writes the folded residual stream.  This saves the
+// LN + Wq GEMV launch of every decoder layer; the slice is re-read by the key-chunk blocks of the head (L2).
+template <int NB, int KQ>    // NB: register-resident beams per window (>= the largest live count this step)
 __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const int* __restrict__ st, StepLayout lay,
                                                              const float* __restrict__ Pq, int KS,
                                                              const float* __restrict__ bq, int d,
                                                              const float* __restrict__ ckv, int ldkv, int koff,
                                                              const int* __restrict__ win_row0,
                                                              const int* __restrict__ win_C, float scale,
-                                                             int n_head, int n_chunks, float* __restrict__ ca) {
+                                                             int n_head, int n_chunks, float* __restrict__ ca,
+                                                             CaFuse fz) {
+  __shared__ __attribute__((aligned(16))) float hs[KQ > 0 ? MAX_BEAMS : 1][KQ > 0 ? 4 * KQ : 1];   // cross_attn_ln(x) rows
   __shared__ __attribute__((aligned(16))) float Kt[CA_CH][65];
   __shared__ __attribute__((aligned(16))) float qs[MAX_BEAMS][64];
   __shared__ float sp[2][MAX_BEAMS][CA_CH];
   __shared__ float pb[MAX_BEAMS][CA_CH];
   __shared__ float stat[MAX_BEAMS][2];
-  __shared__ float ored[4][MAX_BEAMS][64];
+  __shared__ __attribute__((aligned(16))) float ored[4][MAX_BEAMS][64];
   const int c = blockIdx.x, h = blockIdx.y, w = blockIdx.z, tid = threadIdx.x;
   const int nb = st[lay.win_nb + w];
   if (nb == 0) return;
@@ -635,17 +642,85 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const int* __restri
     const int j = gq * 32 + i;
     vreg[i] = j < nk ? Vb[(int64_t)j * ldkv + dh_t] : 0.f;
   }
-  // q = (x Wq + bq) * s  (mod.rs:483, :506-509)
-  for (int e = tid; e < nb * 64; e += 256) {
-    const int b = e >> 6, dh = e & 63, col = h * 64 + dh;
-    qs[b][dh] = fold_partials(Pq, KS, (int64_t)lay.S * d, (int64_t)slots[b] * d + col, bq[col]) * scale;
-  }
+  if constexpr (KQ > 0) {
+    // this thread's slice of Wq: column h*64 + dh_t, rows gq*KQ .. +KQ (in flight with everything above; 16-byte
+    // loads with 16 K-groups per block measured slower: 1167x vs 1308x)
+    float wq[KQ];
+    const float* wcol = fz.Wq + (int64_t)(gq * KQ) * d + h * 64 + dh_t;
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    const int e = tid + i * 256, r = e >> 4, q4 = (e & 15) * 4;
-    Kt[r][q4 + 0] = kreg[i].x; Kt[r][q4 + 1] = kreg[i].y; Kt[r][q4 + 2] = kreg[i].z; Kt[r][q4 + 3] = kreg[i].w;
+    for (int i = 0; i < KQ; i++) wq[i] = wcol[(int64_t)i * d];
+    // x + (out-projection of self-attention) -> cross_attn_ln  (mod.rs:346-348), one wave per beam
+    {
+      constexpr int DPL = KQ / 16;                    // d / 64 columns per lane
+      const int wave = tid >> 6, lane = tid & 63;
+      for (int b = wave; b < nb; b += 4) {
+        const int row = slots[b];
+        float v[DPL];
+#pragma unroll
+        for (int i = 0; i < DPL; i++) {
+          const int col = lane + 64 * i;
+          v[i] = fz.x_in[(int64_t)row * d + col] +
+                 fold_partials(fz.pend, fz.KSp, (int64_t)lay.S * d, (int64_t)row * d + col, fz.pbias[col]);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < DPL; i++) {
+          sum += v[i];
+          if (c == 0 && h == 0) fz.x_out[(int64_t)row * d + lane + 64 * i] = v[i];
+        }
+        const float mean = wave_sum(sum) / (float)d;
+        float q2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < DPL; i++) { const float t = v[i] - mean; q2 += t * t; }
+        const float var = wave_sum(q2) / (float)d;
+        const float denom = fz.ln_inside ? sqrtf(var + fz.ln_eps) : (sqrtf(var) + fz.ln_eps);
+#pragma unroll
+        for (int i = 0; i < DPL; i++) {
+          const int col = lane + 64 * i;
+          hs[b][col] = (v[i] - mean) / denom * fz.ln_g[col] + fz.ln_b[col];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int e = tid + i * 256, r = e >> 4, q4 = (e & 15) * 4;
+      Kt[r][q4 + 0] = kreg[i].x; Kt[r][q4 + 1] = kreg[i].y; Kt[r][q4 + 2] = kreg[i].z; Kt[r][q4 + 3] = kreg[i].w;
+    }
+    __syncthreads();
+    {   // q = (cross_attn_ln(x) Wq + bq) * s  (mod.rs:483, :506-509): quarter-K partial sums, then the four quarters
+      float acc[NB];
+#pragma unroll
+      for (int b = 0; b < NB; b++) acc[b] = 0.f;
+#pragma unroll
+      for (int i = 0; i < KQ; i += 4) {
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+          const float4 hv = *reinterpret_cast<const float4*>(&hs[b][gq * KQ + i]);   // rows b >= nb: stale, never read back
+          acc[b] += hv.x * wq[i] + hv.y * wq[i + 1] + hv.z * wq[i + 2] + hv.w * wq[i + 3];
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < NB; b++) ored[gq][b][dh_t] = acc[b];
+    }
+    __syncthreads();
+    for (int e = tid; e < nb * 64; e += 256) {
+      const int b = e >> 6, dh = e & 63;
+      qs[b][dh] = (((ored[0][b][dh] + ored[1][b][dh]) + (ored[2][b][dh] + ored[3][b][dh])) + bq[h * 64 + dh]) * scale;
+    }
+    __syncthreads();
+  } else {
+    // q = (x Wq + bq) * s  (mod.rs:483, :506-509)
+    for (int e = tid; e < nb * 64; e += 256) {
+      const int b = e >> 6, dh = e & 63, col = h * 64 + dh;
+      qs[b][dh] = fold_partials(Pq, KS, (int64_t)lay.S * d, (int64_t)slots[b] * d + col, bq[col]) * scale;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int e = tid + i * 256, r = e >> 4, q4 = (e & 15) * 4;
+      Kt[r][q4 + 0] = kreg[i].x; Kt[r][q4 + 1] = kreg[i].y; Kt[r][q4 + 2] = kreg[i].z; Kt[r][q4 + 3] = kreg[i].w;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   {
     const int j = tid & (CA_CH - 1), hf = tid >> 7;
     float acc[NB];
@@ -887,17 +962,27 @@ void launch_dec_self_attn(hipStream_t st, const int* state, const StepLayout& la
                      tab, Lmax, scale, att);
 }
 
+bool cross_attn_can_fuse_q(int d) { return d == 128 || d == 384 || d == 512; }   // (128: the test fixtures)
+
 void launch_dec_cross_attn(hipStream_t st, const int* state, const StepLayout& lay, int n_windows, int n_head,
                            int n_chunks, const float* Pq, int KS, const float* bq, int d, const float* ckv, int ldkv,
-                           int koff, const int* win_row0, const int* win_C, float scale, float* ca, int max_nb) {
+                           int koff, const int* win_row0, const int* win_C, float scale, float* ca, int max_nb,
+                           const CaFuse* fuse) {
   dim3 grid(n_chunks, n_head, n_windows);
-#define WB_CA(NB_)                                                                                                   \
-  hipLaunchKernelGGL(dec_cross_attn_kernel<NB_>, grid, dim3(256), 0, st, state, lay, Pq, KS, bq, d, ckv, ldkv, koff, \
-                     win_row0, win_C, scale, n_head, n_chunks, ca)
-  if (max_nb <= 1) WB_CA(1);
-  else if (max_nb <= 2) WB_CA(2);
-  else if (max_nb <= 4) WB_CA(4);
-  else WB_CA(8);
+  const CaFuse fz = fuse ? *fuse : CaFuse();
+#define WB_CA(NB_, KQ_)                                                                                              \
+  hipLaunchKernelGGL((dec_cross_attn_kernel<NB_, KQ_>), grid, dim3(256), 0, st, state, lay, Pq, KS, bq, d, ckv, ldkv, \
+                     koff, win_row0, win_C, scale, n_head, n_chunks, ca, fz)
+#define WB_CA_NB(KQ_)                  \
+  if (max_nb <= 1) WB_CA(1, KQ_);      \
+  else if (max_nb <= 2) WB_CA(2, KQ_); \
+  else if (max_nb <= 4) WB_CA(4, KQ_); \
+  else WB_CA(8, KQ_)
+  if (fuse && d == 128) { WB_CA_NB(32); }
+  else if (fuse && d == 384) { WB_CA_NB(96); }
+  else if (fuse && d == 512) { WB_CA_NB(128); }
+  else { WB_CA_NB(0); }
+#undef WB_CA_NB
 #undef WB_CA
 }
 

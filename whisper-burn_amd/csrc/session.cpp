@@ -407,6 +407,11 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
     }
     return WB_OK;
   }
+  // small models, exact-f32 weights, few enough blocks for one resident wave of them: the cross-attention blocks
+  // project their own queries (decode.hip)
+  static const bool fuse_q_enabled = []() { const char* e = getenv("WHISPER_HIP_FUSE_Q"); return !(e && e[0] == '0'); }();
+  const bool fuse_q = fuse_q_enabled && fuse_ln && cross_attn_can_fuse_q(d) && m->compute_dtype != WB_BF16 &&
+                      s->n_chunks * H * s->W <= 256;
   for (int l = 0; l < NL; l++) {   // ResidualDecoderAttentionBlock::forward, mod.rs:345-350
     const DecBlockW& b = m->dec[l];
     ln_gemv(gemv(b.qkv, s->ks_qkv, s->ksl_qkv, PRO_PLAIN, nullptr, d, s->Pqkv.as<float>()),
@@ -416,10 +421,21 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
                          s->kc.as<float>() + (size_t)l * pool * d, s->vc.as<float>() + (size_t)l * pool * d, tabs,
                          s->Lmax, m->qk_scale, att);
     launch_dec_gemv(st, gemv(b.out, s->ks_o, s->ksl_o, PRO_PLAIN, att, d, s->Po.as<float>()), n, false);
-    ln_gemv(gemv(b.cq, s->ks_o, s->ksl_o, PRO_PLAIN, nullptr, d, s->Pq.as<float>()), s->Po.as<float>(), s->ks_o,
-            b.out.b, b.ln2, false);
-    launch_dec_cross_attn(st, dst, L, s->W, H, s->n_chunks, s->Pq.as<float>(), s->ks_o, b.cq.b, d, s->ckv.as<float>(),
-                          ldkv, l * 2 * d, win_row0, win_C, m->qk_scale, s->ca.as<float>(), max_nb);
+    if (fuse_q) {
+      // cross_attn_ln + the query projection inside the cross-attention blocks (one launch less per layer)
+      CaFuse fz;
+      fz.x_in = xb[xi]; fz.pend = s->Po.as<float>(); fz.KSp = s->ks_o; fz.pbias = b.out.b; fz.x_out = xb[xi ^ 1];
+      fz.ln_g = b.ln2.g; fz.ln_b = b.ln2.b; fz.ln_eps = b.ln2.eps; fz.ln_inside = m->ln_eps_inside_sqrt;
+      fz.Wq = b.cq.w;
+      launch_dec_cross_attn(st, dst, L, s->W, H, s->n_chunks, nullptr, 0, b.cq.b, d, s->ckv.as<float>(), ldkv,
+                            l * 2 * d, win_row0, win_C, m->qk_scale, s->ca.as<float>(), max_nb, &fz);
+      xi ^= 1;
+    } else {
+      ln_gemv(gemv(b.cq, s->ks_o, s->ksl_o, PRO_PLAIN, nullptr, d, s->Pq.as<float>()), s->Po.as<float>(), s->ks_o,
+              b.out.b, b.ln2, false);
+      launch_dec_cross_attn(st, dst, L, s->W, H, s->n_chunks, s->Pq.as<float>(), s->ks_o, b.cq.b, d,
+                            s->ckv.as<float>(), ldkv, l * 2 * d, win_row0, win_C, m->qk_scale, s->ca.as<float>(), max_nb);
+    }
     {
       GemvArgs a = gemv(b.cout, s->ks_o, s->ksl_o, PRO_ATTN, s->ca.as<float>(), 0, s->Po.as<float>());
       a.n_head = H; a.n_chunks = s->n_chunks;
