@@ -950,8 +950,7 @@ void launch_dec_gemv(hipStream_t st, const GemvArgs& a, int n_rows_hint, bool st
     else launch_gemv_dpl<8, GV_KSL_MAX, true, false>(st, grid, a);
   } else {
     if (n_rows_hint <= 4) launch_gemv_dpl<4, GV_KSL_MAX, false, false>(st, grid, a);
-    else if (n_rows_hint <= 8) launch_gemv_dpl<8, GV_KSL_MAX, false, false>(st, grid, a);
-    else launch_gemv_dpl<16, GV_KSL_MAX, false, false>(st, grid, a);
+    else launch_gemv_dpl<8, GV_KSL_MAX, false, false>(st, grid, a);
   }
 }
 

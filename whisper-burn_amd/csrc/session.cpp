@@ -336,21 +336,9 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
   // normalises, multiplies -- in one launch when few beams are live
   auto ln_gemv = [&](GemvArgs a, const float* pend, int ks_pend, const float* pbias, const LayerNormW& ln, bool stats) {
     a.ln_g = ln.g; a.ln_b = ln.b; a.ln_eps = ln.eps; a.ln_inside = m->ln_eps_inside_sqrt;
-    if (fuse_ln) {
-      a.pro = PRO_LN; a.src = xb[xi]; a.ld_src = d; a.pend = pend; a.KSp = ks_pend; a.pbias = pbias; a.x_out = xb[xi ^ 1];
-      launch_dec_gemv(st, a, n, stats);
-      xi ^= 1;
-    } else if (stats) {
-      // the tile-statistics kernel is an LN-prologue instantiation: fold in its own launch first
-      launch_dec_resolve_ln(st, dst, n, xb[xi], xb[xi ^ 1], pend, ks_pend, S, pbias, d, ln, m->ln_eps_inside_sqrt, h);
-      a.pro = PRO_LN; a.src = xb[xi ^ 1]; a.ld_src = d; a.pend = nullptr; a.KSp = 0; a.pbias = nullptr; a.x_out = xb[xi];
-      launch_dec_gemv(st, a, n, true);            // (re-writes the same stream into the other buffer)
-    } else {
-      launch_dec_resolve_ln(st, dst, n, xb[xi], xb[xi ^ 1], pend, ks_pend, S, pbias, d, ln, m->ln_eps_inside_sqrt, h);
-      a.pro = PRO_PLAIN; a.src = h; a.ld_src = d;
-      launch_dec_gemv(st, a, n, false);
-      xi ^= 1;
-    }
+    a.pro = PRO_LN; a.src = xb[xi]; a.ld_src = d; a.pend = pend; a.KSp = ks_pend; a.pbias = pbias; a.x_out = xb[xi ^ 1];
+    launch_dec_gemv(st, a, n, stats);
+    xi ^= 1;
   };
   if (!fuse_ln) {
     // ---- batch mode (more than 8 live beams): rows are many enough for the matrix cores ----

@@ -2,10 +2,8 @@
 // session API: window extents, beam search, token-overlap stitch.  Pure integer / f64 host
 // logic, restated exactly (property-tested against the Python restatement in oracle/).
 #include <algorithm>
-#include <atomic>
 #include <cstring>
 #include <string>
-#include <thread>
 
 #include "engine.h"
 #include "session.h"
@@ -283,18 +281,11 @@ static int waveform_to_tokens_impl(wb_model* m, const float* pcm, bool pcm_on_de
   if (win_end < 0 || win_end > n_win) win_end = (int)n_win;
   win_begin = std::max(0, std::min(win_begin, win_end));
   const int n_local = win_end - win_begin;
-  // Window groups: the decode step of one group is a chain of short, latency-bound launches, so
-  // several groups run concurrently, each on its own session / HIP stream / host thread, and their
-  // launches interleave on the GPU (windows are independent: transcribe.rs:195-201).
-  int batch = p->max_batch_windows > 0 ? p->max_batch_windows : 64;
-  static const int max_groups = []() { const char* e = getenv("WHISPER_HIP_GROUPS"); int g = e ? atoi(e) : 1; return std::max(1, std::min(g, 16)); }();
-  int groups = 1;
-  if (p->max_batch_windows <= 0 && !profile().on && n_local >= 16) {
-    groups = std::min(max_groups, n_local / 8);
-    batch = std::min(64, (n_local + groups - 1) / groups);
-  }
+  // windows are independent (transcribe.rs:195-201): they are decoded in batches of up to 64, one session each
+  // (several sessions on concurrent host threads were measured: +9 % at two, slower beyond -- not kept)
+  const int batch = p->max_batch_windows > 0 ? p->max_batch_windows : 64;
   const int n_batches = (n_local + batch - 1) / batch;
-  auto run_batch = [&](int bi, std::string* err) -> int {
+  auto run_batch = [&](int bi) -> int {
     const int b0 = bi * batch, nb = std::min(batch, n_local - b0);
     wb_session* s = nullptr;
     int rc = session_create(m, nb, p->beam_size, p->padding, &s);
@@ -306,24 +297,9 @@ static int waveform_to_tokens_impl(wb_model* m, const float* pcm, bool pcm_on_de
       if (rc == WB_OK) rc = wb_session_decode(s, p, win_tokens + (size_t)b0 * row_stride, row_stride, win_lens + b0);
       wb_session_free(s);
     }
-    if (rc != WB_OK && err) *err = get_error();
     return rc;
   };
-  if (groups <= 1 || n_batches <= 1) {
-    for (int bi = 0; bi < n_batches; bi++) WB_TRY(run_batch(bi, nullptr));
-  } else {
-    std::vector<int> rcs(n_batches, WB_OK);
-    std::vector<std::string> errs(n_batches);
-    std::atomic<int> next{0};
-    std::vector<std::thread> workers;
-    for (int g = 0; g < std::min(groups, n_batches); g++)
-      workers.emplace_back([&]() {
-        for (int bi = next.fetch_add(1); bi < n_batches; bi = next.fetch_add(1)) rcs[bi] = run_batch(bi, &errs[bi]);
-      });
-    for (auto& w : workers) w.join();
-    for (int bi = 0; bi < n_batches; bi++)
-      if (rcs[bi] != WB_OK) { set_error("%s", errs[bi].c_str()); return rcs[bi]; }
-  }
+  for (int bi = 0; bi < n_batches; bi++) WB_TRY(run_batch(bi));
   if (stitched) {
     WB_REQUIRE(n_stitched, WB_ERR_ARG, "n_stitched is null");
     WB_TRY(wb_stitch_windows(win_tokens, row_stride, win_lens, n_local, p->max_n_offsets, p->min_n_overlaps, stitched,
