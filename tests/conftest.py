@@ -12,3 +12,12 @@ for p in (ROOT, PKG):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run via gpurun)")
+
+
+def pytest_sessionstart(session):
+    """A fresh checkout has no lib/libwhisper_hip.so (git-ignored): build it once (hipcc cross-compiles gfx950
+    without a GPU; on the GPU box the built library travels with the snapshot and this is a no-op)."""
+    lib = os.environ.get("WHISPER_HIP_LIB", os.path.join(PKG, "lib", "libwhisper_hip.so"))
+    if not os.path.exists(lib):
+        import __graft_entry__ as g
+        g.build()
