@@ -3,9 +3,9 @@
 // Replaces /root/reference/src/audio.rs:34-56 (prep_audio) + :284-367 (stfft: dense DFT by
 // two [201x400]x[400xT] f32 matmuls, ~60 tiny launches and 3 blocking D2H reads per window)
 // with one launch per batch of windows plus a small finalize pass:
-//   stage 0  the block's contiguous PCM span (5360 samples) is read once, coalesced, with reflect
-//            indexing at the window edges (audio.rs:297-306; no materialised padded copy), and each
-//            sample is scattered to the <= 3 frame rows that contain it
+//   stage 0  interior blocks copy their 32 frame rows as 16-byte pieces (overlaps served by L1); blocks at a
+//            window edge read their contiguous PCM span (5360 samples) once with reflect indexing
+//            (audio.rs:297-306; no materialised padded copy) and scatter each sample to its <= 3 frame rows
 //   stage 1  Hann (audio.rs:272-278, per-lane registers) + 20-point DFTs over n1   } 400-point DFT as an
 //   stage 2  twiddles W400^{n2 k1}, transpose through LDS, 20-point DFTs over n2   } LDS-staged 20x20
 //            Cooley-Tukey FFT, two real frames packed into one complex transform
@@ -43,6 +43,8 @@ constexpr int MEL_THREADS = PAIRS * 20;   // 320
 constexpr int FROW = 426;        // LDS floats per frame row: 2*FROW = 852 >= 840 (U) and 852 % 32 == 20
 constexpr int UROW = 21;         // padded row (float2) of the 20x20 intermediate
 constexpr int OT_OFF = 416;      // a pair's 2 x 80 outputs live behind its two 208-float power spectra
+constexpr int TAP_OFF = 576;     // ... and behind them the taps of mel rows 5p .. 5p+4 (5 x 16 floats) for stage 4
+constexpr int BMAX_OFF = 800;    // the block-maximum scratch (pair 0's region)
 
 struct cpx { float re, im; };
 
@@ -117,15 +119,39 @@ __global__ __launch_bounds__(MEL_THREADS, 3) void mel_spectrogram_kernel(
   const int tid = threadIdx.x;
   const int N = w.n_samples;
   const float* x = pcm + w.pcm_off;
+  // this thread's 4 of the 80 x 16 filterbank taps: they move to LDS next to the power spectra (stage 3), so that
+  // stage 4's tap loop runs on LDS latency instead of one dependent global load per tap
+  const float4 tapq = *reinterpret_cast<const float4*>(&tabs->tap_w[tid * 4]);
+  static_assert(MEL_N_MELS * MEL_MAX_TAPS == MEL_THREADS * 4, "one float4 of taps per thread");
 
   // ---- stage 0: the block's contiguous PCM span (31 hops + 400 = 5360 samples) is read ONCE, coalesced,
   // with reflect indexing at the window edges (audio.rs:297-306); every sample is scattered to the <= 3
   // frame rows that contain it.  The Hann window is applied in stage 1 from per-lane registers.
   constexpr int SPAN = (FPB - 1) * MEL_HOP + MEL_N_FFT;   // 5360
   constexpr int S0_ITERS = (SPAN + MEL_THREADS - 1) / MEL_THREADS;   // 17
-  {
+  const int g0 = f0 * MEL_HOP - MEL_N_FFT / 2;
+  if (g0 >= 0 && g0 + SPAN <= N) {
+    // interior block (all but the first and the last one or two of a window): no reflection, so every frame
+    // row is 100 consecutive 16-byte pieces of the PCM -- straight copies, ten per thread (the overlapping
+    // parts of neighbouring rows come from L1; HBM still sees each sample once)
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // window starts are sample-, not 16 B-aligned
+    constexpr int ROW_Q = MEL_N_FFT / 4, S0F_ITERS = FPB * ROW_Q / MEL_THREADS;   // 100 pieces per row, 10 per thread
+    static_assert(FPB * ROW_Q % MEL_THREADS == 0, "frame rows must divide over the block");
+    f4u v[S0F_ITERS];
+#pragma unroll
+    for (int i = 0; i < S0F_ITERS; i++) {
+      const int e = tid + i * MEL_THREADS, fr = e / ROW_Q, c4 = (e - fr * ROW_Q) * 4;
+      v[i] = *reinterpret_cast<const f4u*>(x + g0 + fr * MEL_HOP + c4);
+    }
+#pragma unroll
+    for (int i = 0; i < S0F_ITERS; i++) {
+      const int e = tid + i * MEL_THREADS, fr = e / ROW_Q, c4 = (e - fr * ROW_Q) * 4;
+      float2* dst = reinterpret_cast<float2*>(&lds[fr * FROW + c4]);      // FROW is even: 8-byte aligned
+      dst[0] = make_float2(v[i].x, v[i].y);
+      dst[1] = make_float2(v[i].z, v[i].w);
+    }
+  } else {
     float xv[S0_ITERS];
-    const int g0 = f0 * MEL_HOP - MEL_N_FFT / 2;
 #pragma unroll
     for (int i = 0; i < S0_ITERS; i++) {
       const int g = tid + i * MEL_THREADS;
@@ -210,11 +236,15 @@ __global__ __launch_bounds__(MEL_THREADS, 3) void mel_spectrogram_kernel(
     int k = q + 20 * i;
     if (k <= 200) { P[k] = pa[i]; P[208 + k] = pb[i]; }
   }
+  {
+    const int m = tid >> 2;                     // taps 4 tid .. 4 tid + 3 belong to mel row m
+    *reinterpret_cast<float4*>(&lds[(m / 5) * 2 * FROW + TAP_OFF + (m % 5) * MEL_MAX_TAPS + (tid & 3) * 4]) = tapq;
+  }
   __syncthreads();
   if constexpr (MEL_STAGE_LIMIT <= 3) { if (lds[tid] == 123.456f) out[0] = 1.f; return; }
   // ---- stage 4: sparse mel filterbank, log10, local max ----
   // lane = frame, half-wave = group of 8 mel rows: the filter taps are uniform over each half-wave
-  // (broadcast loads), only the power spectra come from LDS
+  // (broadcast LDS reads), the power spectra are the lane's own frame
   const float LN10 = 2.30258509299404568402f;   // (f32) ln 10, helper.rs:25
   float lmax = -INFINITY;
   {
@@ -231,7 +261,14 @@ __global__ __launch_bounds__(MEL_THREADS, 3) void mel_spectrogram_kernel(
       const int s0 = s0v[r], len = lenv[r];
       float acc = 0.f;
 #if !defined(MEL_DBG_NOTAPS)
-      for (int t = 0; t < len; t++) acc += tabs->tap_w[m * MEL_MAX_TAPS + t] * Pf[s0 + t];
+      const float* tw = lds + (m / 5) * 2 * FROW + TAP_OFF + (m % 5) * MEL_MAX_TAPS;   // uniform over the half-wave
+      // taps past len are stored as zeros and Pf[s0 + t] stays inside the pair's region (finite FFT leftovers),
+      // so a chunk of four needs no predicate: its eight LDS reads are in flight together
+      for (int t0 = 0; t0 < len; t0 += 4) {
+        const float4 w4 = *reinterpret_cast<const float4*>(tw + t0);
+        const float p0 = Pf[s0 + t0], p1 = Pf[s0 + t0 + 1], p2 = Pf[s0 + t0 + 2], p3 = Pf[s0 + t0 + 3];
+        acc += w4.x * p0; acc += w4.y * p1; acc += w4.z * p2; acc += w4.w * p3;
+      }
 #else
       acc = Pf[s0] + (float)len;
 #endif
@@ -246,14 +283,14 @@ __global__ __launch_bounds__(MEL_THREADS, 3) void mel_spectrogram_kernel(
     }
   }
   lmax = wave_max(lmax);
-  if ((tid & 63) == 0) lds[OT_OFF + 200 + (tid >> 6)] = lmax;   // free tail of pair 0's region
+  if ((tid & 63) == 0) lds[BMAX_OFF + (tid >> 6)] = lmax;   // free tail of pair 0's region
   __syncthreads();
   // one value per block, reduced by the finalize pass: no atomics (235 of them per window would
   // serialise on one L2 word)
   if (tid == 0) {
-    float bm = lds[OT_OFF + 200];
+    float bm = lds[BMAX_OFF];
 #pragma unroll
-    for (int i = 1; i < MEL_THREADS / 64; i++) bm = fmaxf(bm, lds[OT_OFF + 200 + i]);
+    for (int i = 1; i < MEL_THREADS / 64; i++) bm = fmaxf(bm, lds[BMAX_OFF + i]);
     gmax[(int64_t)blockIdx.y * bmax_stride + blockIdx.x] = bm;
   }
   if constexpr (MEL_STAGE_LIMIT <= 4) { if (lds[tid] == 123.456f) out[0] = 1.f; return; }
