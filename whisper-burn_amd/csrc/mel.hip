@@ -42,7 +42,8 @@ constexpr int PAIRS = FPB / 2;   // 16
 constexpr int MEL_THREADS = PAIRS * 20;   // 320
 constexpr int FROW = 426;        // LDS floats per frame row: 2*FROW = 852 >= 840 (U) and 852 % 32 == 20
 constexpr int UROW = 21;         // padded row (float2) of the 20x20 intermediate
-constexpr int OT_OFF = 416;      // a pair's 2 x 80 outputs live behind its two 208-float power spectra
+constexpr int PB_OFF = 209;      // frame b's power spectrum: 209 = 17 mod 64, so stage 4's lane = frame reads hit 32 distinct banks
+constexpr int OT_OFF = 416;      // a pair's 2 x 80 outputs live behind its two power spectra
 constexpr int TAP_OFF = 576;     // ... and behind them the taps of mel rows 5p .. 5p+4 (5 x 16 floats) for stage 4
 constexpr int BMAX_OFF = 800;    // the block-maximum scratch (pair 0's region)
 
@@ -230,11 +231,11 @@ __global__ __launch_bounds__(MEL_THREADS, 3) void mel_spectrogram_kernel(
     }
   }
   __syncthreads();
-  float* P = reg;   // P[0..207] frame a, P[208..415] frame b
+  float* P = reg;   // P[0..200] frame a, P[209..409] frame b
 #pragma unroll
   for (int i = 0; i < 11; i++) {
     int k = q + 20 * i;
-    if (k <= 200) { P[k] = pa[i]; P[208 + k] = pb[i]; }
+    if (k <= 200) { P[k] = pa[i]; P[PB_OFF + k] = pb[i]; }
   }
   {
     const int m = tid >> 2;                     // taps 4 tid .. 4 tid + 3 belong to mel row m
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(MEL_THREADS, 3) void mel_spectrogram_kernel(
   {
     const int f = tid & (FPB - 1), grp = tid >> 5;            // 10 groups x 8 rows
     float* fr_reg = lds + (f >> 1) * 2 * FROW;
-    const float* Pf = fr_reg + (f & 1) * 208;
+    const float* Pf = fr_reg + (f & 1) * PB_OFF;
     const bool live = f0 + f < w.n_frames;
     int s0v[8], lenv[8];
 #pragma unroll
@@ -297,9 +298,19 @@ __global__ __launch_bounds__(MEL_THREADS, 3) void mel_spectrogram_kernel(
   // ---- stage 5: coalesced store of the [80][32] tile ----
   float* o = out + (int64_t)blockIdx.y * win_stride + f0;
   const int nf = min(FPB, w.n_emit - f0);
-  for (int e = tid; e < MEL_N_MELS * FPB; e += MEL_THREADS) {
-    int m = e / FPB, f = e - m * FPB;
-    if (f < nf) o[(int64_t)m * row_stride + f] = lds[(f >> 1) * 2 * FROW + OT_OFF + 2 * m + (f & 1)];
+  if (nf == FPB && (row_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+    // full tile: 80 rows x 8 pieces of 16 bytes, two per thread
+#pragma unroll
+    for (int i = 0; i < MEL_N_MELS * FPB / 4 / MEL_THREADS; i++) {
+      const int e = tid + i * MEL_THREADS, m = e >> 3, f = (e & 7) * 4;
+      const float* a = lds + (f >> 1) * 2 * FROW + OT_OFF + 2 * m;     // frames f, f+1 in one pair region, f+2, f+3 in the next
+      *reinterpret_cast<float4*>(o + (int64_t)m * row_stride + f) = make_float4(a[0], a[1], a[2 * FROW], a[2 * FROW + 1]);
+    }
+  } else {
+    for (int e = tid; e < MEL_N_MELS * FPB; e += MEL_THREADS) {
+      int m = e / FPB, f = e - m * FPB;
+      if (f < nf) o[(int64_t)m * row_stride + f] = lds[(f >> 1) * 2 * FROW + OT_OFF + 2 * m + (f & 1)];
+    }
   }
 }
 
