@@ -314,30 +314,36 @@ __global__ __launch_bounds__(MEL_THREADS, 3) void mel_spectrogram_kernel(
   }
 }
 
-__global__ void mel_finalize_kernel(const MelWindow* __restrict__ wins, int max_frames_padded, int pad,
-                                    float* __restrict__ out, int64_t win_stride, int row_stride,
-                                    const float* __restrict__ bmax, int bmax_stride) {
+// one block per (mel row, window): the window maximum is reduced once per block, the row is rewritten in
+// 16-byte pieces
+__global__ __launch_bounds__(256) void mel_finalize_kernel(const MelWindow* __restrict__ wins, int max_frames_padded,
+                                                           int pad, float* __restrict__ out, int64_t win_stride,
+                                                           int row_stride, const float* __restrict__ bmax,
+                                                           int bmax_stride) {
   __shared__ float wmax;
-  const int w = blockIdx.z, m = blockIdx.y;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (threadIdx.x < 64) {   // global max of the window (audio.rs:50) = max over its blocks' maxima
+  const int m = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
+  if (tid < 64) {   // global max of the window (audio.rs:50) = max over its blocks' maxima
     const int nblk = (wins[w].n_frames + FPB - 1) / FPB;
     float v = -INFINITY;
-    for (int i = threadIdx.x; i < nblk; i += 64) v = fmaxf(v, bmax[(int64_t)w * bmax_stride + i]);
+    for (int i = tid; i < nblk; i += 64) v = fmaxf(v, bmax[(int64_t)w * bmax_stride + i]);
     v = wave_max(v);
-    if (threadIdx.x == 0) wmax = v;
+    if (tid == 0) wmax = v;
   }
   __syncthreads();
-  if (t >= max_frames_padded) return;
-  const int nf = wins[w].n_emit;
-  float* p = out + (int64_t)w * win_stride + (int64_t)m * row_stride + t;
-  if (t < nf) {
-    // audio.rs:50-53: max computed as f64 from the f32 max, (max - 8.0) handed back as f32
-    const float m8 = (float)((double)wmax - 8.0);
-    float v = fmaxf(*p - m8, 0.f) + m8;
-    *p = (v + 4.0f) / 4.0f;
-  } else if (t < nf + pad) {
-    *p = 0.f;   // transcribe.rs:171-177: zero frames in normalised log-mel space
+  const int nf = wins[w].n_emit, end = min(nf + pad, max_frames_padded);
+  float* row = out + (int64_t)w * win_stride + (int64_t)m * row_stride;
+  // audio.rs:50-53: max computed as f64 from the f32 max, (max - 8.0) handed back as f32
+  const float m8 = (float)((double)wmax - 8.0);
+  auto norm = [&](float x) { return (fmaxf(x - m8, 0.f) + m8 + 4.0f) / 4.0f; };
+  const bool vec = (reinterpret_cast<uintptr_t>(row) & 15) == 0;
+  for (int t = tid * 4; t < end; t += 256 * 4) {
+    if (vec && t + 4 <= nf) {
+      float4 v = *reinterpret_cast<float4*>(row + t);
+      *reinterpret_cast<float4*>(row + t) = make_float4(norm(v.x), norm(v.y), norm(v.z), norm(v.w));
+    } else {
+      for (int k = t; k < min(t + 4, end); k++)
+        row[k] = k < nf ? norm(row[k]) : 0.f;   // k >= nf: transcribe.rs:171-177, zero frames in normalised log-mel space
+    }
   }
 }
 
@@ -381,7 +387,7 @@ void launch_mel_spectrogram(hipStream_t st, const float* pcm, const MelWindow* w
 void launch_mel_finalize(hipStream_t st, const MelWindow* wins_dev, int n_windows, int max_frames_padded,
                          int pad, float* out, int64_t win_stride, int row_stride, const float* bmax_dev,
                          int max_frames) {
-  dim3 grid((max_frames_padded + 255) / 256, MEL_N_MELS, n_windows);
+  dim3 grid(MEL_N_MELS, n_windows);
   hipLaunchKernelGGL(mel_finalize_kernel, grid, dim3(256), 0, st, wins_dev, max_frames_padded, pad, out,
                      win_stride, row_stride, bmax_dev, mel_bmax_stride(max_frames));
 }
