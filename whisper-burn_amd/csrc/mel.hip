@@ -107,7 +107,7 @@ __device__ __forceinline__ void dft20(cpx (&x)[20]) {
   }
 }
 
-__global__ __launch_bounds__(MEL_THREADS, 3) void mel_spectrogram_kernel(
+__global__ __launch_bounds__(MEL_THREADS, 4) void mel_spectrogram_kernel(
     const float* __restrict__ pcm, const MelWindow* __restrict__ wins, const MelTables* __restrict__ tabs,
     float* __restrict__ out, int64_t win_stride, int row_stride, float* __restrict__ gmax, int bmax_stride) {
   // 16 x 852 floats = 54 528 B: three blocks per CU (163 584 B of the 160 KiB); every stage aliases the same
@@ -120,9 +120,6 @@ __global__ __launch_bounds__(MEL_THREADS, 3) void mel_spectrogram_kernel(
   const int tid = threadIdx.x;
   const int N = w.n_samples;
   const float* x = pcm + w.pcm_off;
-  // this thread's 4 of the 80 x 16 filterbank taps: they move to LDS next to the power spectra (stage 3), so that
-  // stage 4's tap loop runs on LDS latency instead of one dependent global load per tap
-  const float4 tapq = *reinterpret_cast<const float4*>(&tabs->tap_w[tid * 4]);
   static_assert(MEL_N_MELS * MEL_MAX_TAPS == MEL_THREADS * 4, "one float4 of taps per thread");
 
   // ---- stage 0: the block's contiguous PCM span (31 hops + 400 = 5360 samples) is read ONCE, coalesced,
@@ -218,6 +215,11 @@ __global__ __launch_bounds__(MEL_THREADS, 3) void mel_spectrogram_kernel(
   if constexpr (MEL_STAGE_LIMIT <= 2) { if (lds[tid] == 123.456f) out[0] = 1.f; return; }
   // ---- stage 3: split the packed transform, power spectrum of both frames ----
   // A[k] = (Z[k] + conj Z[400-k]) / 2,  B[k] = (Z[k] - conj Z[400-k]) / (2i)
+  // this thread's 4 of the 80 x 16 filterbank taps (+ start / length of row tid): requested here, they land under
+  // the unpack arithmetic and move to LDS next to the power spectra, so that stage 4's tap loop runs on LDS
+  // latency instead of one dependent global load per tap
+  const float4 tapq = *reinterpret_cast<const float4*>(&tabs->tap_w[tid * 4]);
+  const int tap_s0 = tid < MEL_N_MELS ? tabs->tap_start[tid] : 0, tap_n = tid < MEL_N_MELS ? tabs->tap_len[tid] : 0;
   float pa[11], pb[11];
 #pragma unroll
   for (int i = 0; i < 11; i++) {
@@ -240,13 +242,17 @@ __global__ __launch_bounds__(MEL_THREADS, 3) void mel_spectrogram_kernel(
   {
     const int m = tid >> 2;                     // taps 4 tid .. 4 tid + 3 belong to mel row m
     *reinterpret_cast<float4*>(&lds[(m / 5) * 2 * FROW + TAP_OFF + (m % 5) * MEL_MAX_TAPS + (tid & 3) * 4]) = tapq;
+    if (tid < MEL_N_MELS) {                     // (start, length) of row tid behind its pair region's taps
+      int* meta = reinterpret_cast<int*>(&lds[(tid / 5) * 2 * FROW + TAP_OFF + 5 * MEL_MAX_TAPS + (tid % 5) * 2]);
+      meta[0] = tap_s0; meta[1] = tap_n;
+    }
   }
   __syncthreads();
   if constexpr (MEL_STAGE_LIMIT <= 3) { if (lds[tid] == 123.456f) out[0] = 1.f; return; }
   // ---- stage 4: sparse mel filterbank, log10, local max ----
   // lane = frame, half-wave = group of 8 mel rows: the filter taps are uniform over each half-wave
   // (broadcast LDS reads), the power spectra are the lane's own frame
-  const float LN10 = 2.30258509299404568402f;   // (f32) ln 10, helper.rs:25
+  const float INV_LN10 = 0.43429448190325182765f;   // 1 / ln 10 (helper.rs:24-27 divides by ln 10)
   float lmax = -INFINITY;
   {
     const int f = tid & (FPB - 1), grp = tid >> 5;            // 10 groups x 8 rows
@@ -255,7 +261,11 @@ __global__ __launch_bounds__(MEL_THREADS, 3) void mel_spectrogram_kernel(
     const bool live = f0 + f < w.n_frames;
     int s0v[8], lenv[8];
 #pragma unroll
-    for (int r = 0; r < 8; r++) { s0v[r] = tabs->tap_start[grp * 8 + r]; lenv[r] = tabs->tap_len[grp * 8 + r]; }
+    for (int r = 0; r < 8; r++) {
+      const int m = grp * 8 + r;
+      const int* meta = reinterpret_cast<const int*>(&lds[(m / 5) * 2 * FROW + TAP_OFF + 5 * MEL_MAX_TAPS + (m % 5) * 2]);
+      s0v[r] = meta[0]; lenv[r] = meta[1];
+    }
 #pragma unroll
     for (int r = 0; r < 8; r++) {
       const int m = grp * 8 + r;
@@ -275,7 +285,7 @@ __global__ __launch_bounds__(MEL_THREADS, 3) void mel_spectrogram_kernel(
 #endif
       // tensor_max_scalar(x, 1e-10) = relu(x - 1e-10) + 1e-10 (helper.rs:8-10); log10 = ln/ln10 (:24-27)
 #if !defined(MEL_DBG_NOLOG)
-      const float v = logf(fmaxf(acc - 1.0e-10f, 0.f) + 1.0e-10f) / LN10;
+      const float v = logf(fmaxf(acc - 1.0e-10f, 0.f) + 1.0e-10f) * INV_LN10;   // (x / ln10 up to 1 ulp; tolerance class "mel")
 #else
       const float v = acc;
 #endif
