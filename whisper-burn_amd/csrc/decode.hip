@@ -526,6 +526,15 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const int* __restric
     float* dst = (which == 1 ? Kc : Vc) + (int64_t)tbs[len - 1] * d + h * 64 + lane;
     *dst = qkv[which][lane];
   }
+  // this thread's V column for positions p = wave (mod 4): requested BEFORE the K rows are consumed, so the two
+  // cache streams share one round trip (they only depend on the position table)
+  const int col = h * 64 + lane;
+  float vpre[28];
+#pragma unroll
+  for (int i = 0; i < 28; i++) {
+    const int p = wave + 4 * i;
+    vpre[i] = p < len - 1 ? Vc[(int64_t)tbs[p] * d + col] : 0.f;
+  }
   // scores: one position per thread (len <= 448 -> at most 2 passes)
   float sc[2];
   float m = -INFINITY;
@@ -552,14 +561,6 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const int* __restric
       sc[j] = acc;
       m = fmaxf(m, acc);
     }
-  }
-  // this thread's V column for positions p = wave (mod 4): issued before the softmax reductions
-  const int col = h * 64 + lane;
-  float vpre[28];
-#pragma unroll
-  for (int i = 0; i < 28; i++) {
-    const int p = wave + 4 * i;
-    vpre[i] = p < len - 1 ? Vc[(int64_t)tbs[p] * d + col] : 0.f;
   }
   m = wave_max(m);
   if (lane == 0) red[wave] = m;

@@ -10,10 +10,11 @@
 //   stage 2  twiddles W400^{n2 k1}, transpose through LDS, 20-point DFTs over n2   } LDS-staged 20x20
 //            Cooley-Tukey FFT, two real frames packed into one complex transform
 //   stage 3  unpack the two spectra, |X|^2 for bins 0..200
-//   stage 4  sparse Slaney filterbank (<= 14 taps per row, audio.rs:67-143; lane = frame, half-wave = 8
-//            mel rows so the taps are broadcast loads), relu(x-1e-10)+1e-10, ln(x)/ln10
+//   stage 4  sparse Slaney filterbank (<= 16 taps per row, audio.rs:67-143; lane = frame, half-wave = 8
+//            mel rows; taps, starts and lengths sit in LDS behind the power spectra so the tap loop is
+//            unpredicated 4-tap chunks of broadcast LDS reads), relu(x-1e-10)+1e-10, ln(x)/ln10
 //            (helper.rs:8-10, :24-27), block maximum (no atomics)
-//   stage 5  coalesced store of the [80][32] tile
+//   stage 5  16-byte stores of the [80][32] tile
 // finalize: window max over the block maxima (audio.rs:50), max(x, max-8), (x+4)/4, zero padding frames.
 // Bound: HBM (640 B PCM in + 320 B mel out per frame); ~11 kFLOP per frame of f32 VALU.
 //
