@@ -226,7 +226,7 @@ def main() -> None:
                "roofline_ms_per_step": {k: round(v, 4) for k, v in rl.items()},
                "note": "per-GPU roofline of the same step: algorithmic bytes over 8 TB/s (mel, decode) and FLOPs over "
                        "the dense MFMA peak of the path's dtype (encoder, cross-K/V); decode is launch-latency-bound "
-                       "at this size (35 dependent launches per token)"}
+                       "at this size (30 dependent launches per token)"}
         out = {
             "metric": "real-time factor (audio-sec/wall-sec)",
             "value": round(audio_s / dt, 2),

@@ -159,7 +159,11 @@ int wb_waveform_to_mels_dev(int device, const float* pcm_dev, int64_t n_samples,
   WB_TRY(d_max.alloc((size_t)n_windows * mel_bmax_stride(maxF) * 4));
   hipStream_t st = nullptr;
   WB_HIP(hipMemcpyAsync(d_win.p, wins.data(), wins.size() * sizeof(MelWindow), hipMemcpyHostToDevice, st));
-  hipEvent_t e0 = nullptr, e1 = nullptr;
+  struct Events {   // released on every return path
+    hipEvent_t a = nullptr, b = nullptr;
+    ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+  } ev;
+  hipEvent_t& e0 = ev.a; hipEvent_t& e1 = ev.b;
   if (elapsed_ms) { WB_HIP(hipEventCreate(&e0)); WB_HIP(hipEventCreate(&e1)); WB_HIP(hipEventRecord(e0, st)); }
   for (int it = 0; it < iters; it++) {
     launch_mel_spectrogram(st, pcm_dev, d_win.as<MelWindow>(), n_windows, maxF, tabs, mel_dev, win_stride, row_stride,
@@ -174,7 +178,6 @@ int wb_waveform_to_mels_dev(int device, const float* pcm_dev, int64_t n_samples,
     float ms = 0.f;
     WB_HIP(hipEventElapsedTime(&ms, e0, e1));
     *elapsed_ms = ms;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   }
   return WB_OK;
 }
