@@ -3,13 +3,14 @@
 // The reference re-runs the whole decoder over the whole prefix for every beam at every step
 // and re-projects the cross-attention K/V in every layer (/root/reference/src/transcribe.rs:270,
 // src/model/mod.rs:482-490), then ships [n, L, V] logits to log_softmax and V floats per beam to
-// the host (transcribe.rs:276-284).  Here a step touches each decoder weight once, in 8 launches
-// per layer + 3:
+// the host (transcribe.rs:276-284).  Here a step touches each decoder weight once, in 7-8 launches
+// per layer + 2-3 (small models project the cross-attention queries inside the attention blocks; in the
+// device-chained greedy loop the merge kernel prepares the next step):
 //   skinny GEMMs (rows = live beams) stream W[K][N] once with K split over blocks into
 //   deterministic partial sums; the CONSUMER folds the partials in its prologue (+bias, residual,
 //   LayerNorm / GELU / q-scale / attention-chunk combine), so there is no reduction kernel and
-//   no atomic; the first weight tile is prefetched ahead of the prologue so the two global
-//   latencies overlap;
+//   no atomic; weight rounds are software-pipelined through 2-3 register sets, the first one
+//   requested ahead of the prologue so the two global latencies overlap;
 //   self-attention reads a paged self-KV cache through per-beam position tables (beam
 //   re-indexing = copying a row of ints); cross-attention streams each window's cached K/V once
 //   for all of that window's beams, split over key chunks (flash-decoding);
