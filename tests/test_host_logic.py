@@ -218,3 +218,40 @@ def test_partition_windows_is_a_contiguous_cover(n, world):
     for (a, b), (c, d) in zip(blocks, blocks[1:]):
         assert b == c and a <= b
     assert max(b - a for a, b in blocks) <= shard.rows_per_rank(n, world)
+
+
+def test_frontend_entry_validates_its_arguments_before_touching_a_device():
+    """wb_waveform_to_mels_dev: window / stride errors are reported without a GPU (pointers are never read)."""
+    starts = np.array([0, 190559], dtype=np.int64)
+    lens = np.array([238559, 238559], dtype=np.int64)
+    n = 190559 + 238559
+    with pytest.raises(wb.WbError) as e:                    # row stride below the 1500 padded frames
+        wb.waveform_to_mels_dev(0x1000, n, starts, lens, 0x2000, 80 * 1500, 1496)
+    assert e.value.status == -1
+    with pytest.raises(wb.WbError) as e:                    # window past the end of the waveform
+        wb.waveform_to_mels_dev(0x1000, n - 1, starts, lens, 0x2000, 80 * 1500, 1500)
+    assert e.value.status == -1
+    with pytest.raises(wb.WbError) as e:                    # a window shorter than n_fft (audio.rs:292)
+        wb.waveform_to_mels_dev(0x1000, n, starts, np.array([238559, 399], dtype=np.int64), 0x2000, 80 * 1500, 1500)
+    assert e.value.status == -2
+
+
+def test_end_to_end_roofline_model_of_the_bench():
+    """bench.e2e_roofline_ms: stage terms scale the way SURVEY.md 8(d) states them."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    dims = dict(n_text_state=384, n_text_layer=4, n_vocab=51864)
+    lens = [238559, 238559, 98882]                          # the 30 s bench workload
+    a = bench.e2e_roofline_ms(dims, lens, 103, "f32")
+    b = bench.e2e_roofline_ms(dims, lens, 206, "f32")
+    c = bench.e2e_roofline_ms(dims, lens, 103, "bf16")
+    assert abs(b["decode"] - 2 * a["decode"]) < 1e-9 and b["mel"] == a["mel"]
+    assert c["encoder_and_cross_kv"] < a["encoder_and_cross_kv"] and c["decode"] < a["decode"]
+    frames = sum(n // 160 for n in lens)
+    assert abs(a["mel"] - 960.0 * frames / 8e12 * 1e3) < 1e-12
+    # logits stream alone: 4 * V * d bytes per step
+    assert a["decode"] > 103 * 4 * 51864 * 384 / 8e12 * 1e3
+    assert abs(a["total"] - (a["mel"] + a["encoder_and_cross_kv"] + a["decode"])) < 1e-12
