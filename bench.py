@@ -255,6 +255,7 @@ def main() -> None:
         }
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()                 # rank 0 is still printing / profiling while the others are done
         dist.destroy_process_group()
 
 
