@@ -45,7 +45,8 @@ def e2e_roofline_ms(dims, lens, n_steps, dtype):
     enc_ms = (enc_flops + ckv_flops) / (MFMA_PEAK_TFLOPS[dtype] * 1e12) * 1e3
     step_bytes = s * (V * d + L * 14 * d * d) + 4.0 * L * 2 * d * sum(C)     # cached K/V stay f32
     dec_ms = n_steps * step_bytes / (HBM_PEAK_GBS * 1e9) * 1e3
-    return {"mel": mel_ms, "encoder_and_cross_kv": enc_ms, "decode": dec_ms, "total": mel_ms + enc_ms + dec_ms}
+    return {"mel": mel_ms, "encoder_and_cross_kv": enc_ms, "decode": dec_ms, "total": mel_ms + enc_ms + dec_ms,
+            "_work": {"encoder_flops": float(enc_flops + ckv_flops), "decode_bytes": float(n_steps * step_bytes)}}
 
 
 def main() -> None:
@@ -220,6 +221,16 @@ def main() -> None:
         audio_s = args.seconds * world * args.steps
         lo, hi = shard.partition_windows(n_win, rank, world)
         rl = e2e_roofline_ms(eng.dims, lens[lo:hi], 3 + args.max_depth, args.dtype)      # per rank (weak scaling)
+        work = rl.pop("_work")
+        if stages:
+            # achieved rates of the two big stages from their algorithmic work: encoder + cross-K/V from the profiled
+            # passes (large kernels, launch mode does not matter), decode from the TIMED steps minus those stages
+            enc_ms = stages["encoder_ms_per_step"] + stages["cross_kv_ms_per_step"]
+            dec_ms = dt / args.steps * 1e3 - enc_ms - stages["mel_ms_per_step"]
+            stages["encoder_TFLOPs_algorithmic"] = round(work["encoder_flops"] / (enc_ms * 1e-3) / 1e12, 2) if enc_ms > 0 else None
+            stages["encoder_frac_of_mfma_peak"] = round(work["encoder_flops"] / (enc_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[args.dtype], 4) if enc_ms > 0 else None
+            stages["decode_GBps_algorithmic"] = round(work["decode_bytes"] / (dec_ms * 1e-3) / 1e9, 1) if dec_ms > 0 else None
+            stages["decode_frac_of_hbm_peak"] = round(work["decode_bytes"] / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dec_ms > 0 else None
         rtf = audio_s / dt
         rl_rtf = args.seconds / (rl["total"] * 1e-3)
         e2e = {"roofline_rtf": round(rl_rtf, 1), "frac": round((rtf / world) / rl_rtf, 4),

@@ -255,3 +255,4 @@ def test_end_to_end_roofline_model_of_the_bench():
     # logits stream alone: 4 * V * d bytes per step
     assert a["decode"] > 103 * 4 * 51864 * 384 / 8e12 * 1e3
     assert abs(a["total"] - (a["mel"] + a["encoder_and_cross_kv"] + a["decode"])) < 1e-12
+    assert abs(a["_work"]["decode_bytes"] / 8e12 * 1e3 - a["decode"]) < 1e-9
