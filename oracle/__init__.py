@@ -7,7 +7,8 @@ one hot path of Gadersd/whisper-burn:
     src/audio.rs        -> oracle/mel.py
     src/helper.rs       -> oracle/mel.py (tensor_max_scalar, tensor_log10, ...)
     src/model/mod.rs    -> oracle/model.py
-    src/model/load.rs   -> oracle/dumpdir.py   (dump-dir weight format reader)
+    src/model/load.rs   -> (product) whisper-burn_amd/csrc/model_load.cpp; the Python dump-dir reader /
+                           writer the tests use is whisper_burn_amd/dumpdir.py
     src/beam.rs         -> oracle/beam.py
     src/transcribe.rs   -> oracle/transcribe.py
 

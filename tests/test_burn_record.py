@@ -1,6 +1,6 @@
 """The converted-model reader (`<name>.mpk.gz` + `<name>.cfg`; src/bin/convert/main.rs:17-19, :51 writes them,
 src/bin/transcribe/main.rs:63-70, :116-126 loads them).  Burn 0.9.0 is not vendored with the reference, so the
-fixtures are written by `whisper_burn_amd/burnrecord.py` in the documented layout, in both plausible Param
+fixtures are written by `tests/burnrecord.py` (test infrastructure) in the documented layout, in both plausible Param
 nestings; format parity is unpinned (csrc/record_load.cpp header)."""
 import gzip
 
@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 
 import whisper_burn_amd as wb
-from whisper_burn_amd import burnrecord, synth
+import burnrecord
+from whisper_burn_amd import synth
 
 
 @pytest.fixture(scope="module")

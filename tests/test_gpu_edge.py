@@ -24,27 +24,16 @@ def _special(st: wb.SpecialTokens) -> otr.SpecialTokens:
                              st.end_of_text, st.is_special.astype(bool))
 
 
-def eot_prone_weights(alpha: float = 3.7, seed: int = 4242, n_vocab: int = 1031, **dims_kw):
-    """Micro weights whose final LayerNorm bias leans towards the end-of-text embedding: once the special
-    mask lifts (len > 5) end-of-text wins in SOME contexts, so windows finish at different depths."""
-    dims = synth.micro_dims(n_state=128, n_head=2, n_layer=2, n_vocab=n_vocab, **dims_kw)
-    w = synth.synth_weights(dims, seed=seed)
-    st = wb.SpecialTokens.for_vocab(n_vocab)
-    e = w["decoder/token_embedding/weight"][st.end_of_text]
-    w["decoder/ln/bias"] = w["decoder/ln/bias"] + (alpha * e / np.linalg.norm(e)).astype(np.float32)
-    return w, st
-
-
 @pytest.fixture(scope="module")
 def eot_micro():
-    w, st = eot_prone_weights()
-    return OracleWhisper(w), wb.Whisper.from_tensors(w), st
+    """The default synthetic checkpoint: its <|endoftext|> logit ramps up with the position (synth.py), so
+    windows / beams finish at different depths."""
+    dims = synth.micro_dims(n_state=128, n_head=2, n_layer=2, n_vocab=1031)
+    w = synth.synth_weights(dims, seed=4242)
+    return OracleWhisper(w), wb.Whisper.from_tensors(w), wb.SpecialTokens.for_vocab(1031)
 
 
-@pytest.fixture(scope="module")
-def eot_micro_strong():
-    w, st = eot_prone_weights(alpha=4.2)                         # about half of the windows finish early
-    return OracleWhisper(w), wb.Whisper.from_tensors(w), st
+eot_micro_strong = eot_micro
 
 
 @pytest.fixture(scope="module")
@@ -54,11 +43,19 @@ def micro():
     return OracleWhisper(w), wb.Whisper.from_tensors(w), wb.SpecialTokens.for_vocab(1031)
 
 
+@pytest.fixture(scope="module")
+def micro_no_eot():
+    """Without the <|endoftext|> ramp a decode runs to max_depth (long sequences)."""
+    dims = synth.micro_dims(n_state=128, n_head=2, n_layer=2, n_vocab=1031)
+    w = synth.synth_weights(dims, seed=4242, eot_beta=0.0)
+    return OracleWhisper(w), wb.Whisper.from_tensors(w), wb.SpecialTokens.for_vocab(1031)
+
+
 @pytest.mark.parametrize("beam_size", [1, 3, 5])
 def test_windows_finish_on_end_of_text_at_different_depths(eot_micro, beam_size):
     oracle, eng, st = eot_micro
     audio = synth.synth_audio(16000 * 60, 1236)                  # 60 s -> 6 reference windows
-    depth = 24
+    depth = 10
     ref, ref_win = otr.waveform_to_tokens(oracle, _special(st), audio, 16000, beam_size, depth, return_windows=True)
     ended = [w[-1] == st.end_of_text for w in ref_win]
     assert any(ended) and not all(ended), "fixture no longer mixes finished and unfinished windows"
@@ -72,7 +69,7 @@ def test_batch_mode_with_finishing_windows(eot_micro_strong, beam_size):
     """> 8 live rows (batch-mode kernels) while rows drop out on end-of-text."""
     oracle, eng, st = eot_micro_strong
     audio = synth.synth_audio(16000 * 150, 777)                  # 13 windows
-    depth = 16
+    depth = 10
     ref, ref_win = otr.waveform_to_tokens(oracle, _special(st), audio, 16000, beam_size, depth, return_windows=True)
     ended = [w[-1] == st.end_of_text for w in ref_win]
     assert sum(ended) >= 4 and not all(ended)
@@ -84,21 +81,58 @@ def test_batch_mode_with_finishing_windows(eot_micro_strong, beam_size):
 def test_finishing_windows_are_batch_composition_invariant(eot_micro_strong):
     _, eng, st = eot_micro_strong
     audio = synth.synth_audio(16000 * 150, 777)
-    _, wins = wb.waveform_to_tokens(eng, st, audio, 16000, 3, 16)
-    p = wb.decode_params(st, beam_size=3, max_depth=16, max_batch_windows=2)
+    _, wins = wb.waveform_to_tokens(eng, st, audio, 16000, 3, 10)
+    p = wb.decode_params(st, beam_size=3, max_depth=10, max_batch_windows=2)
     _, wins2 = wb.waveform_to_tokens(eng, st, audio, 16000, params=p)
     assert wins2 == wins
 
 
 @pytest.mark.parametrize("beam_size,depth", [(1, 150), (3, 124)])
-def test_long_sequences_cross_the_self_attention_tile(micro, beam_size, depth):
+def test_long_sequences_cross_the_self_attention_tile(micro_no_eot, beam_size, depth):
     """More than 112 cached positions: the second self-attention key tile and the position tables."""
-    oracle, eng, st = micro
+    oracle, eng, st = micro_no_eot
     audio = synth.synth_audio(16000 * 3, 31)
     ref = otr.waveform_to_tokens(oracle, _special(st), audio, 16000, beam_size, depth)
     got, _ = wb.waveform_to_tokens(eng, st, audio, 16000, beam_size, depth)
-    assert len(ref) == 4 + depth
+    assert len(ref) == 4 + depth and len(set(ref[4:])) >= 40
     assert got == ref
+
+
+def test_decode_without_special_mask_is_a_state_error(micro):
+    """The first generated tokens read the special-token mask (transcribe.rs:271-275): a session decode
+    before wb_session_set_special_mask must fail like wb_session_step does, on both decode paths."""
+    _, eng, st = micro
+    audio = synth.synth_audio(16000 * 2, 35)
+    for beams in (1, 2):
+        sess = wb.Session.begin(eng, audio, [0], [len(audio)], max_beams=beams)
+        with pytest.raises(wb.WbError) as e:
+            sess.decode(wb.decode_params(st, beam_size=beams, max_depth=4))
+        assert e.value.status == -6, e.value.status       # WB_ERR_STATE
+        sess.close()
+    # a pooled session must not inherit the previous caller's mask either
+    sess = wb.Session.begin(eng, audio, [0], [len(audio)], max_beams=1)
+    sess.set_special_mask(st.is_special)
+    assert len(sess.decode(wb.decode_params(st, beam_size=1, max_depth=4))[0]) >= 5
+    sess.close()
+    sess = wb.Session.begin(eng, audio, [0], [len(audio)], max_beams=1)
+    with pytest.raises(wb.WbError):
+        sess.decode(wb.decode_params(st, beam_size=1, max_depth=4))
+    sess.close()
+
+
+def test_large_max_depth_only_fails_when_a_window_outgrows_the_context(micro, micro_no_eot):
+    """mod.rs:134-139 fires when a sequence REACHES n_text_ctx, not when max_depth could: with every window
+    ending on <|endoftext|> early, max_depth = 1000 succeeds on both greedy paths; without it, it fails."""
+    oracle, eng, st = micro
+    audio = synth.synth_audio(16000 * 5, 36)
+    ref = otr.waveform_to_tokens(oracle, _special(st), audio, 16000, 1, 460)
+    assert ref[-1] == st.end_of_text and len(ref) < 60
+    got, _ = wb.waveform_to_tokens(eng, st, audio, 16000, 1, 460)
+    assert got == ref
+    _, eng2, _ = micro_no_eot
+    with pytest.raises(wb.WbError) as e:
+        wb.waveform_to_tokens(eng2, st, audio, 16000, 1, 460)
+    assert e.value.status == -2
 
 
 @pytest.mark.parametrize("beam_size", [1, 2])

@@ -50,5 +50,11 @@ def test_tiny_en_on_reference_wav_matches_golden(tmp_path):
     eng = wb.Whisper.load_dump_dir(str(tmp_path))
     assert eng.dims == dict(synth.preset_dims("tiny.en"))
     st = wb.SpecialTokens.for_vocab(51864)
-    assert wb.waveform_to_tokens(eng, st, audio, 16000, 1, 16)[0] == g["tiny_en_greedy"].tolist()
-    assert wb.waveform_to_tokens(eng, st, audio, 16000, 5, 8)[0] == g["tiny_en_beam5"].tolist()
+    assert wb.waveform_to_tokens(eng, st, audio, 16000, 1, 100)[0] == g["tiny_en_wav_greedy"].tolist()
+    assert wb.waveform_to_tokens(eng, st, audio, 16000, 5, 24)[0] == g["tiny_en_wav_beam5"].tolist()
+    eng.close()
+    eng = wb.Whisper.from_tensors(synth.synth_preset("tiny.en", eot_beta=0.0))      # no EOT ramp: to max_depth
+    long = wb.waveform_to_tokens(eng, st, audio, 16000, 1, 100)[0]
+    assert len(long) == 104 and len(set(long[4:])) >= 50
+    assert long == g["tiny_en_wav_greedy_long"].tolist()
+    assert wb.waveform_to_tokens(eng, st, audio, 16000, 5, 40)[0] == g["tiny_en_wav_beam5_long"].tolist()

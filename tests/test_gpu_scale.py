@@ -1,12 +1,9 @@
-"""GPU: BASELINE.json's other configurations as parity cases, at their full geometry where the oracle
-is too slow through size-independent properties:
+"""GPU: size-independent properties of long-audio decoding (the geometry of BASELINE.json's configs #4 / #5:
+10 minutes = 51 reference windows), on tiny.en's real shape to keep the test short -- the NAMED models of
+configs #3-#5 are compared with the oracle in tests/test_gpu_workloads.py:
 
-  #3 base.en, beam 5                      -> token-exact vs the oracle on a short clip
-  #4 small-class long audio (10 min, 51 windows, real tiny.en shapes to keep the test short)
-                                          -> determinism, batch-composition invariance, rank-sharding
-                                             invariance (world sizes 1/2/4/8), oracle spot checks on
-                                             the first and the last window
-  #5 large-v2 (real shape, 1.5 B synthetic parameters) -> greedy token-exact vs the oracle on a 2 s clip
+  determinism, batch-composition invariance, rank-sharding invariance (world sizes 1/2/4/8), oracle spot
+  checks on the first and the last window; plus two short literal-oracle runs on base.en and large-v2.
 """
 import numpy as np
 import pytest
@@ -24,7 +21,7 @@ def _special(st):
                              st.end_of_text, st.is_special.astype(bool))
 
 
-def test_config3_base_en_beam5_matches_oracle():
+def test_base_en_beam5_short_clip_matches_oracle():
     w = synth.synth_preset("base.en")
     eng, oracle = wb.Whisper.from_tensors(w), OracleWhisper(w)
     st = wb.SpecialTokens.for_vocab(51864)
@@ -46,14 +43,15 @@ def tiny_long():
     return w, eng, st, audio, depth, full, wins
 
 
-def test_config4_long_audio_geometry_and_determinism(tiny_long):
+def test_long_audio_geometry_and_determinism(tiny_long):
     _, eng, st, audio, depth, full, wins = tiny_long
-    assert len(wins) == 51 and all(len(t) == 4 + depth for t in wins)
+    assert len(wins) == 51 and all(len(t) <= 4 + depth for t in wins)
+    assert len({tuple(t[4:]) for t in wins}) >= 45            # not a degenerate fixture: the windows differ
     again, wins2 = wb.waveform_to_tokens(eng, st, audio, 16000, 1, depth)
     assert wins2 == wins and again == full                    # bitwise-deterministic decode (no atomics)
 
 
-def test_config4_batch_composition_invariance(tiny_long):
+def test_long_audio_batch_composition_invariance(tiny_long):
     _, eng, st, audio, depth, _, wins = tiny_long
     # windows decoded 7 at a time (small-batch GEMV path) must equal the 51-window batch (MFMA batch path)
     p = wb.decode_params(st, beam_size=1, max_depth=depth, max_batch_windows=7)
@@ -62,7 +60,7 @@ def test_config4_batch_composition_invariance(tiny_long):
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
-def test_config4_rank_sharding_invariance(tiny_long, world):
+def test_long_audio_rank_sharding_invariance(tiny_long, world):
     _, eng, st, audio, depth, full, wins = tiny_long
     rows = []
     for r in range(world):
@@ -76,7 +74,7 @@ def test_config4_rank_sharding_invariance(tiny_long, world):
     assert wb.stitch_windows(buf, lens) == full
 
 
-def test_config4_oracle_spot_checks(tiny_long):
+def test_long_audio_oracle_spot_checks(tiny_long):
     w, _, st, audio, depth, _, wins = tiny_long
     oracle = OracleWhisper(w)
     starts, lens = wb.window_extents(len(audio), 16000, 238559)
@@ -87,7 +85,7 @@ def test_config4_oracle_spot_checks(tiny_long):
         assert ref_windows[0] == wins[i], i
 
 
-def test_config5_large_v2_greedy_matches_oracle():
+def test_large_v2_short_clip_matches_oracle():
     w = synth.synth_preset("large-v2")
     eng = wb.Whisper.from_tensors(w)
     assert eng.dims["n_audio_state"] == 1280 and eng.dims["n_text_layer"] == 32 and eng.dims["n_vocab"] == 51865

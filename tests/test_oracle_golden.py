@@ -62,8 +62,12 @@ def test_oracle_micro_model_matches_golden():
 
 
 def test_oracle_tiny_en_tokens_match_golden():
+    """Config #1: the reference's bundled audio.wav, tiny.en, greedy to max_depth 100 -- the literal loop."""
     g, audio = golden()
     o = OracleWhisper(synth.synth_preset("tiny.en"))
     st = SpecialTokens.for_vocab(51864)
-    assert otr.waveform_to_tokens(o, _ost(st), audio, 16000, 1, 16) == g["tiny_en_greedy"].tolist()
-    assert g["tiny_en_greedy"][:4].tolist() == [50257, 50258, 50358, 50362]
+    assert otr.waveform_to_tokens(o, _ost(st), audio, 16000, 1, 100) == g["tiny_en_wav_greedy"].tolist()
+    assert g["tiny_en_wav_greedy"][:4].tolist() == [50257, 50258, 50358, 50362]
+    on = OracleWhisper(synth.synth_preset("tiny.en", eot_beta=0.0))
+    assert otr.waveform_to_tokens(on, _ost(st), audio, 16000, 1, 100) == g["tiny_en_wav_greedy_long"].tolist()
+    assert len(set(g["tiny_en_wav_greedy_long"][4:].tolist())) >= 50

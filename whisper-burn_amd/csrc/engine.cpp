@@ -45,11 +45,8 @@ int gemm_dispatch(const wb_model* m, hipStream_t st, const GemmArgs& a, const ui
   return WB_OK;
 }
 
-// The LinearW a GemmArgs was built from travels in a side slot so call sites stay one-liners.
-static thread_local const LinearW* g_cur_w = nullptr;
-static int gemm(const wb_model* m, hipStream_t st, const GemmArgs& a) {
-  const LinearW* w = g_cur_w;
-  g_cur_w = nullptr;
+// GEMM against a model weight: `w` supplies the bf16 copy for the speed path (null: f32 kernel only).
+static int gemm(const wb_model* m, hipStream_t st, const GemmArgs& a, const LinearW* w) {
   return gemm_dispatch(m, st, a, w ? w->wt : nullptr, w ? w->k : 0);
 }
 
@@ -57,7 +54,6 @@ static GemmArgs linear_args(const float* A, int M, const LinearW& w, float* C) {
   GemmArgs g;
   g.A = A; g.lda = w.k; g.B = w.w; g.ldb = w.n; g.C = C; g.ldc = w.n; g.bias = w.b;
   g.M = M; g.N = w.n; g.K = w.k;
-  g_cur_w = &w;
   return g;
 }
 
@@ -119,7 +115,7 @@ int run_encoder(wb_model* m, hipStream_t st, Workspace& ws, const MelBatch& mb, 
     g.A = mb.mel; g.a_desc = ws.desc1.as<RowDesc>(); g.conv1_tstride = mb.row_stride;
     g.B = m->conv1.w; g.ldb = d; g.C = x1; g.ldc = d; g.bias = m->conv1.b;
     g.M = rows1; g.N = d; g.K = 240; g.act = ACT_GELU;
-    WB_TRY(gemm(m, st, g));
+    WB_TRY(gemm(m, st, g, nullptr));
   }
   // conv2 (stride 2) + GELU + transpose + positional add (mod.rs:244-252): rows 2c-1..2c+1 of x1 form one A row
   {
@@ -128,27 +124,26 @@ int run_encoder(wb_model* m, hipStream_t st, Workspace& ws, const MelBatch& mb, 
     g.B = m->conv2.w; g.ldb = d; g.C = x; g.ldc = d; g.bias = m->conv2.b;
     g.M = rows2; g.N = d; g.K = 3 * d; g.act = ACT_GELU;
     g.aux = m->enc_pos; g.aux_idx = ws.auxidx.as<int32_t>(); g.ld_aux = d;
-    g_cur_w = &m->conv2;
-    WB_TRY(gemm(m, st, g));
+    WB_TRY(gemm(m, st, g, &m->conv2));
   }
   for (int i = 0; i < D.n_audio_layer; i++) {   // ResidualEncoderAttentionBlock::forward, mod.rs:299-303
     const EncBlockW& b = m->enc[i];
     launch_layernorm(st, x, h, rows2, d, b.ln1.g, b.ln1.b, b.ln1.eps, m->ln_eps_inside_sqrt);
     GemmArgs g = linear_args(h, rows2, b.qkv, qkv);
     g.col_scale = m->qk_scale; g.col_scale_period = 3 * d; g.col_scale_width = 2 * d;   // q*s, k*s (mod.rs:506-514)
-    WB_TRY(gemm(m, st, g));
+    WB_TRY(gemm(m, st, g, &b.qkv));
     launch_attention_f32(st, qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, att, d, ws.segs.as<AttnSeg>(), nw, maxC, H,
                          1.0f, 0);
     g = linear_args(att, rows2, b.out, x);
     g.residual = x; g.ldr = d;
-    WB_TRY(gemm(m, st, g));
+    WB_TRY(gemm(m, st, g, &b.out));
     launch_layernorm(st, x, h, rows2, d, b.ln2.g, b.ln2.b, b.ln2.eps, m->ln_eps_inside_sqrt);
     g = linear_args(h, rows2, b.mlp1, hm);
     g.act = ACT_GELU;
-    WB_TRY(gemm(m, st, g));
+    WB_TRY(gemm(m, st, g, &b.mlp1));
     g = linear_args(hm, rows2, b.mlp2, x);
     g.residual = x; g.ldr = d;
-    WB_TRY(gemm(m, st, g));
+    WB_TRY(gemm(m, st, g, &b.mlp2));
   }
   launch_layernorm(st, x, out_dev, rows2, d, m->ln_post.g, m->ln_post.b, m->ln_post.eps, m->ln_eps_inside_sqrt);
   WB_HIP(hipGetLastError());
@@ -181,33 +176,33 @@ int run_decoder_stateless(wb_model* m, hipStream_t st, Workspace& ws, const int3
   // cross-attention K/V (mod.rs:484-485) for all layers in one GEMM; K columns pre-scaled (mod.rs:510-514)
   GemmArgs g = linear_args(enc_dev, krows, m->ckv_all, ckv);
   g.col_scale = m->qk_scale; g.col_scale_period = 2 * d; g.col_scale_width = d;
-  WB_TRY(gemm(m, st, g));
+  WB_TRY(gemm(m, st, g, &m->ckv_all));
   for (int i = 0; i < NL; i++) {   // ResidualDecoderAttentionBlock::forward, mod.rs:345-350
     const DecBlockW& b = m->dec[i];
     launch_layernorm(st, x, h, rows, d, b.ln1.g, b.ln1.b, b.ln1.eps, m->ln_eps_inside_sqrt);
     g = linear_args(h, rows, b.qkv, qkv);
     g.col_scale = m->qk_scale; g.col_scale_period = 3 * d; g.col_scale_width = 2 * d;
-    WB_TRY(gemm(m, st, g));
+    WB_TRY(gemm(m, st, g, &b.qkv));
     launch_attention_f32(st, qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, att, d, sg, n, L, H, 1.0f, 1);
     g = linear_args(att, rows, b.out, x);
     g.residual = x; g.ldr = d;
-    WB_TRY(gemm(m, st, g));
+    WB_TRY(gemm(m, st, g, &b.out));
     launch_layernorm(st, x, h, rows, d, b.ln2.g, b.ln2.b, b.ln2.eps, m->ln_eps_inside_sqrt);
     g = linear_args(h, rows, b.cq, qkv);
     g.col_scale = m->qk_scale; g.col_scale_period = d; g.col_scale_width = d;
-    WB_TRY(gemm(m, st, g));
+    WB_TRY(gemm(m, st, g, &b.cq));
     launch_attention_f32(st, qkv, d, ckv + (size_t)i * 2 * d, ckv + (size_t)i * 2 * d + d, ldkv, att, d, sg + n, n,
                          L, H, 1.0f, 0);
     g = linear_args(att, rows, b.cout, x);
     g.residual = x; g.ldr = d;
-    WB_TRY(gemm(m, st, g));
+    WB_TRY(gemm(m, st, g, &b.cout));
     launch_layernorm(st, x, h, rows, d, b.ln3.g, b.ln3.b, b.ln3.eps, m->ln_eps_inside_sqrt);
     g = linear_args(h, rows, b.mlp1, hm);
     g.act = ACT_GELU;
-    WB_TRY(gemm(m, st, g));
+    WB_TRY(gemm(m, st, g, &b.mlp1));
     g = linear_args(hm, rows, b.mlp2, x);
     g.residual = x; g.ldr = d;
-    WB_TRY(gemm(m, st, g));
+    WB_TRY(gemm(m, st, g, &b.mlp2));
   }
   launch_layernorm(st, x, h, rows, d, m->ln_dec.g, m->ln_dec.b, m->ln_dec.eps, m->ln_eps_inside_sqrt);
   // logits = x . token_embedding^T (mod.rs:156), streamed from the [d][Vp] transposed copy

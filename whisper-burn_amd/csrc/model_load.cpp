@@ -12,6 +12,8 @@
 
 #include "wb_internal.h"
 
+namespace wb { void session_pool_register(wb_model* m); }
+
 namespace fs = std::filesystem;
 
 namespace wb {
@@ -415,6 +417,7 @@ int build_model(TensorMap& tm, int device, int compute_dtype, wb_model** out) {
     m->tok_emb_bf = b16 + e_bf; m->tok_emb_t_bf = b16 + et_bf;
   }
   *out = m.release();
+  session_pool_register(*out);
   return WB_OK;
 }
 

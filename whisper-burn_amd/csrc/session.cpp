@@ -33,9 +33,18 @@ ScopedTimer::~ScopedTimer() {
   if (b) (void)hipEventDestroy(b);
 }
 
-// sessions are recycled per model so that a transcription loop does not pay hipMalloc per batch
+// sessions are recycled per model so that a transcription loop does not pay hipMalloc per batch.
+// g_pool has an entry for exactly the models that are alive: a session released after its model was freed is
+// destroyed instead of being parked under a dangling key, and a pooled session never outlives its model.
 static std::mutex g_pool_mu;
 static std::unordered_map<wb_model*, std::vector<wb_session*>> g_pool;
+constexpr size_t POOL_MAX_SESSIONS = 8;
+constexpr size_t POOL_MAX_BYTES = (size_t)4 << 30;   // per model: big batches (large-v2 x 64 windows ~ 20 GB) are not parked
+
+void session_pool_register(wb_model* m) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  g_pool[m];
+}
 
 // wb_model_free: pooled sessions of that model die with it
 void session_pool_purge(wb_model* m) {
@@ -48,6 +57,17 @@ void session_pool_purge(wb_model* m) {
   for (wb_session* s : dead) delete s;
 }
 
+static size_t session_device_bytes(const wb_session* s) {
+  size_t n = 0;
+  for (const DevMem* b : {&s->pcm, &s->mel, &s->wins, &s->gmax, &s->enc_out, &s->ckv, &s->win_meta, &s->kc, &s->vc,
+                          &s->tabs, &s->state, &s->x, &s->h, &s->att, &s->Pqkv, &s->Po, &s->Pq, &s->P1, &s->P2, &s->ca,
+                          &s->logits, &s->tstats, &s->row_stats, &s->mask, &s->lp_tmp, &s->gctl, &s->gtok, &s->hm,
+                          &s->ws.x1, &s->ws.x, &s->ws.h, &s->ws.qkv, &s->ws.att, &s->ws.hm, &s->ws.desc1, &s->ws.desc2,
+                          &s->ws.auxidx, &s->ws.segs, &s->ws.misc})
+    n += b->bytes;
+  return n;
+}
+
 int session_create(wb_model* m, int n_windows, int max_beams, int padding, wb_session** out) {
   WB_REQUIRE(m && out, WB_ERR_ARG, "session: null argument");
   WB_REQUIRE(n_windows >= 1, WB_ERR_ARG, "session: n_windows must be >= 1");
@@ -57,19 +77,22 @@ int session_create(wb_model* m, int n_windows, int max_beams, int padding, wb_se
   wb_session* s = nullptr;
   {
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    auto& v = g_pool[m];
-    if (!v.empty()) { s = v.back(); v.pop_back(); }
+    auto it = g_pool.find(m);
+    WB_REQUIRE(it != g_pool.end(), WB_ERR_ARG, "session: the model handle is not alive");
+    if (!it->second.empty()) { s = it->second.back(); it->second.pop_back(); }
   }
   if (!s) {
     s = new wb_session();
     s->m = m;
+    s->device = m->device;
     hipError_t e = hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking);
     if (e != hipSuccess) { delete s; set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); return WB_ERR_HIP; }
   }
   s->W = n_windows; s->max_beams = max_beams; s->S = n_windows * max_beams; s->padding = padding;
   s->T.assign(n_windows, 0); s->C.clear(); s->row0.clear();
   s->prev_len.clear(); s->prev_win.clear(); s->prev_n = 0; s->step = 0;
-  s->has_mask = false; s->decode_ready = false; s->last_had_logits = 0;
+  s->has_mask = false; s->decode_ready = false; s->last_had_logits = 0; s->last_use_mask = 0;
+  s->sample_rate = 16000.0;          // per-use state: a pooled session must not remember its previous caller
   *out = s;
   return WB_OK;
 }
@@ -275,10 +298,20 @@ int wb_session_begin_mel(wb_model* m, const float* mel, const int32_t* T, int n_
 
 void wb_session_free(wb_session* s) {
   if (!s) return;
-  std::lock_guard<std::mutex> lk(g_pool_mu);
-  auto& v = g_pool[s->m];
-  if (v.size() < 8) { v.push_back(s); return; }   // keep the allocations (and captured graphs) for the next batch
-  (void)hipSetDevice(s->m->device);
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = g_pool.find(s->m);     // absent: the model was freed first -- s->m dangles and must not be touched
+    if (it != g_pool.end()) {
+      size_t parked = 0;
+      for (const wb_session* q : it->second) parked += session_device_bytes(q);
+      // keep the allocations (and captured graphs) for the next batch, within a byte budget
+      if (it->second.size() < POOL_MAX_SESSIONS && parked + session_device_bytes(s) <= POOL_MAX_BYTES) {
+        it->second.push_back(s);
+        return;
+      }
+    }
+  }
+  (void)hipSetDevice(s->device);
   delete s;
 }
 
@@ -517,8 +550,14 @@ int session_greedy_chain(wb_session* s, int first_token, int eot, int max_depth,
   const int S = s->S, W = s->W;
   WB_REQUIRE(S == W, WB_ERR_STATE, "chained greedy decode needs max_beams == 1");
   WB_REQUIRE(s->prev_n == W && s->step == prompt_len - 1, WB_ERR_STATE, "chained greedy decode: prompt prefill missing");
-  WB_REQUIRE(s->step + max_depth <= s->Lmax, WB_ERR_SHAPE, "Token sequence length %d must not exceed %d.",
-             s->step + max_depth, s->Lmax);
+  // the first steps read the special-token mask (transcribe.rs:271-275): same contract as wb_session_step
+  WB_REQUIRE(s->has_mask || mask_until_len < prompt_len || max_depth == 0, WB_ERR_STATE,
+             "wb_session_decode: special mask not set");
+  // The reference only fails (mod.rs:134-139) when a sequence actually outgrows n_text_ctx: a large max_depth
+  // whose windows all end on EOT earlier succeeds.  Run at most the steps the context holds; raise the
+  // reference's error afterwards if a window is still unfinished.
+  const int asked_depth = max_depth;
+  max_depth = std::min(max_depth, s->Lmax - s->step);
   WB_HIP(hipSetDevice(m->device));
   hipStream_t st = s->st;
   const size_t ctl_ints = GC_HDR + 3 * (size_t)S;
@@ -578,6 +617,10 @@ int session_greedy_chain(wb_session* s, int first_token, int eot, int max_depth,
   s->step += depth;
   s->prev_len.assign(W, s->step);
   s->last_had_logits = 0;
+  if (max_depth < asked_depth)
+    for (int w = 0; w < W; w++)
+      WB_REQUIRE(ctl[GC_HDR + S + w] != 0, WB_ERR_SHAPE, "Token sequence length %d must not exceed %d.", s->Lmax + 1,
+                 s->Lmax);
   return WB_OK;
 }
 }  // namespace wb

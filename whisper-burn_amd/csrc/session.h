@@ -7,6 +7,7 @@
 
 struct wb_session {
   wb_model* m = nullptr;
+  int device = 0;               // m->device, kept so that a session can be destroyed after its model
   hipStream_t st = nullptr;
   int W = 0, max_beams = 0, S = 0, padding = 0;
   double sample_rate = 16000.0;   // only feeds the mel filterbank (audio.rs:44)
@@ -54,6 +55,7 @@ struct ScopedTimer {
   ~ScopedTimer();
 };
 
+void session_pool_register(wb_model* m);   // a model became alive (build_model)
 void session_pool_purge(wb_model* m);
 int session_create(wb_model* m, int n_windows, int max_beams, int padding, wb_session** out);
 int session_encode_pcm(wb_session* s, const float* pcm, int64_t n_pcm, const int64_t* starts, const int64_t* lens,

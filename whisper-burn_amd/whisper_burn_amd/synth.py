@@ -45,17 +45,65 @@ def sinusoids(length: int, channels: int, max_timescale: float = 10000.0) -> np.
     return np.concatenate([np.sin(t), np.cos(t)], axis=1).astype(np.float32)
 
 
-def synth_weights(dims: dict, seed: int, logit_scale: float = 6.0) -> "OrderedDict[str, np.ndarray]":
-    """Weights dict keyed by dump-dir relative names (no '.npy').
+BENCH_AUDIO_SEED = 1236       # seed 1234 + config# (bench.py's workload = config #2)
 
-    Linear/Conv ~ N(0, gain^2/d_in); LayerNorm gamma = 1 + 0.1 N, beta = 0.02 N, eps = 1e-5;
-    encoder positions = sinusoid table; decoder positions ~ N(0, 0.5^2); token embedding
-    ~ N(0, logit_scale^2 / d) so the tied-embedding logits have std ~ logit_scale and greedy
-    / beam decisions are separated by far more than fp32 round-off ("peaky" fixtures).
-    Linear weights are stored [d_in, d_out] as the dump does (dump.py:141-145).
+# Recipe constants of the synthetic checkpoints (see synth_weights).
+RECIPE = dict(
+    bias_s=0.02, beta_s=0.02, logit_scale=6.0,
+    conv1_gain=8.0, conv2_gain=3.0, enc_pos_scale=1.0,
+    q_rand=0.7,                      # random (content) part of every query projection
+    enc_loc=0.1, self_loc=0.4, cross_loc=0.25,   # strength of the positional (structured) attention scores
+    frames_per_token=3.0,            # monotonic cross-attention: step p looks at encoder position ~3 p
+    enc_sa=1.0, enc_mlp=1.0, dec_pos=0.3, dec_sa=1.0, dec_ca=1.5, dec_mlp=1.0, layer0=0.3,
+    sin_amp=3.0,                     # amplitude of the decoder's positional sinusoids
+    succ_share=0.15, anti_self=1.0, e_noise=0.3,
+    eot_ramp=(1.0, 3.5), eot_beta=12.0,
+)
+
+
+def eot_id(n_vocab: int) -> int:
+    """<|endoftext|> of the standard vocabularies (tokens.py); synthetic vocabularies: V - 16."""
+    return 50256 if n_vocab == 51864 else 50257 if n_vocab == 51865 else n_vocab - 16
+
+
+def synth_weights(dims: dict, seed: int, logit_scale: float = 6.0, **overrides) -> "OrderedDict[str, np.ndarray]":
+    """Seeded synthetic checkpoint, keyed by dump-dir relative names (no '.npy'); Linear weights are
+    stored [d_in, d_out] as the dump does (dump.py:141-145).
+
+    A plain random init makes a useless fixture: every attention averages over its whole context, the
+    residual stream is dominated by context-independent offsets (GELU's positive mean, the constant part of
+    the sinusoid table, the stationary part of the log-mel spectrum), the tied embedding feeds the current
+    token straight back into its own logit, and greedy decoding falls into a fixed point after one or two
+    tokens -- parity tests on such weights check one decision per window.  The tensors below are still
+    seeded noise, but with the structure a trained checkpoint has, so that a decode is a long,
+    audio- and history-dependent token sequence whose decisions are separated by far more than fp32
+    round-off yet not amplified chaotically (mel round-off of 1e-6 moves the logits by < 1e-4):
+
+    * conv stem: zero-sum taps (the filters see temporal CHANGES of the log-mel, not its stationary
+      shape); encoder positions = the sinusoid table, centred over the positions;
+    * MLP second layers have zero column mean over the hidden units (GELU's uniform DC cancels);
+    * half of the heads of every attention are positional: q and k read sinusoid components so that
+      q_i . k_j = g sum_m cos(w_m (i - j')) -- encoder: local (a few frames), decoder self: recency (a few
+      tokens), decoder cross: monotonic alignment (step p attends encoder position ~3 p); the other heads
+      attend by content (random projections, diffuse), so every cached row matters to the output;
+    * token embedding with an orbit structure E[sigma(k+1)] = R E[sigma(k)] + noise (sigma a random
+      permutation of the ordinary tokens, R a random rotation), and a linear path through the first
+      decoder MLP (hidden pairs +z / -z: GELU(z) - GELU(-z) = z exactly) that adds c R x - x to the
+      residual stream: the successor of the current token gets a coherent logit bonus, the token itself
+      loses its own, and the argmax is a competition between that bigram prior, the audio seen through
+      cross-attention, the recent tokens seen through self-attention and the position;
+    * <|endoftext|> gains a logit that ramps up with the position, so windows end at different depths
+      (some before max_depth, some not).
     """
+    P = dict(RECIPE)
+    P["logit_scale"] = logit_scale
+    P.update(overrides)
     rng = np.random.Generator(np.random.PCG64(seed))
     d = dims["n_audio_state"]
+    V = dims["n_vocab"]
+    H = dims["n_audio_head"]
+    dh = d // H
+    half = d // 2
     w: "OrderedDict[str, np.ndarray]" = OrderedDict()
 
     def randn(*shape, scale=1.0):
@@ -64,72 +112,181 @@ def synth_weights(dims: dict, seed: int, logit_scale: float = 6.0) -> "OrderedDi
     def scalar(v):
         return np.array([v], dtype=np.float32)
 
-    # A plain 1/sqrt(d_in) random init degenerates: the residual stream is dominated by
-    # context-independent offsets (biases, LayerNorm beta, the positive mean of GELU), so one
-    # token wins whatever the audio or the history and every parity test would pass trivially.
-    # The gains below keep the fixture honest: small biases, sharp attention (query gain) with
-    # strong attention outputs so logits depend on WHICH encoder frames / past tokens are
-    # attended, a conv stem gain so the audio outweighs the positional table, and sizeable
-    # decoder positions so consecutive steps differ.
-    bias_s, beta_s = 0.02, 0.02
-    q_gain, self_out, cross_out, mlp_out, conv1_gain, dec_pos_s = 3.0, 3.0, 6.0, 1.0, 4.0, 0.5
-
-    def linear(p, d_in, d_out, bias=True, gain=1.0):
-        w[p + "/weight"] = randn(d_in, d_out, scale=gain / math.sqrt(d_in))
+    def linear(p, d_in, d_out, bias=True, gain=1.0, center_in=False):
+        W = randn(d_in, d_out, scale=gain / math.sqrt(d_in))
+        if center_in:
+            W -= W.mean(0, keepdims=True)
+        w[p + "/weight"] = W
         if bias:
-            w[p + "/bias"] = randn(d_out, scale=bias_s)
+            w[p + "/bias"] = randn(d_out, scale=P["bias_s"])
 
     def layer_norm(p, n):
         w[p + "/weight"] = 1.0 + randn(n, scale=0.1)
-        w[p + "/bias"] = randn(n, scale=beta_s)
+        w[p + "/bias"] = randn(n, scale=P["beta_s"])
         w[p + "/eps"] = scalar(1e-5)
 
-    def attention(p, n_head, out_gain):
+    n_slot = max(4, min(dh // 2, d // 16))      # sinusoid pairs a positional head reads
+
+    def attention(p, n_head, out_gain, q_pairs, k_pairs, loc, amp_q, amp_k):
+        """q_pairs / k_pairs: (sin_dim, cos_dim) of frequency slot m in the query / key INPUT.  amp_*: amplitude
+        of those sinusoids after the LayerNorm in front (table amplitude / rms of the residual stream)."""
         w[p + "/n_head"] = scalar(n_head)
-        linear(p + "/query", d, d, gain=q_gain)
+        linear(p + "/query", d, d, gain=P["q_rand"])
         linear(p + "/key", d, d, bias=False)        # mod.rs:402-404: key has no bias
         linear(p + "/value", d, d)
         linear(p + "/out", d, d, gain=out_gain)
+        Wq, Wk = w[p + "/query/weight"], w[p + "/key/weight"]
+        n = min(n_slot, len(q_pairs))
+        # q and k are each scaled by dh^-0.25 (mod.rs:503-514)
+        g = math.sqrt(loc * math.sqrt(dh) / (amp_q * amp_k))
+        for h in range(max(1, n_head // 2)):        # positional heads; the rest attend by content only
+            for m in range(n):
+                (qs, qc), (ks, kc) = q_pairs[m], k_pairs[m]
+                c0 = h * dh + 2 * m
+                Wq[qs, c0] += g
+                Wq[qc, c0 + 1] += g
+                Wk[ks, c0] += g
+                Wk[kc, c0 + 1] += g
 
-    def mlp(p):
+    def mlp(p, g):
         linear(p + "/mlp1", d, 4 * d)
-        linear(p + "/mlp2", 4 * d, d, gain=mlp_out)
+        linear(p + "/mlp2", 4 * d, d, gain=g, center_in=True)
 
+    # ---------------- encoder ----------------
     e = "encoder"
-    w[e + "/n_layer"] = scalar(dims["n_audio_layer"])
+    NLe = dims["n_audio_layer"]
+    w[e + "/n_layer"] = scalar(NLe)
     w[e + "/n_mels"] = scalar(dims["n_mels"])
     w[e + "/n_audio_state"] = scalar(d)
-    w[e + "/positional_embedding"] = sinusoids(dims["n_audio_ctx"], d)
-    w[e + "/conv1/weight"] = randn(d, dims["n_mels"], 3, scale=conv1_gain / math.sqrt(3 * dims["n_mels"]))
-    w[e + "/conv1/bias"] = randn(d, scale=bias_s)
-    w[e + "/conv2/weight"] = randn(d, d, 3, scale=1.0 / math.sqrt(3 * d))
-    w[e + "/conv2/bias"] = randn(d, scale=bias_s)
-    for i in range(dims["n_audio_layer"]):
+    pe = sinusoids(dims["n_audio_ctx"], d)
+    w[e + "/positional_embedding"] = ((pe - pe.mean(0, keepdims=True)) * np.float32(P["enc_pos_scale"])).astype(np.float32)
+    inv = np.exp(-math.log(10000.0) / (half - 1) * np.arange(half))
+    band = [i for i in range(half) if inv[i] >= 0.08]          # frequencies that resolve a few frames
+    band = band[:: max(1, len(band) // n_slot)][:n_slot]
+    enc_pairs = [(i, half + i) for i in band]
+    c1 = randn(d, dims["n_mels"], 3, scale=P["conv1_gain"] / math.sqrt(3 * dims["n_mels"]))
+    w[e + "/conv1/weight"] = c1 - c1.mean(2, keepdims=True)
+    w[e + "/conv1/bias"] = randn(d, scale=P["bias_s"])
+    c2 = randn(d, d, 3, scale=P["conv2_gain"] / math.sqrt(3 * d))
+    w[e + "/conv2/weight"] = c2 - c2.mean(2, keepdims=True)
+    w[e + "/conv2/bias"] = randn(d, scale=P["bias_s"])
+    var_layer = P["enc_sa"] ** 2 + 0.35 * P["enc_mlp"] ** 2     # what one encoder block adds to the stream
+    var0 = 0.42 + 0.5 * P["enc_pos_scale"] ** 2
+    for i in range(NLe):
         p = f"{e}/block_{i}"
-        attention(p + "/attn", dims["n_audio_head"], self_out)
+        amp = P["enc_pos_scale"] / math.sqrt(var0 + i * var_layer)
+        attention(p + "/attn", H, P["enc_sa"], enc_pairs, enc_pairs, P["enc_loc"], amp, amp)
         layer_norm(p + "/attn_ln", d)
-        mlp(p + "/mlp")
+        mlp(p + "/mlp", P["enc_mlp"])
         layer_norm(p + "/mlp_ln", d)
     layer_norm(e + "/ln_post", d)
+    amp_enc_out = P["enc_pos_scale"] / math.sqrt(var0 + NLe * var_layer)
 
+    # ---------------- decoder ----------------
     t = "decoder"
-    w[t + "/n_layer"] = scalar(dims["n_text_layer"])
-    w[t + "/token_embedding/weight"] = randn(dims["n_vocab"], d, scale=logit_scale / math.sqrt(d))
-    w[t + "/positional_embedding"] = randn(dims["n_text_ctx"], d, scale=dec_pos_s)
-    for i in range(dims["n_text_layer"]):
+    NL = dims["n_text_layer"]
+    n_ctx = dims["n_text_ctx"]
+    w[t + "/n_layer"] = scalar(NL)
+    # dims [0, 2 n_slot): recency sinusoids; [2 n_slot, 2 n_slot + 2 len(band)): alignment sinusoids; the token
+    # embedding, the rotation R and the EOT direction live in the remaining dims
+    sa_pairs = [(2 * m, 2 * m + 1) for m in range(n_slot)]
+    ca_pairs = [(2 * n_slot + 2 * m, 2 * n_slot + 2 * m + 1) for m in range(len(band))]
+    n_sin = 2 * n_slot + 2 * len(band)
+    de = d - n_sin                                   # embedding dims
+    de -= de % 2
+    eo = d - de                                      # first embedding dim
+    eot = eot_id(V)
+    n_ord = eot                                      # ordinary tokens: ids below <|endoftext|>
+    Q, _ = np.linalg.qr(rng.standard_normal((de, de)))
+    theta = rng.uniform(0.2, 2 * math.pi - 0.2, de // 2)
+    phi = rng.uniform(0, 2 * math.pi, de // 2)
+    r = np.abs(rng.standard_normal(de // 2)) + 0.5
+    r *= P["logit_scale"] / math.sqrt((r ** 2).sum())
+    sigma = rng.permutation(n_ord)
+    ang = np.arange(n_ord, dtype=np.float64)[:, None] * theta[None, :] + phi[None, :]
+    Z = np.empty((n_ord, de))
+    Z[:, 0::2] = r * np.cos(ang)
+    Z[:, 1::2] = r * np.sin(ang)
+    E = np.zeros((V, d), dtype=np.float32)
+    E[sigma, eo:] = (Z @ Q.T).astype(np.float32)
+    E[n_ord:, eo:] = randn(V - n_ord, de, scale=P["logit_scale"] / math.sqrt(de))
+    E[:, eo:] += randn(V, de, scale=P["e_noise"] * P["logit_scale"] / math.sqrt(de))
+    B = np.zeros((de, de))
+    c, s = np.cos(theta), np.sin(theta)
+    idx = np.arange(0, de, 2)
+    B[idx, idx] = c
+    B[idx + 1, idx + 1] = c
+    B[idx, idx + 1] = s
+    B[idx + 1, idx] = -s
+    R = (Q @ B @ Q.T).astype(np.float32)             # row-vector convention: E[sigma(k)] @ R = E[sigma(k+1)]
+    pos = np.zeros((n_ctx, d), dtype=np.float32)
+    pos[:, eo:] = randn(n_ctx, de, scale=P["dec_pos"])
+    pp = np.arange(n_ctx, dtype=np.float64)
+    sa_w = np.exp(np.linspace(math.log(0.05), math.log(0.6), n_slot))     # recency kernel a few tokens wide
+    for m, (a, b) in enumerate(sa_pairs):
+        pos[:, a] = P["sin_amp"] * np.sin(pp * sa_w[m])
+        pos[:, b] = P["sin_amp"] * np.cos(pp * sa_w[m])
+    for m, (a, b) in enumerate(ca_pairs):
+        wm = inv[band[m]] * P["frames_per_token"]
+        pos[:, a] = P["sin_amp"] * np.sin(pp * wm)
+        pos[:, b] = P["sin_amp"] * np.cos(pp * wm)
+    # analytic variance of the residual stream in front of every sublayer (zero-mean independent contributions)
+    var_e = (P["logit_scale"] ** 2 * (1 + P["e_noise"] ** 2) + de * P["dec_pos"] ** 2) / d     # embedding dims
+    var_s = n_sin * 0.5 * P["sin_amp"] ** 2 / d                                              # sinusoid dims
+    l0 = P["layer0"]
+    var_l0 = l0 ** 2 * (P["dec_sa"] ** 2 + P["dec_ca"] ** 2)
+    var_fin = (var_e + var_s + var_l0 + (NL - 1) * (P["dec_sa"] ** 2 + P["dec_ca"] ** 2 + 0.35 * P["dec_mlp"] ** 2))
+    c_succ = P["succ_share"] * math.sqrt(var_fin * d) / P["logit_scale"]
+    var_mlp0 = (c_succ ** 2 + P["anti_self"] ** 2) * (var_e + var_l0 * de / d) + 0.5 * 0.35 * P["dec_mlp"] ** 2
+    var_fin += var_mlp0
+    c_succ = P["succ_share"] * math.sqrt(var_fin * d) / P["logit_scale"]
+    u = np.zeros(d, dtype=np.float32)
+    u[eo:] = randn(de)
+    u /= np.linalg.norm(u)
+    if P["eot_beta"]:
+        r0, r1 = P["eot_ramp"]
+        # the best ordinary logit sits near logit_scale * sqrt(2 ln V): smaller vocabularies need a lower ramp
+        # (factor 2: the small test models also have fewer layers, hence flatter logits)
+        r0 -= 2.0 * (math.sqrt(2 * math.log(51864.0)) - math.sqrt(2 * math.log(V))) * P["logit_scale"] / P["eot_beta"]
+        pos += ((r0 + r1 * (pp - 4) / 100.0) * math.sqrt(var_fin))[:, None].astype(np.float32) * u[None, :]
+        E[eot] += np.float32(P["eot_beta"]) * u
+    w[t + "/token_embedding/weight"] = E
+    w[t + "/positional_embedding"] = pos
+    var = var_e + var_s
+    for i in range(NL):
         p = f"{t}/block_{i}"
-        attention(p + "/attn", dims["n_text_head"], self_out)
+        sc = l0 if i == 0 else 1.0
+        amp = P["sin_amp"] / math.sqrt(var)
+        attention(p + "/attn", H, P["dec_sa"] * sc, sa_pairs, sa_pairs, P["self_loc"], amp, amp)
         layer_norm(p + "/attn_ln", d)
-        attention(p + "/cross_attn", dims["n_text_head"], cross_out)
+        var += (P["dec_sa"] * sc) ** 2
+        attention(p + "/cross_attn", H, P["dec_ca"] * sc, ca_pairs, enc_pairs, P["cross_loc"],
+                  P["sin_amp"] / math.sqrt(var), amp_enc_out)
         layer_norm(p + "/cross_attn_ln", d)
-        mlp(p + "/mlp")
+        var += (P["dec_ca"] * sc) ** 2
+        mlp(p + "/mlp", P["dec_mlp"])
         layer_norm(p + "/mlp_ln", d)
+        if i == 0 and P["succ_share"] > 0:
+            # successor path: hidden units [0, de) compute +z, [de, 2 de) compute -z of the embedding dims of
+            # LN(x); their second-layer rows are +M / -M, so the pair contributes z M exactly
+            M = (c_succ * R - np.float32(P["anti_self"]) * np.eye(de, dtype=np.float32)) * np.float32(math.sqrt(var))
+            W1, b1, W2 = w[p + "/mlp/mlp1/weight"], w[p + "/mlp/mlp1/bias"], w[p + "/mlp/mlp2/weight"]
+            W1[:, 0:2 * de] = 0
+            W1[eo + np.arange(de), np.arange(de)] = 1.0
+            W1[eo + np.arange(de), de + np.arange(de)] = -1.0
+            b1[0:2 * de] = 0
+            W2[0:2 * de] = 0
+            W2[0:de, eo:] = M
+            W2[de:2 * de, eo:] = -M
+            var += var_mlp0
+        else:
+            var += 0.35 * P["dec_mlp"] ** 2
     layer_norm(t + "/ln", d)
     return w
 
 
-def synth_preset(name: str, logit_scale: float = 6.0):
-    return synth_weights(preset_dims(name), preset_seed(name), logit_scale)
+def synth_preset(name: str, logit_scale: float = 6.0, **overrides):
+    return synth_weights(preset_dims(name), preset_seed(name), logit_scale, **overrides)
 
 
 def micro_dims(n_state=128, n_head=2, n_layer=2, n_vocab=1031, n_audio_ctx=1500, n_text_ctx=448) -> dict:
