@@ -52,8 +52,8 @@ def e2e_roofline_ms(dims, lens, n_steps, dtype):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (default: a timed region of ~5 s)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--model", default="tiny.en")
     ap.add_argument("--seconds", type=float, default=30.0, help="audio seconds per GPU per step")
     ap.add_argument("--beam", type=int, default=1)
@@ -63,15 +63,25 @@ def main() -> None:
                     help="f32 = exact-f32 MFMA parity path (the judged configuration); bf16 = speed path")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU over RCCL, same flags
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                                   f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+                                   "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus}` "
-                         f"(WORLD_SIZE={world})")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -93,7 +103,7 @@ def main() -> None:
 
     sr = 16000
     n_total = int(round(args.seconds * sr)) * world
-    audio = synth.synth_audio(n_total, 1234 + 2)                       # seed 1234 + config#
+    audio = synth.synth_audio(n_total, synth.BENCH_AUDIO_SEED)         # seed 1234 + config#
     pcm_dev = torch.from_numpy(audio).to(dev)                           # resident in HBM before the timed region
     wlen = wb.max_waveform_samples(eng.encoder_ctx_size() - params.padding)
     starts, lens = wb.window_extents(n_total, sr, wlen, params.overlap_seconds)
@@ -128,45 +138,55 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # ---- roofline of the dominant kernel (HIP events on the engine's stream, profiled pass) ----
+    # ---- per-kernel roofline (profiled passes: every decode-step launch carries its own start / stop HIP events on
+    # the engine's stream = the dispatch's begin -> end, the quantity `rocprofv3 --kernel-trace` reports) ----
     roofline = None
+    kernels = None
     stages = None
     if rank == 0:
         lib.wb_profile_enable(1)
         buf = (np.zeros(8, dtype=np.float64))
         lib.wb_profile_read(buf.ctypes.data_as(_lib.c_double_p), 1)
+        _lib.profile_kernels(reset=True)
         n_prof = 3
         for _ in range(n_prof):
             decode_local(*shard.partition_windows(n_win, rank, world))
         lib.wb_profile_read(buf.ctypes.data_as(_lib.c_double_p), 1)
+        kstats = _lib.profile_kernels(reset=True)
         lib.wb_profile_enable(0)
         mel_ms, enc_ms, ckv_ms, dec_ms, n_steps, n_mel, logit_ms, n_logit = [float(x) for x in buf]
-        d = eng.dims["n_text_state"]
-        lo, hi = shard.partition_windows(n_win, rank, world)
-        n_rows = (hi - lo) * args.beam
-        # logits GEMV: streams E^T [d][V] once, reads n rows of d, writes n rows of V (f32)
-        algo_bytes = (2.0 if args.dtype == "bf16" else 4.0) * V * d + 4.0 * (n_rows * d + n_rows * V)
-        # measured HBM bytes per launch of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
-        # same command, corrected per MI355X_MICROARCH.md (profiles/summarize_pmc.py); only valid for the
-        # workload the counters were collected on
-        traffic = None
-        pmc_json = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic_tiny_en_30s.json")
-        if args.model in ("tiny.en", "tiny_en") and n_rows == 3 and args.dtype == "f32" and os.path.exists(pmc_json):
-            for kname, nbytes in json.load(open(pmc_json)).items():
-                if "dec_gemv_kernel" in kname and "true, true" in kname:
-                    traffic = int(nbytes)
-        if n_logit > 0 and logit_ms > 0:
-            avg_s = logit_ms / n_logit * 1e-3
-            ach = algo_bytes / avg_s / 1e9
-            roofline = {"kernel": "dec_gemv_kernel<.., LN, STATS> (tied-embedding logits over E^T [d][V] f32 "
-                                  "+ per-tile log-softmax/top-k statistics)", "bound": "hbm",
-                        "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                        "algorithmic_bytes_per_launch": int(algo_bytes),
-                        "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": int(n_logit)}
+        # measured HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command,
+        # corrected per MI355X_MICROARCH.md (profiles/summarize_pmc.py), keyed by kernel class; only used when the
+        # file was collected on this workload (it records the command line)
+        pmc = {}
+        pmc_json = os.path.join(ROOT, "profiles", "r02_pmc_traffic_tiny_en_30s.json")
+        if args.model in ("tiny.en", "tiny_en") and args.dtype == "f32" and args.beam == 1 and args.seconds == 30.0 \
+                and os.path.exists(pmc_json):
+            pmc = json.load(open(pmc_json))
+        tot_ms = sum(k["total_ms"] for k in kstats) or 1.0
+        kernels = []
+        for k in sorted(kstats, key=lambda k: -k["total_ms"]):
+            avg_s = k["total_ms"] / k["calls"] * 1e-3
+            per_launch = k["algo_bytes"] / k["calls"]
+            ach = per_launch / avg_s / 1e9
+            kernels.append({"kernel": k["name"], "share_of_decode_kernel_time": round(k["total_ms"] / tot_ms, 4),
+                            "launches_timed": k["calls"], "avg_launch_us": round(avg_s * 1e6, 2),
+                            "algorithmic_bytes_per_launch": int(per_launch), "achieved_GBps": round(ach, 1),
+                            "frac_of_hbm_peak": round(ach / HBM_PEAK_GBS, 4),
+                            "traffic": pmc.get(k["name"].split(" ")[0])})
+        if kernels:
+            k0 = kernels[0]                                   # the dominant kernel by total time
+            roofline = {"kernel": k0["kernel"], "bound": "hbm", "achieved": k0["achieved_GBps"], "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": k0["frac_of_hbm_peak"], "traffic": k0["traffic"],
+                        "traffic_source": os.path.relpath(pmc_json, ROOT) if k0["traffic"] is not None else None,
+                        "algorithmic_bytes_per_launch": k0["algorithmic_bytes_per_launch"],
+                        "avg_launch_us": k0["avg_launch_us"], "launches_timed": k0["launches_timed"],
+                        "share_of_decode_kernel_time": k0["share_of_decode_kernel_time"],
+                        "note": "dominant decode-step kernel by total duration; `kernels` lists every class"}
         stages = {"mel_ms_per_step": round(mel_ms / n_prof, 4), "encoder_ms_per_step": round(enc_ms / n_prof, 4),
                   "cross_kv_ms_per_step": round(ckv_ms / n_prof, 4), "decode_ms_per_step": round(dec_ms / n_prof, 4),
                   "decode_steps_per_step": n_steps / n_prof,
+                  "decode_kernels_per_token": round(sum(k["calls"] for k in kstats) / max(n_steps, 1), 2),
                   "mel_frames_per_s": round(n_frames_local / (mel_ms / n_prof * 1e-3), 1) if mel_ms > 0 else None,
                   "mel_GBps_algorithmic": round(960.0 * n_frames_local / (mel_ms / n_prof * 1e-3) / 1e9, 2) if mel_ms > 0 else None}
 
@@ -203,12 +223,11 @@ def main() -> None:
         ow = OracleWhisper(weights)
         ost = otr.SpecialTokens(st.start_of_transcript, st.language, st.transcribe, st.no_timestamps,
                                 st.end_of_text, st.is_special.astype(bool))
-        n_cpu = min(n_total, int(wlen))                                  # one reference window
-        depth_cpu = min(args.max_depth, 100 if args.model.startswith("tiny") else 8)
+        n_cpu = min(n_total, int(wlen))                                  # bounded sample: ONE reference window,
+        depth_cpu = args.max_depth                                       # same decode settings as the GPU run
         tc = time.perf_counter()
         otr.waveform_to_tokens(ow, ost, audio[:n_cpu], sr, args.beam, depth_cpu)
         cpu_dt = time.perf_counter() - tc
-        # scale decode-bound time to max_depth when the sample was truncated in depth
         cpu_rtf = (n_cpu / sr) / cpu_dt
         cpu_baseline = {"value": round(cpu_rtf, 3), "unit": "x real-time", "cores": torch.get_num_threads(),
                         "kind": "port",
@@ -237,7 +256,7 @@ def main() -> None:
                "roofline_ms_per_step": {k: round(v, 4) for k, v in rl.items()},
                "note": "per-GPU roofline of the same step: algorithmic bytes over 8 TB/s (mel, decode) and FLOPs over "
                        "the dense MFMA peak of the path's dtype (encoder, cross-K/V); decode is launch-latency-bound "
-                       "at this size (30 dependent launches per token)"}
+                       "at this size (stages.decode_kernels_per_token dependent launches per token)"}
         out = {
             "metric": "real-time factor (audio-sec/wall-sec)",
             "value": round(audio_s / dt, 2),
@@ -255,10 +274,11 @@ def main() -> None:
                                    f"windowing ({n_win} windows <= 14.9 s, 3 s overlap), HIP mel + encoder + "
                                    f"KV-cached decode, {'greedy (beam_size 1)' if args.beam == 1 else 'beam ' + str(args.beam)}, "
                                    f"max_depth {args.max_depth}",
-                       "model": args.model, "windows": n_win, "beam_size": args.beam, "max_depth": args.max_depth,
+                       "windows": n_win, "beam_size": args.beam, "max_depth": args.max_depth,
                        "tokens_out": len(tokens) if tokens is not None else 0,
                        "parallelism": f"windows sharded over {world} GPU(s), 1 token all-gather"},
             "roofline": roofline,
+            "kernels": kernels,
             "cpu_baseline": cpu_baseline,
             "e2e_roofline": e2e,
             "mel_frontend": mel_frontend,

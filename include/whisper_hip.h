@@ -244,6 +244,18 @@ int wb_stitch_windows(const int32_t* win_tokens, int32_t row_stride, const int32
 int wb_profile_enable(int on);
 int wb_profile_read(double* out8, int reset);
 
+/* Per-kernel statistics of the decode-step launches made while profiling was on: every launch carries its own
+ * start / stop HIP events (the dispatch's begin -> end, what `rocprofv3 --kernel-trace` reports) and the
+ * algorithmic bytes it streams (weights + cached K/V).  Fills at most `cap` entries, returns the number of
+ * kernel classes that ran (may exceed cap).  New: the reference has no profiling hooks. */
+typedef struct wb_kernel_stat {
+  char name[96];
+  int64_t calls;
+  double total_ms;      /* sum of the launches' own durations */
+  double algo_bytes;    /* sum of their algorithmic bytes     */
+} wb_kernel_stat;
+int wb_profile_kernels(wb_kernel_stat* out, int cap, int reset);
+
 const char* wb_last_error(void);
 const char* wb_version(void);
 

@@ -1,0 +1,76 @@
+"""The tokenizer side of the boundary (src/token.rs): ids by name and the special-token mask derived exactly
+as the reference derives them, from a `tokenizer.json` -- a SYNTHETIC one (no Whisper tokenizer.json exists
+offline) with the real special-token names, written with the same HuggingFace `tokenizers` crate the
+reference wraps.  CPU: the derivation; GPU: the derived table drives the engine."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from whisper_burn_amd import synth
+from whisper_burn_amd.tokens import SpecialTokens, TokenizerAdapter, special_token_name
+
+tokenizers = pytest.importorskip("tokenizers")
+
+N_VOCAB = 1031            # the test models' vocabulary: ids >= 1015 are special (tokens.py layout)
+
+
+def write_synthetic_tokenizer_json(path):
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    eot = N_VOCAB - 16
+    vocab = {f"w{i}": i for i in range(eot)}
+    vocab["<unk>"] = vocab.pop(f"w{eot - 1}")                                 # keep ids dense: the last word slot is <unk>
+    tok = Tokenizer(models.WordLevel(vocab=vocab, unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.Whitespace()
+    # ids eot .. eot + 15 in the layout of tokens.py: eot, sot, language(s), transcribe, notimestamps, timestamps
+    names = ["<|endoftext|>", "<|startoftranscript|>", "<|en|>", "<|zh|>", "<|transcribe|>", "<|translate|>",
+             "<|notimestamps|>"] + [f"<|{0.02 * i:.2f}|>" for i in range(9)]
+    assert tok.add_special_tokens(names) == 16
+    tok.save(path)
+    return names
+
+
+def test_special_tokens_are_derived_like_the_reference(tmp_path):
+    path = str(tmp_path / "tokenizer.json")
+    names = write_synthetic_tokenizer_json(path)
+    assert json.load(open(path))["model"]["type"] == "WordLevel"
+    bpe = TokenizerAdapter.from_file(path)
+    assert bpe.vocab_size() == N_VOCAB
+    st = bpe.special_tokens("en")
+    ref = SpecialTokens.for_vocab(N_VOCAB)
+    assert (st.start_of_transcript, st.language, st.transcribe, st.no_timestamps, st.end_of_text) == \
+        (ref.start_of_transcript, ref.language, ref.transcribe, ref.no_timestamps, ref.end_of_text)
+    assert bpe.special_token(special_token_name("language", "zh")) == ref.language + 1
+    # token.rs:37-43: special <=> decode([id], skip_special = true) is empty
+    assert np.array_equal(st.is_special, ref.is_special)
+    assert st.is_special.sum() == 16 and not st.is_special[:N_VOCAB - 16].any()
+    assert bpe.decode([3, ref.end_of_text, 5], skip_special=True) == "w3 w5"           # transcribe.rs:67
+    assert names[0] in bpe.decode([3, ref.end_of_text], skip_special=False)
+    with pytest.raises(KeyError):
+        bpe.special_tokens("xx")
+
+
+@pytest.mark.gpu
+def test_tokenizer_table_drives_the_engine(tmp_path):
+    import whisper_burn_amd as wb
+    path = str(tmp_path / "tokenizer.json")
+    write_synthetic_tokenizer_json(path)
+    bpe = TokenizerAdapter.from_file(path)
+    dims = synth.micro_dims(n_state=128, n_head=2, n_layer=2, n_vocab=N_VOCAB)
+    eng = wb.Whisper.from_tensors(synth.synth_weights(dims, seed=4242))
+    audio = synth.synth_audio(16000 * 20, 51)
+    ref_tokens, _ = wb.waveform_to_tokens(eng, wb.SpecialTokens.for_vocab(N_VOCAB), audio, 16000, 5, 24)
+
+    class Bpe:                                     # what waveform_to_text (transcribe.rs:23-29) needs from its `bpe`
+        def special_tokens(self, lang):
+            return bpe.special_tokens(lang)
+
+        def decode(self, tokens, skip_special):
+            return bpe.decode(tokens, skip_special)
+
+    text, tokens = wb.waveform_to_text(eng, Bpe(), "en", audio, 16000)
+    ref_tokens100, _ = wb.waveform_to_tokens(eng, wb.SpecialTokens.for_vocab(N_VOCAB), audio, 16000, 5, 100)
+    assert tokens == ref_tokens100
+    assert text == bpe.decode(tokens, True) and "<|" not in text and len(text.split()) >= 2
+    assert ref_tokens[:4] == tokens[:4]

@@ -1,6 +1,7 @@
 // Launchers of the KV-cached decode-step kernels (decode.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include <algorithm>
@@ -83,8 +84,24 @@ void launch_dec_cross_attn(hipStream_t st, const int* state, const StepLayout& l
                            int n_chunks, const float* Pq, int KS, const float* bq, int d, const float* ckv, int ldkv,
                            int koff, const int* win_row0, const int* win_C, float scale, float* ca, int max_nb,
                            const CaFuse* fuse = nullptr);
-// profiling: attach start / stop events to the NEXT launch_dec_gemv of this thread (kernel begin -> end)
-void set_launch_events(hipEvent_t start, hipEvent_t stop);
+// ---- per-kernel profiling (wb_profile_enable): the call site tags the NEXT launch of this thread with a kernel
+// class and its algorithmic bytes; the launcher hands the tag's start / stop events to the dispatch itself
+// (hipExtLaunchKernelGGL), so the elapsed time is that kernel's own begin -> end -- the quantity
+// `rocprofv3 --kernel-trace` reports.  With profiling off a tag costs one predictable branch.
+enum KernelClass {
+  KC_PREPARE = 0, KC_ATTN_FUSED, KC_CROSS_ATTN, KC_GEMV_COUT, KC_MLP_FUSED, KC_LOGITS, KC_TOPK_MERGE,
+  KC_GEMV_LN_QKV, KC_SELF_ATTN, KC_GEMV_OUT, KC_GEMV_LN_CQ, KC_GEMV_LN_MLP1, KC_GEMV_MLP2, KC_BATCH, KC_COUNT
+};
+void prof_tag(int cls, double algo_bytes);
+bool prof_take_events(hipEvent_t* start, hipEvent_t* stop);
+#define WB_KLAUNCH(kernel, grid, block, shmem, stream, ...)                                        \
+  do {                                                                                             \
+    hipEvent_t _pa, _pb;                                                                           \
+    if (wb::prof_take_events(&_pa, &_pb))                                                          \
+      hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, _pa, _pb, 0, __VA_ARGS__);         \
+    else                                                                                           \
+      hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                         \
+  } while (0)
 // what the merge kernel needs to prepare the NEXT chained step (x == nullptr: it does not)
 struct NextPrep {
   float* x = nullptr;        // residual-stream rows [S][d] the next step starts from
@@ -105,5 +122,30 @@ void launch_dec_topk_rows(hipStream_t st, const int* state, int n_max, const flo
                           int* gctl, int* gtok, int Lmax, int eot);
 void launch_dec_logprob_row(hipStream_t st, const float* x, int KS, int64_t plane, int V, const float* mask,
                             int use_mask, const float* stats, float* out);
+
+// ---- fused small-batch sublayer kernels (decode_fused.hip) ----------------------------------------------
+// Common prologue of both: x = x_in + (pbias + sum_s pend[s]) (KSp planes of [S][d]; KSp = 0: none), block 0
+// writes x to x_out, then LayerNorm(ln_g, ln_b, ln_eps).
+struct MlpFusedArgs {
+  const int* st = nullptr; int S = 0, d = 0;
+  const float* x_in = nullptr; const float* pend = nullptr; int KSp = 0; const float* pbias = nullptr; float* x_out = nullptr;
+  const float* ln_g = nullptr; const float* ln_b = nullptr; float ln_eps = 0.f; int ln_inside = 0;
+  const float* W1 = nullptr; int ld1 = 0; const float* b1 = nullptr;     // [d][4d], [4d]
+  const float* W2 = nullptr;                                             // [4d][d]
+  float* P = nullptr;                                                    // out: planes [4d / 64][S][d] (lin2 bias NOT added)
+};
+struct AttnFusedArgs {
+  const int* st = nullptr; StepLayout lay; int S = 0, d = 0, n_head = 0;
+  const float* x_in = nullptr; const float* pend = nullptr; int KSp = 0; const float* pbias = nullptr; float* x_out = nullptr;
+  const float* ln_g = nullptr; const float* ln_b = nullptr; float ln_eps = 0.f; int ln_inside = 0;
+  const float* Wqkv = nullptr; int ldqkv = 0; const float* bqkv = nullptr; float scale = 0.f;   // [d][3d], [3d]
+  float* Kc = nullptr; float* Vc = nullptr; const int* tabs = nullptr; int Lmax = 0;            // this layer's cache
+  const float* Wo = nullptr;                                                                    // [d][d]
+  float* P = nullptr;                                                    // out: planes [n_head][S][d] (out bias NOT added)
+};
+bool dec_fused_supported(int d);
+int dec_mlp_fused_planes(int d);
+void launch_dec_mlp_fused(hipStream_t st, const MlpFusedArgs& a, int n_rows_hint);
+void launch_dec_attn_fused(hipStream_t st, const AttnFusedArgs& a, int n_rows_hint);
 
 }  // namespace wb

@@ -884,7 +884,7 @@ __global__ void dec_logprob_row_kernel(const float* __restrict__ x, int KS, int6
 
 void launch_dec_prepare(hipStream_t st, const int* state_host_mapped, int* state_dev, const StepLayout& lay, int n,
                         int* tabs, int Lmax, const float* E, const float* pos, int d, float* x, const int* gctl) {
-  hipLaunchKernelGGL(dec_prepare_kernel, dim3(n), dim3(128), 0, st, state_host_mapped, state_dev, lay, tabs, Lmax, E, pos,
+  WB_KLAUNCH(dec_prepare_kernel, dim3(n), dim3(128), 0, st, state_host_mapped, state_dev, lay, tabs, Lmax, E, pos,
                      d, x, gctl);
 }
 
@@ -892,10 +892,10 @@ void launch_dec_resolve_ln(hipStream_t st, const int* state, int n_max, const fl
                            const float* P, int KS, int S, const float* bias, int d, const LayerNormW& ln,
                            int eps_inside_sqrt, float* h) {
   if (d <= 1024)
-    hipLaunchKernelGGL(dec_resolve_ln_kernel<4>, dim3(n_max), dim3(256), 0, st, state, x_in, x_out, P, KS, S, bias, d,
+    WB_KLAUNCH(dec_resolve_ln_kernel<4>, dim3(n_max), dim3(256), 0, st, state, x_in, x_out, P, KS, S, bias, d,
                        ln.g, ln.b, ln.eps, eps_inside_sqrt, h);
   else
-    hipLaunchKernelGGL(dec_resolve_ln_kernel<8>, dim3(n_max), dim3(256), 0, st, state, x_in, x_out, P, KS, S, bias, d,
+    WB_KLAUNCH(dec_resolve_ln_kernel<8>, dim3(n_max), dim3(256), 0, st, state, x_in, x_out, P, KS, S, bias, d,
                        ln.g, ln.b, ln.eps, eps_inside_sqrt, h);
 }
 
@@ -910,17 +910,9 @@ void gemv_plan(int K, int N, int* KS, int* KSL) {
   *KS = ks; *KSL = ksl;
 }
 
-static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
-void set_launch_events(hipEvent_t start, hipEvent_t stop) { g_ev_start = start; g_ev_stop = stop; }
-
 template <typename K>
 static void launch_gemv_k(K kernel, hipStream_t st, dim3 grid, const GemvArgs& a) {
-  if (g_ev_start) {   // profiled launch: events on the dispatch itself
-    hipExtLaunchKernelGGL(kernel, grid, dim3(256), 0, st, g_ev_start, g_ev_stop, 0, a);
-    g_ev_start = g_ev_stop = nullptr;
-  } else {
-    hipLaunchKernelGGL(kernel, grid, dim3(256), 0, st, a);
-  }
+  WB_KLAUNCH(kernel, grid, dim3(256), 0, st, a);
 }
 
 struct GemmvDummy;
@@ -959,7 +951,7 @@ void launch_dec_gemv(hipStream_t st, const GemvArgs& a, int n_rows_hint, bool st
 void launch_dec_self_attn(hipStream_t st, const int* state, const StepLayout& lay, int n_max, int n_head,
                           const float* Pqkv, int KS, const float* bqkv, int d, float* Kc, float* Vc, const int* tab,
                           int Lmax, float scale, float* att) {
-  hipLaunchKernelGGL(dec_self_attn_kernel, dim3(n_max, n_head), dim3(256), 0, st, state, lay, Pqkv, KS, bqkv, d, Kc, Vc,
+  WB_KLAUNCH(dec_self_attn_kernel, dim3(n_max, n_head), dim3(256), 0, st, state, lay, Pqkv, KS, bqkv, d, Kc, Vc,
                      tab, Lmax, scale, att);
 }
 
@@ -972,7 +964,7 @@ void launch_dec_cross_attn(hipStream_t st, const int* state, const StepLayout& l
   dim3 grid(n_chunks, n_head, n_windows);
   const CaFuse fz = fuse ? *fuse : CaFuse();
 #define WB_CA(NB_, KQ_)                                                                                              \
-  hipLaunchKernelGGL((dec_cross_attn_kernel<NB_, KQ_>), grid, dim3(256), 0, st, state, lay, Pq, KS, bq, d, ckv, ldkv, \
+  WB_KLAUNCH((dec_cross_attn_kernel<NB_, KQ_>), grid, dim3(256), 0, st, state, lay, Pq, KS, bq, d, ckv, ldkv, \
                      koff, win_row0, win_C, scale, n_head, n_chunks, ca, fz)
 #define WB_CA_NB(KQ_)                  \
   if (max_nb <= 1) WB_CA(1, KQ_);      \
@@ -990,29 +982,29 @@ void launch_dec_cross_attn(hipStream_t st, const int* state, const StepLayout& l
 void launch_dec_topk_merge(hipStream_t st, int* state, int n_max, const float* tstats, int n_tiles, int k,
                            int32_t* out_id, float* out_lp, float* row_stats, const StepLayout& lay, int* gctl, int* gtok,
                            int Lmax, int eot, const NextPrep& nx) {
-  hipLaunchKernelGGL(dec_topk_merge_kernel, dim3(n_max), dim3(256), 0, st, state, tstats, n_tiles, k, out_id, out_lp,
+  WB_KLAUNCH(dec_topk_merge_kernel, dim3(n_max), dim3(256), 0, st, state, tstats, n_tiles, k, out_id, out_lp,
                      row_stats, lay, gctl, gtok, Lmax, eot, nx);
 }
 
 void launch_dec_logprob_row(hipStream_t st, const float* x, int KS, int64_t plane, int V, const float* mask,
                             int use_mask, const float* stats, float* out) {
-  hipLaunchKernelGGL(dec_logprob_row_kernel, dim3((V + 255) / 256), dim3(256), 0, st, x, KS, plane, V, mask, use_mask,
+  WB_KLAUNCH(dec_logprob_row_kernel, dim3((V + 255) / 256), dim3(256), 0, st, x, KS, plane, V, mask, use_mask,
                      stats, out);
 }
 
 void launch_dec_gelu_fold(hipStream_t st, const int* state, int n_max, const float* P, int KS, int S, int K,
                           const float* bias, float* out) {
-  hipLaunchKernelGGL(dec_gelu_fold_kernel, dim3((K + 255) / 256, n_max), dim3(256), 0, st, state, P, KS, S, K, bias, out);
+  WB_KLAUNCH(dec_gelu_fold_kernel, dim3((K + 255) / 256, n_max), dim3(256), 0, st, state, P, KS, S, K, bias, out);
 }
 void launch_dec_attn_combine(hipStream_t st, const int* state, int n_max, const float* ca, int n_head, int n_chunks,
                              float* out) {
-  hipLaunchKernelGGL(dec_attn_combine_kernel, dim3((n_head * 64 + 255) / 256, n_max), dim3(256), 0, st, state, ca, n_head,
+  WB_KLAUNCH(dec_attn_combine_kernel, dim3((n_head * 64 + 255) / 256, n_max), dim3(256), 0, st, state, ca, n_head,
                      n_chunks, out);
 }
 void launch_dec_topk_rows(hipStream_t st, const int* state, int n_max, const float* logits, int V, const float* mask,
                           int use_mask, int k, int32_t* out_id, float* out_lp, float* row_stats, const StepLayout& lay,
                           int* gctl, int* gtok, int Lmax, int eot) {
-  hipLaunchKernelGGL(dec_topk_rows_kernel, dim3(n_max), dim3(1024), 0, st, state, logits, V, mask, use_mask, k, out_id,
+  WB_KLAUNCH(dec_topk_rows_kernel, dim3(n_max), dim3(1024), 0, st, state, logits, V, mask, use_mask, k, out_id,
                      out_lp, row_stats, lay, gctl, gtok, Lmax, eot);
 }
 

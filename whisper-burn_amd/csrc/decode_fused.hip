@@ -1,0 +1,498 @@
+// Fused small-batch decode-step kernels: one launch per sublayer instead of one per matrix.
+//
+// With a handful of live beams a decode step is bound by its chain of DEPENDENT launches, not by bytes
+// (tiny.en: 30 launches of 4-6 us around 17 us of streaming).  Two producer-aligned fusions remove kernel
+// boundaries without any grid-wide synchronisation, because the block that OWNS a slice of an intermediate
+// can apply the next matrix to it on its own and leave a partial plane that the consumer's prologue already
+// knows how to fold (fixed order, no atomics -> bit-reproducible):
+//
+//   dec_mlp_fused_kernel    block j owns hidden units [64 j, 64 j + 64):  LN(x + pending) -> W1[:, slice]
+//                           -> + b1 -> GELU -> W2[slice, :]  -> plane j of [4 d / 64][S][d]   (mod.rs:376-382)
+//   dec_attn_fused_kernel   block h owns head h:  LN(x + pending) -> Wqkv[:, head h] -> cache append -> masked
+//                           self-attention over the paged cache -> Wo[head h rows, :] -> plane h of [H][S][d]
+//                                                                            (mod.rs:428-436, :493-533)
+//
+// Every block redoes the row prologue (fold + LayerNorm: a few KB from L2); each weight is still read once.
+#include <hip/hip_runtime.h>
+
+#include "decode.h"
+#include "wave_ops.h"
+
+namespace wb {
+namespace {
+
+constexpr int FD_MAX = 512;      // largest n_state of the fused path (test models 128, tiny.en 384, base.en 512)
+constexpr int FA_MAXPOS = 448;   // n_text_ctx
+
+__device__ __forceinline__ float gelu_erf_f(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+// One wave folds row `row`: v = x_in + (pbias + sum_s pend[s]) (s ascending, mod.rs:346-348), optionally writes
+// the folded stream, then LayerNorm (Burn nn::LayerNorm: biased variance, two passes) into out[0..d).
+// Every load is unconditional (columns past d alias column `lane`; planes past KSp alias the last plane).
+template <int DPL>
+__device__ __forceinline__ void fold_ln_row(const float* __restrict__ x_in, const float* __restrict__ pend, int KSp,
+                                            int64_t plane, const float* __restrict__ pbias, float* __restrict__ x_out,
+                                            const float* __restrict__ g, const float* __restrict__ b, float eps,
+                                            int eps_inside, int d, int row, int lane, float* __restrict__ out) {
+  int co[DPL];
+#pragma unroll
+  for (int i = 0; i < DPL; i++) co[i] = lane + (64 * i < d ? 64 * i : 0);
+  float gv[DPL], bv[DPL], v[DPL];
+  const float* xr = x_in + (int64_t)row * d;
+#pragma unroll
+  for (int i = 0; i < DPL; i++) { gv[i] = g[co[i]]; bv[i] = b[co[i]]; v[i] = xr[co[i]]; }
+  if (KSp > 0) {
+    float acc[DPL];
+#pragma unroll
+    for (int i = 0; i < DPL; i++) acc[i] = pbias[co[i]];
+    const float* pp = pend + (int64_t)row * d;
+    constexpr int CH = DPL <= 6 ? 8 : 4;
+    for (int sp = 0; sp < KSp; sp += CH) {
+      float t[CH][DPL];
+#pragma unroll
+      for (int j = 0; j < CH; j++) {
+        const float* pj = pp + (int64_t)min(sp + j, KSp - 1) * plane;
+#pragma unroll
+        for (int i = 0; i < DPL; i++) t[j][i] = pj[co[i]];
+      }
+#pragma unroll
+      for (int j = 0; j < CH; j++) {
+        const bool live = sp + j < KSp;
+#pragma unroll
+        for (int i = 0; i < DPL; i++) acc[i] += live ? t[j][i] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < DPL; i++) v[i] = v[i] + acc[i];
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < DPL; i++) {
+    if (64 * i < d) { s += v[i]; if (x_out) x_out[(int64_t)row * d + co[i]] = v[i]; }
+  }
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < DPL; i++) {
+    if (64 * i < d) { const float t = v[i] - mean; q += t * t; }
+  }
+  const float var = wave_sum(q) / (float)d;
+  const float denom = eps_inside ? sqrtf(var + eps) : (sqrtf(var) + eps);
+#pragma unroll
+  for (int i = 0; i < DPL; i++) {
+    const int c = lane + 64 * i;
+    if (c < d) out[c] = (v[i] - mean) / denom * gv[i] + bv[i];
+  }
+}
+
+// Cooperative fold of the residual stream: xs[r][c] = x_in[r][c] + pbias[c] + sum_s pend[s][r][c] for every
+// r < MR, c < d, all loads of a thread issued together (one memory round trip instead of one per plane chunk).
+// Rows >= n_rows read valid memory (the buffers carry MR rows of slack) and are never used.
+template <int NT, int MR, int EPT, int PCH>
+__device__ __forceinline__ void fold_rows(const float* __restrict__ x_in, const float* __restrict__ pend, int KSp,
+                                          int64_t plane, const float* __restrict__ pbias, int d, int tid,
+                                          float (&v)[EPT]) {
+  int off[EPT], col[EPT];
+#pragma unroll
+  for (int i = 0; i < EPT; i++) {
+    int e = tid + NT * i;
+    if (e >= MR * d) e = tid;                      // past the tile: alias an in-range element, result unused
+    off[i] = e; col[i] = e % d;
+  }
+#pragma unroll
+  for (int i = 0; i < EPT; i++) v[i] = x_in[off[i]];
+  if (KSp > 0) {
+    float acc[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; i++) acc[i] = pbias[col[i]];
+    for (int sp = 0; sp < KSp; sp += PCH) {
+      float t[PCH][EPT];
+#pragma unroll
+      for (int j = 0; j < PCH; j++) {
+        const float* pj = pend + (int64_t)min(sp + j, KSp - 1) * plane;
+#pragma unroll
+        for (int i = 0; i < EPT; i++) t[j][i] = pj[off[i]];
+      }
+#pragma unroll
+      for (int j = 0; j < PCH; j++) {
+        const bool live = sp + j < KSp;
+#pragma unroll
+        for (int i = 0; i < EPT; i++) acc[i] += live ? t[j][i] : 0.f;     // s ascending: fixed order
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < EPT; i++) v[i] = v[i] + acc[i];                   // x + (bias + partials)  (mod.rs:346-348)
+  }
+}
+
+// LayerNorm of row r held in LDS (in place), one wave: Burn nn::LayerNorm, biased variance, two passes.
+template <int DPL>
+__device__ __forceinline__ void ln_row_lds(float* __restrict__ row, int d, int lane, const float (&gv)[DPL],
+                                           const float (&bv)[DPL], float eps, int eps_inside) {
+  float v[DPL];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < DPL; i++) { v[i] = row[lane + 64 * i]; s += v[i]; }
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < DPL; i++) { const float t = v[i] - mean; q += t * t; }
+  const float var = wave_sum(q) / (float)d;
+  const float denom = eps_inside ? sqrtf(var + eps) : (sqrtf(var) + eps);
+#pragma unroll
+  for (int i = 0; i < DPL; i++) row[lane + 64 * i] = (v[i] - mean) / denom * gv[i] + bv[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// MLP.  block = 512 threads, grid = 4 d / 64.  Every global load of the block (fold operands, the W1 slice, the
+// W2 slice) is requested before the first use of any of them: one memory round trip on the critical path.
+// Phase 1: 16 lanes x float4 cover the 64 slice columns of one W1 row; thread (rg = tid / 16, c4) owns rows
+// rg, rg + 32, ... (d / 32 of them).  Phase 2: thread (cf = tid % (d / 4), jg = tid / (d / 4)) owns a float4 of
+// output columns and 64 / G rows of the W2 slice.
+template <int MR, int DPL>
+__global__ __launch_bounds__(512) void dec_mlp_fused_kernel(MlpFusedArgs a) {
+  constexpr int HS = 64, NT = 512;
+  constexpr int d = 64 * DPL;
+  constexpr int CF = d / 4;
+  constexpr int G = CF <= 32 ? 8 : 4;              // phase-2 row groups (d = 128: 8 x 8 rows, 384 / 512: 4 x 16 rows)
+  constexpr int RPG = HS / G;
+  constexpr int EPT = (MR * d + NT - 1) / NT;
+  constexpr int PCH = EPT <= 3 ? 8 : EPT <= 6 ? 6 : 3;
+  __shared__ __attribute__((aligned(16))) float hs[MR][d];              // x + pending, then LN of it
+  __shared__ __attribute__((aligned(16))) float red[8][MR][HS];         // per-wave partial hidden sums
+  __shared__ __attribute__((aligned(16))) float hid[MR][HS];            // GELU(hidden slice)
+  __shared__ __attribute__((aligned(16))) float obuf[(G - 1) * MR * d]; // phase-2 partials of row groups >= 1
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j0 = blockIdx.x * HS;
+  const int rg = tid >> 4, c4 = (tid & 15) * 4;
+  constexpr int NW1 = d / 32;
+  float4 w1[NW1];
+  {
+    const float* wp = a.W1 + (int64_t)rg * a.ld1 + j0 + c4;
+#pragma unroll
+    for (int i = 0; i < NW1; i++) w1[i] = *reinterpret_cast<const float4*>(wp + (int64_t)(32 * i) * a.ld1);
+  }
+  const int cf = tid % CF, jg = tid / CF;
+  const bool p2 = jg < G;
+  const int jb = (p2 ? jg : 0) * RPG;
+  float4 w2[RPG];
+  {
+    const float* wp = a.W2 + (int64_t)(j0 + jb) * d + cf * 4;
+#pragma unroll
+    for (int i = 0; i < RPG; i++) w2[i] = *reinterpret_cast<const float4*>(wp + (int64_t)i * d);
+  }
+  float gv[DPL], bv[DPL];
+#pragma unroll
+  for (int i = 0; i < DPL; i++) { gv[i] = a.ln_g[lane + 64 * i]; bv[i] = a.ln_b[lane + 64 * i]; }
+  const float b1v = a.b1[j0 + (tid & 63)];
+  const int n_rows = a.st[ST_N];
+  {
+    float v[EPT];
+    fold_rows<NT, MR, EPT, PCH>(a.x_in, a.pend, a.KSp, (int64_t)a.S * d, a.pbias, d, tid, v);
+#pragma unroll
+    for (int i = 0; i < EPT; i++) {
+      const int e = tid + NT * i;
+      if (e < MR * d) {
+        (&hs[0][0])[e] = v[i];
+        if (blockIdx.x == 0 && e < n_rows * d) a.x_out[e] = v[i];
+      }
+    }
+  }
+  __syncthreads();
+  if (wave < MR) ln_row_lds<DPL>(hs[wave], d, lane, gv, bv, a.ln_eps, a.ln_inside);
+  __syncthreads();
+  float acc[MR][4];
+#pragma unroll
+  for (int r = 0; r < MR; r++) { acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < NW1; i++) {
+    const int k = rg + 32 * i;
+#pragma unroll
+    for (int r = 0; r < MR; r++) {
+      const float xv = hs[r][k];
+      acc[r][0] += xv * w1[i].x; acc[r][1] += xv * w1[i].y; acc[r][2] += xv * w1[i].z; acc[r][3] += xv * w1[i].w;
+    }
+  }
+  // lanes l, l ^ 16, l ^ 32, l ^ 48 hold the same columns for different rows: fold them, then the eight waves
+#pragma unroll
+  for (int r = 0; r < MR; r++)
+#pragma unroll
+    for (int c = 0; c < 4; c++) { acc[r][c] = xor16_sum(acc[r][c]); acc[r][c] = xor32_sum(acc[r][c]); }
+  if (lane < 16) {
+#pragma unroll
+    for (int r = 0; r < MR; r++)
+      *reinterpret_cast<float4*>(&red[wave][r][c4]) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+  }
+  __syncthreads();
+  if (tid < MR * HS) {
+    const int r = tid >> 6, c = tid & 63;
+    float v = 0.f;
+#pragma unroll
+    for (int w8 = 0; w8 < 8; w8++) v += red[w8][r][c];                  // wave order fixed
+    hid[r][c] = gelu_erf_f(v + b1v);                                    // mod.rs:377-378
+  }
+  __syncthreads();
+  float o[MR][4];
+#pragma unroll
+  for (int r = 0; r < MR; r++) { o[r][0] = o[r][1] = o[r][2] = o[r][3] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < RPG; i++) {
+#pragma unroll
+    for (int r = 0; r < MR; r++) {
+      const float hv = hid[r][jb + i];
+      o[r][0] += hv * w2[i].x; o[r][1] += hv * w2[i].y; o[r][2] += hv * w2[i].z; o[r][3] += hv * w2[i].w;
+    }
+  }
+  if (p2 && jg > 0) {
+#pragma unroll
+    for (int r = 0; r < MR; r++)
+      *reinterpret_cast<float4*>(&obuf[((jg - 1) * MR + r) * d + cf * 4]) = make_float4(o[r][0], o[r][1], o[r][2], o[r][3]);
+  }
+  __syncthreads();
+  if (jg == 0) {
+#pragma unroll
+    for (int g2 = 1; g2 < G; g2++) {               // group order fixed: deterministic sums
+#pragma unroll
+      for (int r = 0; r < MR; r++) {
+        const float4 t = *reinterpret_cast<const float4*>(&obuf[((g2 - 1) * MR + r) * d + cf * 4]);
+        o[r][0] += t.x; o[r][1] += t.y; o[r][2] += t.z; o[r][3] += t.w;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < MR; r++)
+      if (r < n_rows)
+        *reinterpret_cast<float4*>(&a.P[((int64_t)blockIdx.x * a.S + r) * d + cf * 4]) =
+            make_float4(o[r][0], o[r][1], o[r][2], o[r][3]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Self-attention block.  block = 512 threads (8 waves), grid = (n_head, rows): block (h, r) owns head h of beam r.
+// (One block per head for ALL beams keeps 4-8 accumulator sets per thread next to two weight rounds and spills;
+// per-beam blocks re-read the head's weight slices through L2 -- HBM still sees them once.)
+// QKV: wave w owns K-rows [w d / 8, (w + 1) d / 8); lane (seg = lane / 16 in {q, k, v, idle}, c4) reads a float4 of
+// the head's 64 columns of that segment; rounds of 16 rows, two rounds in flight.  Requested up front: two weight
+// rounds + the fold operands; when the weight registers free up: the cached K row of this thread's position and
+// the out-projection slice, so the attention phases and the out-projection do not wait on memory.
+template <int DPL>
+__global__ __launch_bounds__(512) void dec_attn_fused_kernel(AttnFusedArgs a) {
+  constexpr int NT = 512;
+  constexpr int d = 64 * DPL;
+  constexpr int KW = d / 8;                        // K rows per wave (16, 48, 64)
+  constexpr int NIT = KW / 16;
+  constexpr int CF = d / 4;
+  constexpr int G = CF <= 32 ? 8 : 4;              // out-projection row groups (d = 128: 8 x 8 rows, 384 / 512: 4 x 16)
+  constexpr int RPG = 64 / G;
+  constexpr int RED = (8 * 192 > (G - 1) * d) ? 8 * 192 : (G - 1) * d;
+  __shared__ __attribute__((aligned(16))) float hs[d];
+  __shared__ __attribute__((aligned(16))) float red[RED];              // QKV partials, later the out-projection partials
+  __shared__ __attribute__((aligned(16))) float qkv[192];              // q * s, k * s, v of the new token (head h)
+  __shared__ int tbs[FA_MAXPOS];
+  __shared__ float sc[FA_MAXPOS];
+  __shared__ __attribute__((aligned(16))) float ored[8][64];
+  __shared__ __attribute__((aligned(16))) float att[64];
+  __shared__ float lsum_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.x, r = blockIdx.y;
+  // ---- requested first: two QKV weight rounds, LayerNorm parameters, bias, the fold operands of row r
+  const int seg = lane >> 4, c4 = (lane & 15) * 4;
+  const bool seg_ok = seg < 3;
+  const float* wq = a.Wqkv + (int64_t)(wave * KW) * a.ldqkv + (seg_ok ? seg : 0) * d + h * 64 + c4;
+  float4 wr[2][16];
+  auto load_round = [&](float4 (&w)[16], int it) {
+#pragma unroll
+    for (int j = 0; j < 16; j++) w[j] = *reinterpret_cast<const float4*>(wq + (int64_t)(16 * it + j) * a.ldqkv);
+  };
+  load_round(wr[0], 0);
+  if (NIT > 1) load_round(wr[1], 1);
+  float gv[DPL], bv[DPL];
+#pragma unroll
+  for (int i = 0; i < DPL; i++) { gv[i] = a.ln_g[lane + 64 * i]; bv[i] = a.ln_b[lane + 64 * i]; }
+  const float qbias = tid < 192 ? a.bqkv[(tid >> 6) * d + h * 64 + (tid & 63)] : 0.f;   // key part is zero (mod.rs:402-404)
+  {
+    // x + (bias + partial planes), s ascending (mod.rs:346-348): one element per thread, all planes in flight together
+    const int c = tid < d ? tid : 0;
+    const float* pp = a.pend + (int64_t)r * d + c;
+    const int64_t plane = (int64_t)a.S * d;
+    float v = a.x_in[(int64_t)r * d + c];
+    if (a.KSp > 0) {
+      float accp = a.pbias[c];
+      for (int sp = 0; sp < a.KSp; sp += 16) {
+        float t[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) t[j] = pp[(int64_t)min(sp + j, a.KSp - 1) * plane];
+#pragma unroll
+        for (int j = 0; j < 16; j++) accp += (sp + j < a.KSp) ? t[j] : 0.f;
+      }
+      v += accp;
+    }
+    const int n_rows = a.st[ST_N];
+    if (r >= n_rows) return;                       // (block-uniform)
+    if (tid < d) {
+      hs[tid] = v;
+      if (h == 0) a.x_out[(int64_t)r * d + tid] = v;
+    }
+  }
+  const int len = a.st[a.lay.len + r];
+  {
+    const int* tb = a.tabs + (size_t)(a.st[ST_STEP] & 1) * a.lay.S * a.Lmax + r * a.Lmax;
+    for (int p = tid; p < len; p += NT) tbs[p] = tb[p];
+  }
+  __syncthreads();
+  if (wave == 0) ln_row_lds<DPL>(hs, d, lane, gv, bv, a.ln_eps, a.ln_inside);
+  __syncthreads();
+  // ---- QKV for head h (rolled on purpose: unrolled, every round's loads are hoisted to the top and spill)
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int it = 0; it < NIT; it += 2) {
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+      if (it + b < NIT) {
+        const int kb = wave * KW + 16 * (it + b);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          const float xv = hs[kb + j];
+          acc[0] += xv * wr[b][j].x; acc[1] += xv * wr[b][j].y; acc[2] += xv * wr[b][j].z; acc[3] += xv * wr[b][j].w;
+        }
+        if (it + b + 2 < NIT) load_round(wr[b], it + b + 2);
+      }
+    }
+  }
+  __syncthreads();   // (also pins the loads below -- their addresses come from LDS -- behind the FMAs)
+  // ---- requested now: the cached K row of position p = tid and the Wo slice
+  float4 kpre[16];
+  if (tid < len - 1) {
+    const float4* kr = reinterpret_cast<const float4*>(a.Kc + (int64_t)tbs[tid] * d + h * 64);
+#pragma unroll
+    for (int c = 0; c < 16; c++) kpre[c] = kr[c];
+  }
+  const int cf = tid % CF, jg = tid / CF;
+  const bool p5 = jg < G;
+  const int jb = (p5 ? jg : 0) * RPG;
+  float4 wo[RPG];
+  {
+    const float* wp = a.Wo + (int64_t)(h * 64 + jb) * d + cf * 4;
+#pragma unroll
+    for (int i = 0; i < RPG; i++) wo[i] = *reinterpret_cast<const float4*>(wp + (int64_t)i * d);
+  }
+  if (seg_ok) *reinterpret_cast<float4*>(&red[wave * 192 + seg * 64 + c4]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  __syncthreads();
+  if (tid < 192) {
+    float v = 0.f;
+#pragma unroll
+    for (int w8 = 0; w8 < 8; w8++) v += red[w8 * 192 + tid];            // wave order fixed
+    v += qbias;
+    if (tid < 128) v *= a.scale;                                        // q * s, k * s  (mod.rs:506-514)
+    qkv[tid] = v;
+  }
+  __syncthreads();
+  // ---- append k * s, v of the new token to the cache
+  if (tid >= 64 && tid < 192) {
+    float* dst = (tid < 128 ? a.Kc : a.Vc) + (int64_t)tbs[len - 1] * d + h * 64 + (tid & 63);
+    *dst = qkv[tid];
+  }
+  // ---- scores: thread = cached position (len <= 448 < 512); the new token attends to itself from LDS
+  if (tid < len - 1) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+      const float4 qv = *reinterpret_cast<const float4*>(&qkv[4 * c]);
+      s += qv.x * kpre[c].x + qv.y * kpre[c].y + qv.z * kpre[c].z + qv.w * kpre[c].w;
+    }
+    sc[tid] = s;
+  } else if (tid == len - 1) {
+    float s = 0.f;
+    for (int c = 0; c < 64; c++) s += qkv[c] * qkv[64 + c];
+    sc[tid] = s;
+  }
+  __syncthreads();
+  // ---- V columns of this wave's positions (p = wave mod 8): requested before the softmax statistics are known
+  const float* vbase = a.Vc + h * 64;              // uniform base + 32-bit lane offsets
+  float vv[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int p = wave + 8 * i;
+    vv[i] = p < len - 1 ? vbase[(unsigned)(tbs[p] * d + lane)] : 0.f;
+  }
+  // softmax statistics, redundantly per wave (no extra barrier): m, l over all positions
+  float m = -INFINITY;
+  for (int p = lane; p < len; p += 64) m = fmaxf(m, sc[p]);
+  m = wave_max(m);
+  float l = 0.f;
+  for (int p = lane; p < len; p += 64) l += expf(sc[p] - m);
+  l = wave_sum(l);
+  float o = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int p = wave + 8 * i;
+    if (p < len - 1) o += expf(sc[p] - m) * vv[i];
+  }
+  for (int p0 = wave + 128; p0 < len - 1; p0 += 128) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int p = p0 + 8 * i;
+      vv[i] = p < len - 1 ? vbase[(unsigned)(tbs[p] * d + lane)] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int p = p0 + 8 * i;
+      if (p < len - 1) o += expf(sc[p] - m) * vv[i];
+    }
+  }
+  if (wave == ((len - 1) & 7)) o += expf(sc[len - 1] - m) * qkv[128 + lane];
+  ored[wave][lane] = o;
+  if (tid == 0) lsum_s = l;
+  __syncthreads();
+  if (tid < 64) {
+    float v = 0.f;
+#pragma unroll
+    for (int g8 = 0; g8 < 8; g8++) v += ored[g8][tid];
+    att[tid] = v / lsum_s;
+  }
+  __syncthreads();
+  // ---- plane h, row r = att Wo[head h rows, :]
+  float ov[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < RPG; i++) {
+    const float av = att[jb + i];
+    ov[0] += av * wo[i].x; ov[1] += av * wo[i].y; ov[2] += av * wo[i].z; ov[3] += av * wo[i].w;
+  }
+  if (p5 && jg > 0)                                 // (the QKV partials in `red` are dead)
+    *reinterpret_cast<float4*>(&red[(jg - 1) * d + cf * 4]) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+  __syncthreads();
+  if (jg == 0) {
+#pragma unroll
+    for (int g2 = 1; g2 < G; g2++) {
+      const float4 t = *reinterpret_cast<const float4*>(&red[(g2 - 1) * d + cf * 4]);
+      ov[0] += t.x; ov[1] += t.y; ov[2] += t.z; ov[3] += t.w;
+    }
+    *reinterpret_cast<float4*>(&a.P[((int64_t)h * a.S + r) * d + cf * 4]) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+  }
+}
+
+}  // namespace
+
+bool dec_fused_supported(int d) { return d == 128 || d == 384 || d == 512; }
+int dec_mlp_fused_planes(int d) { return 4 * d / 64; }
+
+void launch_dec_mlp_fused(hipStream_t st, const MlpFusedArgs& a, int n_rows_hint) {
+  const dim3 grid(4 * a.d / 64), block(512);
+#define WB_MLP(MR_, DPL_) WB_KLAUNCH((dec_mlp_fused_kernel<MR_, DPL_>), grid, block, 0, st, a)
+  if (n_rows_hint <= 4) {
+    if (a.d == 128) WB_MLP(4, 2); else if (a.d == 384) WB_MLP(4, 6); else WB_MLP(4, 8);
+  } else {
+    if (a.d == 128) WB_MLP(8, 2); else if (a.d == 384) WB_MLP(8, 6); else WB_MLP(8, 8);
+  }
+#undef WB_MLP
+}
+
+void launch_dec_attn_fused(hipStream_t st, const AttnFusedArgs& a, int n_rows_hint) {
+  const dim3 grid(a.n_head, n_rows_hint), block(512);
+  if (a.d == 128) WB_KLAUNCH((dec_attn_fused_kernel<2>), grid, block, 0, st, a);
+  else if (a.d == 384) WB_KLAUNCH((dec_attn_fused_kernel<6>), grid, block, 0, st, a);
+  else WB_KLAUNCH((dec_attn_fused_kernel<8>), grid, block, 0, st, a);
+}
+
+}  // namespace wb

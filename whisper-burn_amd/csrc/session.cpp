@@ -14,14 +14,53 @@ Profile& profile() {
   return p;
 }
 
-ScopedTimer::ScopedTimer(hipStream_t s, int slot_, bool attach_) : st(s), slot(slot_), on(profile().on), attach(attach_) {
+ScopedTimer::ScopedTimer(hipStream_t s, int slot_) : st(s), slot(slot_), on(profile().on) {
   if (!on) return;
   if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
-  if (attach) set_launch_events(a, b);        // consumed by the next GEMV launch
-  else (void)hipEventRecord(a, st);
+  (void)hipEventRecord(a, st);
 }
 void ScopedTimer::stop() {
-  if (on && !attach) (void)hipEventRecord(b, st);
+  if (on) (void)hipEventRecord(b, st);
+}
+
+// ---- per-kernel profiling --------------------------------------------------------------------------------
+static const char* const g_kernel_names[KC_COUNT] = {
+    "dec_prepare", "dec_attn_fused (LN + QKV + self-attention + out-proj)", "dec_cross_attn (LN + Wq + cross-attention)",
+    "dec_gemv cross-attn out-proj", "dec_mlp_fused (LN + lin1 + GELU + lin2)", "dec_gemv logits (LN + E^T + tile stats)",
+    "dec_topk_merge", "dec_gemv LN + QKV", "dec_self_attn", "dec_gemv self-attn out-proj", "dec_gemv LN + Wq",
+    "dec_gemv LN + lin1", "dec_gemv GELU + lin2", "batch-mode decode kernels"};
+struct PendingLaunch { hipEvent_t a, b; int cls; double bytes; };
+static std::mutex g_prof_mu;
+static std::vector<PendingLaunch> g_pending;
+static KernelStat g_kstats[KC_COUNT];
+static thread_local hipEvent_t tl_ev_a = nullptr, tl_ev_b = nullptr;
+
+void prof_tag(int cls, double algo_bytes) {
+  if (!profile().on) return;
+  hipEvent_t a = nullptr, b = nullptr;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+  {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_pending.push_back(PendingLaunch{a, b, cls, algo_bytes});
+  }
+  tl_ev_a = a; tl_ev_b = b;
+}
+bool prof_take_events(hipEvent_t* start, hipEvent_t* stop) {
+  if (!tl_ev_a) return false;
+  *start = tl_ev_a; *stop = tl_ev_b;
+  tl_ev_a = tl_ev_b = nullptr;
+  return true;
+}
+void prof_collect() {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (PendingLaunch& p : g_pending) {
+    float ms = 0.f;
+    if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      g_kstats[p.cls].calls++; g_kstats[p.cls].ms += ms; g_kstats[p.cls].bytes += p.bytes;
+    }
+    (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b);
+  }
+  g_pending.clear();
 }
 void ScopedTimer::collect() {
   if (!on) return;
@@ -60,7 +99,7 @@ void session_pool_purge(wb_model* m) {
 static size_t session_device_bytes(const wb_session* s) {
   size_t n = 0;
   for (const DevMem* b : {&s->pcm, &s->mel, &s->wins, &s->gmax, &s->enc_out, &s->ckv, &s->win_meta, &s->kc, &s->vc,
-                          &s->tabs, &s->state, &s->x, &s->h, &s->att, &s->Pqkv, &s->Po, &s->Pq, &s->P1, &s->P2, &s->ca,
+                          &s->tabs, &s->state, &s->x, &s->h, &s->att, &s->Pqkv, &s->Po, &s->Pq, &s->P1, &s->P2, &s->Pa, &s->ca,
                           &s->logits, &s->tstats, &s->row_stats, &s->mask, &s->lp_tmp, &s->gctl, &s->gtok, &s->hm,
                           &s->ws.x1, &s->ws.x, &s->ws.h, &s->ws.qkv, &s->ws.att, &s->ws.hm, &s->ws.desc1, &s->ws.desc2,
                           &s->ws.auxidx, &s->ws.segs, &s->ws.misc})
@@ -217,15 +256,17 @@ int session_reserve(wb_session* s, int max_len) {
   s->ks_v = 1; s->ksl_v = d;                    // logits: whole rows per block (tile statistics need complete sums)
   s->ct_v = GV_CT_LOGITS;
   s->n_tiles_v = (V + s->ct_v - 1) / s->ct_v;
-  WB_TRY(s->x.ensure((size_t)2 * S * d * 4));   // residual stream, ping-pong
+  // (+ 8 rows of slack: the fused kernels read whole MR-row tiles unconditionally, live or not)
+  WB_TRY(s->x.ensure(((size_t)2 * S + 8) * d * 4));   // residual stream, ping-pong
   WB_TRY(s->h.ensure((size_t)S * d * 4));
   WB_TRY(s->att.ensure((size_t)S * d * 4));
   WB_TRY(s->hm.ensure((size_t)S * 4 * d * 4));
   WB_TRY(s->Pqkv.ensure((size_t)s->ks_qkv * S * 3 * d * 4));
-  WB_TRY(s->Po.ensure((size_t)s->ks_o * S * d * 4));
+  WB_TRY(s->Po.ensure(((size_t)s->ks_o * S + 8) * d * 4));
   WB_TRY(s->Pq.ensure((size_t)s->ks_o * S * d * 4));
   WB_TRY(s->P1.ensure((size_t)s->ks_1 * S * 4 * d * 4));
-  WB_TRY(s->P2.ensure((size_t)s->ks_2 * S * d * 4));
+  WB_TRY(s->P2.ensure(((size_t)std::max(s->ks_2, dec_mlp_fused_planes(d)) * S + 8) * d * 4));
+  WB_TRY(s->Pa.ensure(((size_t)D.n_text_head * S + 8) * d * 4));
   WB_TRY(s->ca.ensure((size_t)S * D.n_text_head * std::max(1, s->n_chunks) * CA_STRIDE * 4));
   WB_TRY(s->logits.ensure((size_t)S * V * 4));
   WB_TRY(s->tstats.ensure((size_t)S * s->n_tiles_v * TS_STRIDE * 4));
@@ -351,11 +392,17 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
   const int* win_row0 = s->win_meta.as<int>();
   const int* win_C = win_row0 + s->W;
   const int n = n_launch;
+  // algorithmic bytes of the tagged launches (profiling): the weights a launch streams + the cached K/V it reads
+  const double wsz = m->compute_dtype == WB_BF16 ? 2.0 : 4.0, dd = (double)d * d;
+  double ckv_bytes = 0;
+  for (int c : s->C) ckv_bytes += 8.0 * c * d;                    // K and V rows of one layer, f32
+  const double self_kv_bytes = 8.0 * (double)n * (s->step + 1) * d;
 
   int* gctl = chained ? s->gctl.as<int>() : nullptr;
   // chained small-batch steps: the previous step's merge kernel already prepared this one (the chain's
   // first step is prepared by session_greedy_chain)
   const bool merge_prepares = chained && fuse_ln;
+  if (!merge_prepares) prof_tag(KC_PREPARE, 8.0 * n * d);
   if (!merge_prepares)
     launch_dec_prepare(st, hst, s->state.as<int>(), L, n, tabs, s->Lmax, m->tok_emb, m->dec_pos, d, xb[0], gctl);
   auto gemv = [&](const LinearW& w, int ks, int ksl, int pro, const float* src, int ld_src, float* P) {
@@ -433,60 +480,103 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
   static const bool fuse_q_enabled = []() { const char* e = getenv("WHISPER_HIP_FUSE_Q"); return !(e && e[0] == '0'); }();
   const bool fuse_q = fuse_q_enabled && fuse_ln && cross_attn_can_fuse_q(d) && m->compute_dtype != WB_BF16 &&
                       s->n_chunks * H * s->W <= 256;
+  // sublayer fusion (decode_fused.hip): self-attention block and MLP block are ONE launch each
+  static const bool fuse_sub_enabled = []() { const char* e = getenv("WHISPER_HIP_FUSE_SUB"); return !(e && e[0] == '0'); }();
+  const bool fuse_sub = fuse_sub_enabled && dec_fused_supported(d) && m->compute_dtype != WB_BF16 && d == 64 * H;
+  const int nb_mlp = dec_mlp_fused_planes(d);
+  const int ks_mlp = fuse_sub ? nb_mlp : s->ks_2;            // planes the MLP leaves pending
   for (int l = 0; l < NL; l++) {   // ResidualDecoderAttentionBlock::forward, mod.rs:345-350
     const DecBlockW& b = m->dec[l];
-    ln_gemv(gemv(b.qkv, s->ks_qkv, s->ksl_qkv, PRO_PLAIN, nullptr, d, s->Pqkv.as<float>()),
-            l == 0 ? nullptr : s->P2.as<float>(), l == 0 ? 0 : s->ks_2, l == 0 ? nullptr : m->dec[l - 1].mlp2.b, b.ln1,
-            false);
-    launch_dec_self_attn(st, dst, L, n, H, s->Pqkv.as<float>(), s->ks_qkv, b.qkv.b, d,
-                         s->kc.as<float>() + (size_t)l * pool * d, s->vc.as<float>() + (size_t)l * pool * d, tabs,
-                         s->Lmax, m->qk_scale, att);
-    launch_dec_gemv(st, gemv(b.out, s->ks_o, s->ksl_o, PRO_PLAIN, att, d, s->Po.as<float>()), n, false);
+    const float* pend_a = l == 0 ? nullptr : s->P2.as<float>();
+    const int ks_a = l == 0 ? 0 : ks_mlp;
+    const float* pb_a = l == 0 ? nullptr : m->dec[l - 1].mlp2.b;
+    const float* att_planes; int att_ks;                     // what the cross-attention prologue folds
+    if (fuse_sub) {
+      AttnFusedArgs fa;
+      fa.st = dst; fa.lay = L; fa.S = S; fa.d = d; fa.n_head = H;
+      fa.x_in = xb[xi]; fa.pend = pend_a; fa.KSp = ks_a; fa.pbias = pb_a; fa.x_out = xb[xi ^ 1];
+      fa.ln_g = b.ln1.g; fa.ln_b = b.ln1.b; fa.ln_eps = b.ln1.eps; fa.ln_inside = m->ln_eps_inside_sqrt;
+      fa.Wqkv = b.qkv.w; fa.ldqkv = b.qkv.n; fa.bqkv = b.qkv.b; fa.scale = m->qk_scale;
+      fa.Kc = s->kc.as<float>() + (size_t)l * pool * d; fa.Vc = s->vc.as<float>() + (size_t)l * pool * d;
+      fa.tabs = tabs; fa.Lmax = s->Lmax; fa.Wo = b.out.w; fa.P = s->Pa.as<float>();
+      prof_tag(KC_ATTN_FUSED, 4.0 * dd * 4 + self_kv_bytes);
+      launch_dec_attn_fused(st, fa, n);
+      xi ^= 1;
+      att_planes = s->Pa.as<float>(); att_ks = H;
+    } else {
+      prof_tag(KC_GEMV_LN_QKV, wsz * dd * 3);
+      ln_gemv(gemv(b.qkv, s->ks_qkv, s->ksl_qkv, PRO_PLAIN, nullptr, d, s->Pqkv.as<float>()), pend_a, ks_a, pb_a, b.ln1, false);
+      prof_tag(KC_SELF_ATTN, self_kv_bytes);
+      launch_dec_self_attn(st, dst, L, n, H, s->Pqkv.as<float>(), s->ks_qkv, b.qkv.b, d,
+                           s->kc.as<float>() + (size_t)l * pool * d, s->vc.as<float>() + (size_t)l * pool * d, tabs,
+                           s->Lmax, m->qk_scale, att);
+      prof_tag(KC_GEMV_OUT, wsz * dd);
+      launch_dec_gemv(st, gemv(b.out, s->ks_o, s->ksl_o, PRO_PLAIN, att, d, s->Po.as<float>()), n, false);
+      att_planes = s->Po.as<float>(); att_ks = s->ks_o;
+    }
     if (fuse_q) {
       // cross_attn_ln + the query projection inside the cross-attention blocks (one launch less per layer)
       CaFuse fz;
-      fz.x_in = xb[xi]; fz.pend = s->Po.as<float>(); fz.KSp = s->ks_o; fz.pbias = b.out.b; fz.x_out = xb[xi ^ 1];
+      fz.x_in = xb[xi]; fz.pend = att_planes; fz.KSp = att_ks; fz.pbias = b.out.b; fz.x_out = xb[xi ^ 1];
       fz.ln_g = b.ln2.g; fz.ln_b = b.ln2.b; fz.ln_eps = b.ln2.eps; fz.ln_inside = m->ln_eps_inside_sqrt;
       fz.Wq = b.cq.w;
+      prof_tag(KC_CROSS_ATTN, ckv_bytes + 4.0 * dd);
       launch_dec_cross_attn(st, dst, L, s->W, H, s->n_chunks, nullptr, 0, b.cq.b, d, s->ckv.as<float>(), ldkv,
                             l * 2 * d, win_row0, win_C, m->qk_scale, s->ca.as<float>(), max_nb, &fz);
       xi ^= 1;
     } else {
-      ln_gemv(gemv(b.cq, s->ks_o, s->ksl_o, PRO_PLAIN, nullptr, d, s->Pq.as<float>()), s->Po.as<float>(), s->ks_o,
-              b.out.b, b.ln2, false);
+      prof_tag(KC_GEMV_LN_CQ, wsz * dd);
+      ln_gemv(gemv(b.cq, s->ks_o, s->ksl_o, PRO_PLAIN, nullptr, d, s->Pq.as<float>()), att_planes, att_ks, b.out.b, b.ln2,
+              false);
+      prof_tag(KC_CROSS_ATTN, ckv_bytes);
       launch_dec_cross_attn(st, dst, L, s->W, H, s->n_chunks, s->Pq.as<float>(), s->ks_o, b.cq.b, d,
                             s->ckv.as<float>(), ldkv, l * 2 * d, win_row0, win_C, m->qk_scale, s->ca.as<float>(), max_nb);
     }
     {
       GemvArgs a = gemv(b.cout, s->ks_o, s->ksl_o, PRO_ATTN, s->ca.as<float>(), 0, s->Po.as<float>());
       a.n_head = H; a.n_chunks = s->n_chunks;
+      prof_tag(KC_GEMV_COUT, wsz * dd);
       launch_dec_gemv(st, a, n, false);
     }
-    ln_gemv(gemv(b.mlp1, s->ks_1, s->ksl_1, PRO_PLAIN, nullptr, d, s->P1.as<float>()), s->Po.as<float>(), s->ks_o,
-            b.cout.b, b.ln3, false);
-    {
+    if (fuse_sub) {
+      MlpFusedArgs ma;
+      ma.st = dst; ma.S = S; ma.d = d;
+      ma.x_in = xb[xi]; ma.pend = s->Po.as<float>(); ma.KSp = s->ks_o; ma.pbias = b.cout.b; ma.x_out = xb[xi ^ 1];
+      ma.ln_g = b.ln3.g; ma.ln_b = b.ln3.b; ma.ln_eps = b.ln3.eps; ma.ln_inside = m->ln_eps_inside_sqrt;
+      ma.W1 = b.mlp1.w; ma.ld1 = b.mlp1.n; ma.b1 = b.mlp1.b; ma.W2 = b.mlp2.w; ma.P = s->P2.as<float>();
+      prof_tag(KC_MLP_FUSED, 4.0 * dd * 8);
+      launch_dec_mlp_fused(st, ma, n);
+      xi ^= 1;
+    } else {
+      prof_tag(KC_GEMV_LN_MLP1, wsz * dd * 4);
+      ln_gemv(gemv(b.mlp1, s->ks_1, s->ksl_1, PRO_PLAIN, nullptr, d, s->P1.as<float>()), s->Po.as<float>(), s->ks_o,
+              b.cout.b, b.ln3, false);
       GemvArgs a = gemv(b.mlp2, s->ks_2, s->ksl_2, PRO_GELU, s->P1.as<float>(), 4 * d, s->P2.as<float>());
       a.pbias = b.mlp1.b; a.KSp = s->ks_1;
+      prof_tag(KC_GEMV_MLP2, wsz * dd * 4);
       launch_dec_gemv(st, a, n, false);
     }
   }
   if (k > 0) {
     // logits = ln(x) . token_embedding^T (mod.rs:155-156), last position only; + mask, tile statistics
-    ScopedTimer tm_logits(st, 6, /*attach=*/true);   // profiled passes: the kernel's own begin -> end
+    ScopedTimer tm_logits(st, 6);
     GemvArgs a;
     a.W = m->tok_emb_t; a.ldw = m->vocab_ld; a.K = d; a.N = V; a.KS = 1; a.KSL = d;
     a.Wb = m->compute_dtype == WB_BF16 ? m->tok_emb_t_bf : nullptr;
     a.P = s->logits.as<float>(); a.st = dst; a.S = S;
     a.mask = s->mask.as<float>(); a.use_mask = use_mask; a.topk = k; a.tstats = s->tstats.as<float>(); a.ct = s->ct_v;
-    ln_gemv(a, s->P2.as<float>(), s->ks_2, m->dec[NL - 1].mlp2.b, m->ln_dec, true);
+    prof_tag(KC_LOGITS, wsz * (double)V * d + 4.0 * ((double)n * d + (double)n * V));
+    ln_gemv(a, s->P2.as<float>(), ks_mlp, m->dec[NL - 1].mlp2.b, m->ln_dec, true);
     tm_logits.stop();
     NextPrep nx;
     if (merge_prepares) { nx.x = xb[0]; nx.E = m->tok_emb; nx.pos = m->dec_pos; nx.tabs = tabs; nx.d = d; }
+    prof_tag(KC_TOPK_MERGE, 4.0 * n * s->n_tiles_v * TS_STRIDE);
     launch_dec_topk_merge(st, s->state.as<int>(), n, s->tstats.as<float>(), s->n_tiles_v, k, out_id_dev, out_lp_dev,
                           s->row_stats.as<float>(), L, gctl, s->gtok.as<int>(), s->Lmax, eot, nx);
     if (timed && tm_logits.on) {
       WB_HIP(hipStreamSynchronize(st));
       tm_logits.collect();
+      prof_collect();
       profile().ms[7] += 1;
     }
   }
@@ -507,7 +597,7 @@ static int launch_step(wb_session* s, int n_launch, int k, int use_mask, bool fu
   uint64_t sig = 1469598103934665603ull;
   auto mix = [&](uint64_t v) { sig = (sig ^ v) * 1099511628211ull; };
   for (const wb::DevMem* b : {&s->kc, &s->vc, &s->tabs, &s->state, &s->x, &s->h, &s->att, &s->Pqkv, &s->Po, &s->Pq,
-                              &s->P1, &s->P2, &s->ca, &s->logits, &s->tstats, &s->row_stats, &s->mask, &s->ckv,
+                              &s->P1, &s->P2, &s->Pa, &s->ca, &s->logits, &s->tstats, &s->row_stats, &s->mask, &s->ckv,
                               &s->win_meta, &s->gctl, &s->gtok, &s->hm})
     mix((uint64_t)(uintptr_t)b->p);
   mix((uint64_t)(uintptr_t)s->host_block_dev);
@@ -722,6 +812,22 @@ int wb_session_encoder_output(wb_session* s, int w, float* out, int32_t* C) {
 int wb_profile_enable(int on) {
   profile().on = on != 0;
   return WB_OK;
+}
+int wb_profile_kernels(wb_kernel_stat* out, int cap, int reset) {
+  WB_REQUIRE(out || cap == 0, WB_ERR_ARG, "wb_profile_kernels: null argument");
+  prof_collect();
+  int n = 0;
+  for (int c = 0; c < KC_COUNT; c++) {
+    if (g_kstats[c].calls == 0) continue;
+    if (n < cap) {
+      snprintf(out[n].name, sizeof(out[n].name), "%s", g_kernel_names[c]);
+      out[n].calls = g_kstats[c].calls; out[n].total_ms = g_kstats[c].ms; out[n].algo_bytes = g_kstats[c].bytes;
+    }
+    n++;
+  }
+  if (reset)
+    for (int c = 0; c < KC_COUNT; c++) g_kstats[c] = KernelStat();
+  return n;
 }
 int wb_profile_read(double* out8, int reset) {
   WB_REQUIRE(out8, WB_ERR_ARG, "wb_profile_read: null argument");

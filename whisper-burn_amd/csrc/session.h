@@ -24,7 +24,7 @@ struct wb_session {
   int* state_host = nullptr;            // views into host_block
   int32_t* topk_id_host = nullptr;      // [S][TOPK_MAX]
   float* topk_lp_host = nullptr;
-  wb::DevMem x, h, att, Pqkv, Po, Pq, P1, P2, ca, logits, tstats, row_stats, mask, lp_tmp, gctl, gtok, hm;
+  wb::DevMem x, h, att, Pqkv, Po, Pq, P1, P2, Pa, ca, logits, tstats, row_stats, mask, lp_tmp, gctl, gtok, hm;
   int n_tiles_v = 0, ct_v = 128;
   int ks_qkv = 1, ksl_qkv = 0, ks_o = 1, ksl_o = 0, ks_1 = 1, ksl_1 = 0, ks_2 = 1, ksl_2 = 0, ks_v = 1, ksl_v = 0;
   std::vector<int> prev_len, prev_win;
@@ -44,12 +44,13 @@ struct Profile {
   double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 Profile& profile();
+// per-kernel-class accumulators of the tagged launches (decode.h: prof_tag / WB_KLAUNCH)
+struct KernelStat { int64_t calls = 0; double ms = 0, bytes = 0; };
+void prof_collect();          // after the stream was synchronised: fold the pending tagged launches into the stats
 // Timed region helper: records two events on `st` and adds the elapsed ms to slot `i` (when profiling is on).
-// `attach` = the events are not recorded on the stream but handed to ONE kernel launch (hipExtLaunchKernelGGL
-// start / stop events): the elapsed time is that kernel's own begin -> end, what rocprofv3 --kernel-trace reports.
 struct ScopedTimer {
-  hipStream_t st; int slot; hipEvent_t a = nullptr, b = nullptr; bool on; bool attach;
-  ScopedTimer(hipStream_t s, int slot_, bool attach_ = false);
+  hipStream_t st; int slot; hipEvent_t a = nullptr, b = nullptr; bool on;
+  ScopedTimer(hipStream_t s, int slot_);
   void stop();          // records the end event
   void collect();       // after the stream was synchronised: accumulate
   ~ScopedTimer();

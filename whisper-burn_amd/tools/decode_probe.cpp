@@ -1,6 +1,6 @@
 // Developer probe (not part of the library): per-kernel latency of the decode-step kernels at
 // tiny.en geometry, launched back to back, warm vs rotating (cold) weights, eager vs hipGraph.
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/decode_probe.cpp csrc/build/decode.hip.o -o tools/decode_probe
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/decode_probe.cpp csrc/build/decode.hip.o csrc/build/decode_fused.hip.o -o tools/decode_probe
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
@@ -8,7 +8,7 @@
 #include <vector>
 #include "../csrc/decode.h"
 using namespace wb;
-namespace wb { void set_error(const char*, ...) {} }
+namespace wb { void set_error(const char*, ...) {} void prof_tag(int, double) {} bool prof_take_events(hipEvent_t*, hipEvent_t*) { return false; } }
 __global__ void k_empty() {}
 static hipStream_t st;
 static double bench(int reps, const std::function<void(int)>& f, bool graph) {
@@ -92,6 +92,20 @@ int main(int argc, char** argv) {
       GemvArgs a = base(W1 + (size_t)(cold ? i % NCOPY : 0) * d * 4 * d, d, 4 * d, ks_1, ksl_1); a.pro = PRO_LN; a.src = x; a.ld_src = d;
       a.pend = P; a.KSp = ks_o; a.pbias = bias; a.x_out = x + (size_t)S * d; a.ln_g = g; a.ln_b = b; a.ln_eps = 1e-5f;
       launch_dec_gemv(st, a, n, false); }});
+  }
+  float* W2m = (float*)dmalloc((size_t)NCOPY * 4 * d * d * 4);
+  float* Pa = (float*)dmalloc((size_t)64 * S * d * 4);
+  for (int cold = 0; cold < 2; cold++) {
+    cases.push_back({cold ? "FUSED mlp block cold" : "FUSED mlp block warm", [&, cold](int i) {
+      MlpFusedArgs ma; ma.st = stdev; ma.S = S; ma.d = d; ma.x_in = x; ma.pend = P; ma.KSp = ks_o; ma.pbias = bias; ma.x_out = x + (size_t)S * d;
+      ma.ln_g = g; ma.ln_b = b; ma.ln_eps = 1e-5f; ma.W1 = W1 + (size_t)(cold ? i % NCOPY : 0) * d * 4 * d; ma.ld1 = 4 * d; ma.b1 = bias;
+      ma.W2 = W2m + (size_t)(cold ? i % NCOPY : 0) * 4 * d * d; ma.P = Pa;
+      launch_dec_mlp_fused(st, ma, n); }});
+    cases.push_back({cold ? "FUSED attn block cold" : "FUSED attn block warm", [&, cold](int i) {
+      AttnFusedArgs fa; fa.st = stdev; fa.lay = L; fa.S = S; fa.d = d; fa.n_head = H; fa.x_in = x; fa.pend = Pa; fa.KSp = 4 * d / 64; fa.pbias = bias;
+      fa.x_out = x + (size_t)S * d; fa.ln_g = g; fa.ln_b = b; fa.ln_eps = 1e-5f; fa.Wqkv = Wqkv + (size_t)(cold ? i % NCOPY : 0) * d * 3 * d; fa.ldqkv = 3 * d;
+      fa.bqkv = bias; fa.scale = 0.35f; fa.Kc = Kc; fa.Vc = Vc; fa.tabs = tabs; fa.Lmax = Lmax; fa.Wo = Wdd + (size_t)(cold ? i % NCOPY : 0) * d * d; fa.P = P2;
+      launch_dec_attn_fused(st, fa, n); }});
   }
   cases.push_back({"self-attn len 50", [&](int) { launch_dec_self_attn(st, stdev, L, n, H, P, ks_q, bias, d, Kc, Vc, tabs, Lmax, 0.35f, att); }});
   cases.push_back({"cross-attn C 750", [&](int) { launch_dec_cross_attn(st, stdev, L, S, H, nch, P, ks_o, bias, d, ckv, ldkv, 0, wmeta, wmeta + S, 0.35f, ca, 1); }});

@@ -86,9 +86,25 @@ SIGNATURES = {
                                     C.c_int64, c_int64_p]),
     "wb_profile_enable": (C.c_int, [C.c_int]),
     "wb_profile_read": (C.c_int, [c_double_p, C.c_int]),
+    "wb_profile_kernels": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "wb_last_error": (C.c_char_p, []),
     "wb_version": (C.c_char_p, []),
 }
+
+
+
+class WbKernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("calls", C.c_int64), ("total_ms", C.c_double), ("algo_bytes", C.c_double)]
+
+
+def profile_kernels(reset: bool = True):
+    """wb_profile_kernels as a list of dicts (name, calls, total_ms, algo_bytes)."""
+    lib = load()
+    buf = (WbKernelStat * 32)()
+    n = min(32, int(lib.wb_profile_kernels(C.cast(buf, C.c_void_p), 32, int(reset))))
+    return [dict(name=buf[i].name.decode(), calls=int(buf[i].calls), total_ms=float(buf[i].total_ms),
+                 algo_bytes=float(buf[i].algo_bytes)) for i in range(n)]
+
 
 _lib = None
 

@@ -1,4 +1,4 @@
-"""Special-token table the decode driver needs (ids only; no tokenizer).
+"""Special-token table the decode driver needs (ids only; the tokenizer stays on the caller's side).
 
 The reference looks these up by name in ./tokenizer.json
 (/root/reference/src/transcribe.rs:179-185, src/token.rs:26-30, :267-295) and builds
@@ -41,3 +41,53 @@ class SpecialTokens:
         is_special = np.zeros(n_vocab, dtype=np.uint8)
         is_special[eot:] = 1
         return SpecialTokens(sot, lang0 + language_index, transcribe, notimestamps, eot, is_special)
+
+
+# ---- tokenizer integration (src/token.rs) -------------------------------------------------------------------
+
+def special_token_name(kind: str, language: str = "en") -> str:
+    """`SpecialToken::to_string` (token.rs:280-295)."""
+    return {"endoftext": "<|endoftext|>", "startoftranscript": "<|startoftranscript|>", "translate": "<|translate|>",
+            "transcribe": "<|transcribe|>", "startoflm": "<|startoflm|>", "startofprev": "<|startofprev|>",
+            "nospeech": "<|nospeech|>", "notimestamps": "<|notimestamps|>", "language": f"<|{language}|>"}[kind]
+
+
+class TokenizerAdapter:
+    """The calls transcribe.rs makes on `Gpt2Tokenizer` (token.rs:12-48), over a HuggingFace `tokenizers.Tokenizer`
+    (the crate the reference wraps, Cargo.lock:3504-3505) loaded from a `tokenizer.json`."""
+
+    def __init__(self, tokenizer):
+        self.tok = tokenizer
+
+    @staticmethod
+    def from_file(path: str = "tokenizer.json") -> "TokenizerAdapter":      # token.rs:13-19
+        import tokenizers
+        return TokenizerAdapter(tokenizers.Tokenizer.from_file(path))
+
+    def special_token(self, name: str):                                     # token.rs:26-30
+        return self.tok.token_to_id(name)
+
+    def decode(self, tokens, skip_special: bool = True) -> str:             # token.rs:32-35
+        return self.tok.decode([int(t) for t in tokens], skip_special_tokens=skip_special)
+
+    def is_special(self, token: int) -> bool:                               # token.rs:37-43
+        try:
+            return self.tok.decode([int(token)], skip_special_tokens=True) == ""
+        except Exception:
+            return False
+
+    def vocab_size(self) -> int:                                            # token.rs:45-47
+        return self.tok.get_vocab_size(with_added_tokens=True)
+
+    def special_tokens(self, language: str = "en") -> SpecialTokens:
+        """The five ids transcribe.rs:179-185 looks up and the mask transcribe.rs:243-251 builds by decoding every
+        vocabulary id -- built ONCE here (the reference rebuilds it for every window)."""
+        ids = {}
+        for kind in ("startoftranscript", "language", "transcribe", "notimestamps", "endoftext"):
+            v = self.special_token(special_token_name(kind, language))
+            if v is None:
+                raise KeyError(f"tokenizer has no {special_token_name(kind, language)}")
+            ids[kind] = int(v)
+        mask = np.array([1 if self.is_special(t) else 0 for t in range(self.vocab_size())], dtype=np.uint8)
+        return SpecialTokens(ids["startoftranscript"], ids["language"], ids["transcribe"], ids["notimestamps"],
+                             ids["endoftext"], mask)
