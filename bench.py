@@ -163,6 +163,21 @@ def main() -> None:
         if args.model in ("tiny.en", "tiny_en") and args.dtype == "f32" and args.beam == 1 and args.seconds == 30.0 \
                 and os.path.exists(pmc_json):
             pmc = json.load(open(pmc_json))
+        def pmc_bytes(cls_name):
+            """HBM bytes per launch of the rocprof kernel(s) behind one profiler class (profiles/r02_pmc_*.json is keyed
+            by the demangled kernel name)."""
+            want = {"dec_attn_fused": lambda n: "dec_attn_fused_kernel" in n,
+                    "dec_mlp_fused": lambda n: "dec_mlp_fused_kernel" in n,
+                    "dec_cross_attn": lambda n: "dec_cross_attn_kernel" in n,
+                    "dec_topk_merge": lambda n: "dec_topk_merge_kernel" in n,
+                    "dec_gemv logits": lambda n: "dec_gemv_kernel" in n and "true, true" in n,
+                    "dec_gemv cross-attn": lambda n: "dec_gemv_kernel" in n and "false, false, false" in n}
+            for key, pred in want.items():
+                if cls_name.startswith(key):
+                    vals = [v for n, v in pmc.items() if pred(n)]
+                    return int(max(vals)) if vals else None
+            return None
+
         tot_ms = sum(k["total_ms"] for k in kstats) or 1.0
         kernels = []
         for k in sorted(kstats, key=lambda k: -k["total_ms"]):
@@ -173,7 +188,7 @@ def main() -> None:
                             "launches_timed": k["calls"], "avg_launch_us": round(avg_s * 1e6, 2),
                             "algorithmic_bytes_per_launch": int(per_launch), "achieved_GBps": round(ach, 1),
                             "frac_of_hbm_peak": round(ach / HBM_PEAK_GBS, 4),
-                            "traffic": pmc.get(k["name"].split(" ")[0])})
+                            "traffic": pmc_bytes(k["name"])})
         if kernels:
             k0 = kernels[0]                                   # the dominant kernel by total time
             roofline = {"kernel": k0["kernel"], "bound": "hbm", "achieved": k0["achieved_GBps"], "peak": HBM_PEAK_GBS,

@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/collect_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 # 1. the bench line (with the CPU baseline leg)
-python "$R/bench.py" --steps 10 --warmup 3 > "$OUT/bench.log" 2>&1
+python "$R/bench.py" --steps 40 --warmup 5 > "$OUT/bench.log" 2>&1
 grep '^{"metric' "$OUT/bench.log" > "$OUT/bench_tiny_en_30s.json"
 # 2. kernel statistics of the same command (no CPU leg: the profiler would only slow it down)
 rocprofv3 --kernel-trace --stats -d /tmp/p_stats -o kt -- python "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline \

@@ -74,3 +74,32 @@ def test_tokenizer_table_drives_the_engine(tmp_path):
     assert tokens == ref_tokens100
     assert text == bpe.decode(tokens, True) and "<|" not in text and len(text.split()) >= 2
     assert ref_tokens[:4] == tokens[:4]
+
+
+def test_cli_argument_errors_match_the_reference(tmp_path, capsys, monkeypatch):
+    """bin/transcribe/main.rs:100-123: usage, invalid language, unreadable audio -> message on stderr, exit code 1."""
+    from whisper_burn_amd import transcribe as cli
+    assert cli.main(["transcribe"]) == 1
+    assert "Usage: transcribe <model name> <audio file> <lang> <transcription file>" in capsys.readouterr().err
+    assert cli.main(["transcribe", "m", "a.wav", "xx", "out.txt"]) == 1
+    assert "Invalid language abbreviation: xx" in capsys.readouterr().err
+    assert cli.main(["transcribe", "m", str(tmp_path / "missing.wav"), "en", "out.txt"]) == 1
+    assert "Failed to load audio file" in capsys.readouterr().err
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end(tmp_path, monkeypatch):
+    """The reference's CLI flow: 16 kHz mono WAV + tokenizer.json in the working directory + model -> transcript file."""
+    import wave
+    from whisper_burn_amd import dumpdir
+    from whisper_burn_amd import transcribe as cli
+    monkeypatch.chdir(tmp_path)
+    write_synthetic_tokenizer_json(str(tmp_path / "tokenizer.json"))
+    dims = synth.micro_dims(n_state=128, n_head=2, n_layer=2, n_vocab=N_VOCAB)
+    dumpdir.write_dump_dir(synth.synth_weights(dims, seed=4242), str(tmp_path / "micro"))
+    pcm = np.clip(np.round(synth.synth_audio(16000 * 6, 52) * 32767.0), -32768, 32767).astype("<i2")
+    with wave.open(str(tmp_path / "a.wav"), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(pcm.tobytes())
+    assert cli.main(["transcribe", "micro", "a.wav", "en", "out.txt"]) == 0
+    text = open(tmp_path / "out.txt").read()
+    assert "<|" not in text and len(text.split()) >= 2

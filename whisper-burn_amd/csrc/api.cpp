@@ -112,15 +112,14 @@ int wb_prep_audio(int device, const float* pcm, int64_t n, double sample_rate, f
   WB_TRY(d_pcm.alloc((size_t)n * 4));
   WB_TRY(d_out.alloc((size_t)80 * T * 4));
   WB_TRY(d_win.alloc(sizeof(MelWindow)));
-  WB_TRY(d_max.alloc((size_t)mel_bmax_stride(T) * 4));
+  WB_TRY(d_max.alloc((size_t)mel_bmax_stride(T) * 2 * 4));
   MelWindow w{0, (int32_t)n, T, T, 0};
   hipStream_t st = nullptr;
   WB_HIP(hipMemcpyAsync(d_pcm.p, pcm, (size_t)n * 4, hipMemcpyHostToDevice, st));
   WB_HIP(hipMemcpyAsync(d_win.p, &w, sizeof(w), hipMemcpyHostToDevice, st));
   launch_mel_spectrogram(st, d_pcm.as<float>(), d_win.as<MelWindow>(), 1, T, tabs, d_out.as<float>(),
-                         (int64_t)80 * T, T, d_max.as<float>());
-  launch_mel_finalize(st, d_win.as<MelWindow>(), 1, T, 0, d_out.as<float>(), (int64_t)80 * T, T,
-                      d_max.as<float>(), T);
+                         (int64_t)80 * T, T, d_max.as<float>(), 0, T);
+  launch_mel_finalize(st, d_win.as<MelWindow>(), 1, d_out.as<float>(), (int64_t)80 * T, T, d_max.as<float>(), T);
   WB_HIP(hipGetLastError());
   WB_HIP(hipMemcpyAsync(mel, d_out.p, (size_t)80 * T * 4, hipMemcpyDeviceToHost, st));
   WB_HIP(hipStreamSynchronize(st));
@@ -156,7 +155,7 @@ int wb_waveform_to_mels_dev(int device, const float* pcm_dev, int64_t n_samples,
   WB_TRY(get_mel_tables(device, sample_rate, &tabs));
   DevMem d_win, d_max;
   WB_TRY(d_win.alloc(wins.size() * sizeof(MelWindow)));
-  WB_TRY(d_max.alloc((size_t)n_windows * mel_bmax_stride(maxF) * 4));
+  WB_TRY(d_max.alloc((size_t)n_windows * mel_bmax_stride(maxF) * 2 * 4));
   hipStream_t st = nullptr;
   WB_HIP(hipMemcpyAsync(d_win.p, wins.data(), wins.size() * sizeof(MelWindow), hipMemcpyHostToDevice, st));
   struct Events {   // released on every return path
@@ -167,9 +166,8 @@ int wb_waveform_to_mels_dev(int device, const float* pcm_dev, int64_t n_samples,
   if (elapsed_ms) { WB_HIP(hipEventCreate(&e0)); WB_HIP(hipEventCreate(&e1)); WB_HIP(hipEventRecord(e0, st)); }
   for (int it = 0; it < iters; it++) {
     launch_mel_spectrogram(st, pcm_dev, d_win.as<MelWindow>(), n_windows, maxF, tabs, mel_dev, win_stride, row_stride,
-                           d_max.as<float>());
-    launch_mel_finalize(st, d_win.as<MelWindow>(), n_windows, row_stride, padding, mel_dev, win_stride, row_stride,
-                        d_max.as<float>(), maxF);
+                           d_max.as<float>(), padding, row_stride);
+    launch_mel_finalize(st, d_win.as<MelWindow>(), n_windows, mel_dev, win_stride, row_stride, d_max.as<float>(), maxF);
   }
   if (elapsed_ms) WB_HIP(hipEventRecord(e1, st));
   WB_HIP(hipGetLastError());

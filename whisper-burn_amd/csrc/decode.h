@@ -23,7 +23,7 @@ constexpr int KS_MAX = 16;       // most K-split partials any consumer folds
 // mapped pinned memory; dec_prepare_kernel copies it to device memory for the rest of the step.
 enum { ST_N = 0, ST_STEP = 1, ST_HDR = 4 };
 // Device control block of the chained greedy decode (ints): step, then cur_tok[S], done[S], out_len[S].
-enum { GC_STEP = 0, GC_HDR = 4 };
+enum { GC_STEP = 0, GC_NDONE = 1, GC_ALLDONE = 2, GC_HDR = 4 };   // [1]: windows finished so far, [2]: all of them
 struct StepLayout {
   int S = 0, W = 0;                                  // slot capacity, windows
   int tok = 0, parent = 0, len = 0, win = 0;         // offsets of int[S] arrays
@@ -78,6 +78,9 @@ struct CaFuse {
   float* x_out = nullptr;         // folded residual stream (written by block chunk 0 / head 0 of each window)
   const float* ln_g = nullptr; const float* ln_b = nullptr; float ln_eps = 0.f; int ln_inside = 0;
   const float* Wq = nullptr;      // [d][d] row-major
+  // fused out-projection (optional): Wo [d][d]; records {m, l, P[d]} go to rec [n_head * n_chunks][S][2 + d]
+  const float* Wo = nullptr;
+  float* rec = nullptr;
 };
 bool cross_attn_can_fuse_q(int d);
 void launch_dec_cross_attn(hipStream_t st, const int* state, const StepLayout& lay, int n_windows, int n_head,
@@ -129,10 +132,14 @@ void launch_dec_logprob_row(hipStream_t st, const float* x, int KS, int64_t plan
 struct MlpFusedArgs {
   const int* st = nullptr; int S = 0, d = 0;
   const float* x_in = nullptr; const float* pend = nullptr; int KSp = 0; const float* pbias = nullptr; float* x_out = nullptr;
+  // n_chunks > 0: `pend` holds cross-attention chunk records [n_head * n_chunks][S][2 + d] = {m, l, o_chunk Wo} instead of
+  // plain partial planes (KSp = n_head * n_chunks): the fold weights plane (h, c) by exp(m_hc - M_h) / sum_c exp(..) l_hc
+  int n_head = 0, n_chunks = 0;
   const float* ln_g = nullptr; const float* ln_b = nullptr; float ln_eps = 0.f; int ln_inside = 0;
   const float* W1 = nullptr; int ld1 = 0; const float* b1 = nullptr;     // [d][4d], [4d]
   const float* W2 = nullptr;                                             // [4d][d]
   float* P = nullptr;                                                    // out: planes [4d / 64][S][d] (lin2 bias NOT added)
+  unsigned long long* stamps = nullptr;                                  // developer probe (-DWB_STAMPS): phase clock of block 0
 };
 struct AttnFusedArgs {
   const int* st = nullptr; StepLayout lay; int S = 0, d = 0, n_head = 0;
@@ -142,6 +149,7 @@ struct AttnFusedArgs {
   float* Kc = nullptr; float* Vc = nullptr; const int* tabs = nullptr; int Lmax = 0;            // this layer's cache
   const float* Wo = nullptr;                                                                    // [d][d]
   float* P = nullptr;                                                    // out: planes [n_head][S][d] (out bias NOT added)
+  unsigned long long* stamps = nullptr;                                  // developer probe (-DWB_STAMPS): phase clock of block 0
 };
 bool dec_fused_supported(int d);
 int dec_mlp_fused_planes(int d);

@@ -215,6 +215,8 @@ __global__ __launch_bounds__(256, (MR >= 8 && DPL >= 16) ? 1 : 2) void dec_gemv_
   };
   const int nit = (kn + 2 * KH - 1) / (2 * KH);   // rounds of 2 KH rows
   load_round(w[0], 0);   // first weight tiles in flight before the prologue touches memory
+  if (n_rows == 0) return;   // chained decode whose windows have all finished (checked AFTER the loads were issued: the
+                             // scalar state load must not sit in front of the weight stream)
 
   {
     constexpr int r0 = 0;     // the host picks MR >= the live row count: one pass over the rows
@@ -389,14 +391,19 @@ __global__ __launch_bounds__(256, (MR >= 8 && DPL >= 16) ? 1 : 2) void dec_gemv_
 }
 
 // device-chained greedy: the argmax feeds the next step, tokens stay on the device
-__device__ __forceinline__ void chained_update(const int* st, const StepLayout& lay, int* gctl, int* gtok, int Lmax,
+// When the last unfinished window ends, the step state is blanked (ST_N = 0): the host enqueues decode chunks ahead
+// of reading the finished flags, and every kernel of an already-enqueued step then exits at its first instruction.
+__device__ __forceinline__ void chained_update(int* st, const StepLayout& lay, int* gctl, int* gtok, int Lmax,
                                                int eot, int r, int gi) {
   const int len = st[lay.len + r];
   gctl[GC_HDR + r] = gi;
   if (!gctl[GC_HDR + lay.S + r]) {
     gtok[r * Lmax + len] = gi;
     gctl[GC_HDR + 2 * lay.S + r] = len + 1;
-    if (gi == eot) gctl[GC_HDR + lay.S + r] = 1;   // finished (transcribe.rs:235-241): later tokens are ignored
+    if (gi == eot) {
+      gctl[GC_HDR + lay.S + r] = 1;                // finished (transcribe.rs:235-241): later tokens are ignored
+      if (atomicAdd(&gctl[GC_NDONE], 1) + 1 == lay.W) { gctl[GC_ALLDONE] = 1; st[ST_N] = 0; }
+    }
   }
   if (r == 0) gctl[GC_STEP] = st[ST_STEP] + 1;
 }
@@ -598,6 +605,9 @@ constexpr int CA_CH = 128;   // keys per chunk
 // of Wq that belong to its head (thread = output column x quarter of K, the weight slice prefetched into
 // registers at kernel start); block (chunk 0, head 0) writes the folded residual stream.  This saves the
 // LN + Wq GEMV launch of every decoder layer; the slice is re-read by the key-chunk blocks of the head (L2).
+// fz.Wo != nullptr: the block also applies its head's 64 rows of the out-projection to its (unnormalised) chunk output
+// and writes {m, l, o_chunk Wo[head rows, :]} records -- the out-projection GEMV launch disappears, the consumer
+// (dec_mlp_fused_kernel) combines the chunk records of all heads while it folds the residual stream.
 template <int NB, int KQ>    // NB: register-resident beams per window (>= the largest live count this step)
 __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const int* __restrict__ st, StepLayout lay,
                                                              const float* __restrict__ Pq, int KS,
@@ -616,12 +626,20 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const int* __restri
   __shared__ __attribute__((aligned(16))) float ored[4][MAX_BEAMS][64];
   const int c = blockIdx.x, h = blockIdx.y, w = blockIdx.z, tid = threadIdx.x;
   const int nb = st[lay.win_nb + w];
-  if (nb == 0) return;
+  if (nb == 0 || st[ST_N] == 0) return;            // (ST_N == 0: a chained decode whose windows have all finished)
   const int* slots = st + lay.win_slots + w * MAX_BEAMS;
   const int C = win_C[w];
   const int j0 = c * CA_CH;
   const int nk = min(CA_CH, C - j0);
   if (nk <= 0) {   // chunk past this window's encoder length: neutral partial
+    if (fz.Wo != nullptr) {
+      const int64_t rstride = d + 2;
+      for (int e = tid; e < nb * (int)rstride; e += 256) {
+        const int b = e / (int)rstride, f = e - b * (int)rstride;
+        fz.rec[((int64_t)(h * n_chunks + c) * lay.S + slots[b]) * rstride + f] = (f == 0) ? -1.0e30f : 0.f;
+      }
+      return;
+    }
     for (int e = tid; e < nb * CA_STRIDE; e += 256) {
       const int b = e / CA_STRIDE, f = e - b * CA_STRIDE;
       ca[((int64_t)(slots[b] * n_head + h) * n_chunks + c) * CA_STRIDE + f] = (f == 0) ? -1.0e30f : 0.f;
@@ -644,6 +662,12 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const int* __restri
     const int j = gq * 32 + i;
     vreg[i] = j < nk ? Vb[(int64_t)j * ldkv + dh_t] : 0.f;
   }
+  // fused out-projection (KQ > 0 variants): thread (cf, jg) owns a float4 of output columns and RPGW rows of Wo's
+  // head slice; requested as soon as the Wq registers are free, consumed in the epilogue
+  constexpr int DD = KQ > 0 ? 4 * KQ : 128, CFW = DD / 4, GW = 256 / CFW >= 8 ? 8 : 2, RPGW = 64 / GW;
+  const int cfw = tid % CFW, jgw = tid / CFW;
+  const bool actw = jgw < GW;
+  float4 wo[KQ > 0 ? RPGW : 1];
   if constexpr (KQ > 0) {
     // this thread's slice of Wq: column h*64 + dh_t, rows gq*KQ .. +KQ (in flight with everything above; 16-byte
     // loads with 16 K-groups per block measured slower: 1167x vs 1308x)
@@ -703,6 +727,11 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const int* __restri
       }
 #pragma unroll
       for (int b = 0; b < NB; b++) ored[gq][b][dh_t] = acc[b];
+    }
+    if (fz.Wo != nullptr) {                        // (uniform) the Wq registers are dead: request the Wo slice
+      const float* wp = fz.Wo + (int64_t)(h * 64 + (actw ? jgw : 0) * RPGW) * DD + cfw * 4;
+#pragma unroll
+      for (int i = 0; i < RPGW; i++) wo[i] = *reinterpret_cast<const float4*>(wp + (int64_t)i * DD);
     }
     __syncthreads();
     for (int e = tid; e < nb * 64; e += 256) {
@@ -766,11 +795,64 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const int* __restri
     for (int b = 0; b < NB; b++) ored[gq][b][dh_t] = o[b];
   }
   __syncthreads();
+  if (fz.Wo == nullptr) {
+    for (int e = tid; e < nb * 64; e += 256) {
+      const int b = e >> 6, dh = e & 63;
+      float* dst = ca + ((int64_t)(slots[b] * n_head + h) * n_chunks + c) * CA_STRIDE;
+      dst[2 + dh] = (ored[0][b][dh] + ored[1][b][dh]) + (ored[2][b][dh] + ored[3][b][dh]);
+      if (dh == 0) { dst[0] = stat[b][0]; dst[1] = stat[b][1]; }
+    }
+    return;
+  }
+  // ---- fused out-projection: P[b][:] = o_chunk[b][:] Wo[h*64 .. h*64+64][:]  (mod.rs:489 is linear: the chunk
+  // combine and the softmax normalisation commute with it and are applied by the consumer)
   for (int e = tid; e < nb * 64; e += 256) {
     const int b = e >> 6, dh = e & 63;
-    float* dst = ca + ((int64_t)(slots[b] * n_head + h) * n_chunks + c) * CA_STRIDE;
-    dst[2 + dh] = (ored[0][b][dh] + ored[1][b][dh]) + (ored[2][b][dh] + ored[3][b][dh]);
-    if (dh == 0) { dst[0] = stat[b][0]; dst[1] = stat[b][1]; }
+    qs[b][dh] = (ored[0][b][dh] + ored[1][b][dh]) + (ored[2][b][dh] + ored[3][b][dh]);   // (the queries are dead)
+  }
+  __syncthreads();
+  if constexpr (KQ > 0) {
+    float o4[NB][4];
+#pragma unroll
+    for (int b = 0; b < NB; b++) { o4[b][0] = o4[b][1] = o4[b][2] = o4[b][3] = 0.f; }
+    const int jb = (actw ? jgw : 0) * RPGW;
+#pragma unroll
+    for (int i = 0; i < RPGW; i++) {
+#pragma unroll
+      for (int b = 0; b < NB; b++) {
+        const float av = qs[b][jb + i];
+        o4[b][0] += av * wo[i].x; o4[b][1] += av * wo[i].y; o4[b][2] += av * wo[i].z; o4[b][3] += av * wo[i].w;
+      }
+    }
+    float* obuf = &Kt[0][0];                        // [GW - 1][NB][DD] floats <= 7 * 8 * 128 or 1 * 8 * 512 < 128 * 65
+    if (actw && jgw > 0) {
+#pragma unroll
+      for (int b = 0; b < NB; b++)
+        *reinterpret_cast<float4*>(&obuf[((jgw - 1) * NB + b) * DD + cfw * 4]) = make_float4(o4[b][0], o4[b][1], o4[b][2], o4[b][3]);
+    }
+    __syncthreads();
+    if (jgw == 0) {
+#pragma unroll
+      for (int g2 = 1; g2 < GW; g2++) {             // group order fixed: deterministic sums
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+          const float4 t = *reinterpret_cast<const float4*>(&obuf[((g2 - 1) * NB + b) * DD + cfw * 4]);
+          o4[b][0] += t.x; o4[b][1] += t.y; o4[b][2] += t.z; o4[b][3] += t.w;
+        }
+      }
+      // record layout: [plane = h * n_chunks + c][S][2 + d]
+      constexpr int RS = DD + 2;
+      float* base = fz.rec + (int64_t)(h * n_chunks + c) * lay.S * RS;
+#pragma unroll
+      for (int b = 0; b < NB; b++) {
+        if (b < nb) {
+          float* dst = base + (int64_t)slots[b] * RS;
+          dst[2 + cfw * 4 + 0] = o4[b][0]; dst[2 + cfw * 4 + 1] = o4[b][1];
+          dst[2 + cfw * 4 + 2] = o4[b][2]; dst[2 + cfw * 4 + 3] = o4[b][3];
+          if (cfw == 0) { dst[0] = stat[b][0]; dst[1] = stat[b][1]; }
+        }
+      }
+    }
   }
 }
 
@@ -859,7 +941,7 @@ __global__ __launch_bounds__(1024) void dec_topk_rows_kernel(const int* __restri
     if (tid == 0) {
       out_id[r * TOPK_MAX + round] = gi;
       out_lp[r * TOPK_MAX + round] = (gv - M) - lse;
-      if (gctl && round == 0) chained_update(st, lay, gctl, gtok, Lmax, eot, r, gi);
+      if (gctl && round == 0) chained_update(const_cast<int*>(st), lay, gctl, gtok, Lmax, eot, r, gi);
     }
     if (ti[0] == gi) {
 #pragma unroll

@@ -21,6 +21,17 @@
 namespace wb {
 namespace {
 
+// developer probe: tools/decode_probe.cpp builds this file with -DWB_STAMPS and prints the phase timeline of block 0
+#ifdef WB_STAMPS
+#define WB_STAMP_DECL __shared__ unsigned long long stamp_buf[16]
+#define WB_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) stamp_buf[i] = wall_clock64(); } while (0)
+#define WB_STAMP_FLUSH(a, n) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && (a).stamps) for (int _i = 0; _i < (n); _i++) (a).stamps[_i] = stamp_buf[_i]; } while (0)
+#else
+#define WB_STAMP_DECL
+#define WB_STAMP(i) do {} while (0)
+#define WB_STAMP_FLUSH(a, n) do {} while (0)
+#endif
+
 constexpr int FD_MAX = 512;      // largest n_state of the fused path (test models 128, tiny.en 384, base.en 512)
 constexpr int FA_MAXPOS = 448;   // n_text_ctx
 
@@ -151,7 +162,7 @@ __device__ __forceinline__ void ln_row_lds(float* __restrict__ row, int d, int l
 // Phase 1: 16 lanes x float4 cover the 64 slice columns of one W1 row; thread (rg = tid / 16, c4) owns rows
 // rg, rg + 32, ... (d / 32 of them).  Phase 2: thread (cf = tid % (d / 4), jg = tid / (d / 4)) owns a float4 of
 // output columns and 64 / G rows of the W2 slice.
-template <int MR, int DPL>
+template <int MR, int DPL, bool REC>
 __global__ __launch_bounds__(512) void dec_mlp_fused_kernel(MlpFusedArgs a) {
   constexpr int HS = 64, NT = 512;
   constexpr int d = 64 * DPL;
@@ -164,45 +175,128 @@ __global__ __launch_bounds__(512) void dec_mlp_fused_kernel(MlpFusedArgs a) {
   __shared__ __attribute__((aligned(16))) float red[8][MR][HS];         // per-wave partial hidden sums
   __shared__ __attribute__((aligned(16))) float hid[MR][HS];            // GELU(hidden slice)
   __shared__ __attribute__((aligned(16))) float obuf[(G - 1) * MR * d]; // phase-2 partials of row groups >= 1
+  __shared__ float mlb[REC ? MR : 1][48][2];                            // record mode: (m, l) of every (head, chunk)
+  __shared__ float coef[REC ? MR : 1][48];                              // ... and its flash-combine weight
+  WB_STAMP_DECL;
+  WB_STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j0 = blockIdx.x * HS;
   const int rg = tid >> 4, c4 = (tid & 15) * 4;
+  // Requested up front, in the order of use (loads return in order): fold operands, LayerNorm parameters, bias, the W1
+  // slice, the W2 slice.  No global STORE before the last phase (a pending store makes every __syncthreads a vmcnt(0)).
+  float xv_fold[EPT];
   constexpr int NW1 = d / 32;
   float4 w1[NW1];
-  {
-    const float* wp = a.W1 + (int64_t)rg * a.ld1 + j0 + c4;
-#pragma unroll
-    for (int i = 0; i < NW1; i++) w1[i] = *reinterpret_cast<const float4*>(wp + (int64_t)(32 * i) * a.ld1);
-  }
   const int cf = tid % CF, jg = tid / CF;
   const bool p2 = jg < G;
   const int jb = (p2 ? jg : 0) * RPG;
   float4 w2[RPG];
-  {
-    const float* wp = a.W2 + (int64_t)(j0 + jb) * d + cf * 4;
-#pragma unroll
-    for (int i = 0; i < RPG; i++) w2[i] = *reinterpret_cast<const float4*>(wp + (int64_t)i * d);
-  }
   float gv[DPL], bv[DPL];
-#pragma unroll
-  for (int i = 0; i < DPL; i++) { gv[i] = a.ln_g[lane + 64 * i]; bv[i] = a.ln_b[lane + 64 * i]; }
-  const float b1v = a.b1[j0 + (tid & 63)];
-  const int n_rows = a.st[ST_N];
+  float b1v;
   {
-    float v[EPT];
-    fold_rows<NT, MR, EPT, PCH>(a.x_in, a.pend, a.KSp, (int64_t)a.S * d, a.pbias, d, tid, v);
+    int off[EPT], col[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; i++) {
+      int e = tid + NT * i;
+      if (e >= MR * d) e = tid;
+      off[i] = e; col[i] = e % d;
+    }
+    float acc0[EPT];
+    constexpr bool rec = REC;                        // pend = cross-attention chunk records {m, l, P[d]}
+    const int64_t plane = rec ? (int64_t)a.S * (d + 2) : (int64_t)a.S * d;
+    int poff[EPT];                                   // element offset inside a plane / record plane
+#pragma unroll
+    for (int i = 0; i < EPT; i++) poff[i] = rec ? (off[i] / d) * (d + 2) + 2 + col[i] : off[i];
+    constexpr int PCHR = EPT <= 3 ? 18 : EPT <= 4 ? 16 : EPT <= 6 ? 12 : 8;
+    constexpr int PC = REC ? PCHR : PCH;
+    float t[PC][EPT];
+    const int npl = a.KSp;
+    const int ch = rec ? PCHR : PCH;                 // planes per round
+#pragma unroll
+    for (int i = 0; i < EPT; i++) { xv_fold[i] = a.x_in[off[i]]; acc0[i] = npl > 0 ? a.pbias[col[i]] : 0.f; }
+    float mlv0 = -1.0e30f, mlv1 = 0.f;
+    if (rec && tid < MR * npl) {                     // (m, l) of record (row tid / npl, plane tid % npl)
+      const float* rp = a.pend + (int64_t)(tid % npl) * plane + (int64_t)(tid / npl) * (d + 2);
+      mlv0 = rp[0]; mlv1 = rp[1];
+    }
+    if (npl > 0) {
+#pragma unroll
+      for (int j = 0; j < PC; j++)
+        if (j < ch) {
+#pragma unroll
+          for (int i = 0; i < EPT; i++) t[j][i] = a.pend[(int64_t)min(j, npl - 1) * plane + poff[i]];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < DPL; i++) { gv[i] = a.ln_g[lane + 64 * i]; bv[i] = a.ln_b[lane + 64 * i]; }
+    b1v = a.b1[j0 + (tid & 63)];
+    {
+      const float* wp = a.W1 + (int64_t)rg * a.ld1 + j0 + c4;
+#pragma unroll
+      for (int i = 0; i < NW1; i++) w1[i] = *reinterpret_cast<const float4*>(wp + (int64_t)(32 * i) * a.ld1);
+    }
+    {
+      const float* wp = a.W2 + (int64_t)(j0 + jb) * d + cf * 4;
+#pragma unroll
+      for (int i = 0; i < RPG; i++) w2[i] = *reinterpret_cast<const float4*>(wp + (int64_t)i * d);
+    }
+    if constexpr (REC) {
+      // flash-combine weights: coef[r][h][c] = exp(m_hc - M_h) / sum_c' exp(m_hc' - M_h) l_hc'  (mod.rs:529 softmax,
+      // split over key chunks by dec_cross_attn_kernel)
+      if (tid < MR * npl) { mlb[tid / npl][tid % npl][0] = mlv0; mlb[tid / npl][tid % npl][1] = mlv1; }
+      __syncthreads();
+      if (tid < MR * a.n_head) {
+        const int r = tid / a.n_head, hh = tid % a.n_head;
+        float M = -1.0e30f;
+        for (int c = 0; c < a.n_chunks; c++) M = fmaxf(M, mlb[r][hh * a.n_chunks + c][0]);
+        float den = 0.f;
+        for (int c = 0; c < a.n_chunks; c++) den += expf(mlb[r][hh * a.n_chunks + c][0] - M) * mlb[r][hh * a.n_chunks + c][1];
+        for (int c = 0; c < a.n_chunks; c++)
+          coef[r][hh * a.n_chunks + c] = den > 0.f ? expf(mlb[r][hh * a.n_chunks + c][0] - M) / den : 0.f;
+      }
+      __syncthreads();
+    }
+    if (npl > 0) {
+      int rowi[EPT];
+#pragma unroll
+      for (int i = 0; i < EPT; i++) rowi[i] = off[i] / d;
+      for (int sp = 0; sp < npl; sp += ch) {
+        if (sp > 0) {
+#pragma unroll
+          for (int j = 0; j < PC; j++)
+            if (j < ch) {
+#pragma unroll
+              for (int i = 0; i < EPT; i++) t[j][i] = a.pend[(int64_t)min(sp + j, npl - 1) * plane + poff[i]];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PC; j++)
+          if (j < ch) {
+#pragma unroll
+            for (int i = 0; i < EPT; i++) {
+              const bool live = sp + j < npl;
+              float wgt = 1.f;
+              if constexpr (REC) wgt = coef[rowi[i]][min(sp + j, npl - 1)];
+              acc0[i] += live ? wgt * t[j][i] : 0.f;                                        // plane order fixed
+            }
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < EPT; i++) xv_fold[i] += acc0[i];                               // x + (bias + partials)  (mod.rs:346-348)
+    }
 #pragma unroll
     for (int i = 0; i < EPT; i++) {
       const int e = tid + NT * i;
-      if (e < MR * d) {
-        (&hs[0][0])[e] = v[i];
-        if (blockIdx.x == 0 && e < n_rows * d) a.x_out[e] = v[i];
-      }
+      if (e < MR * d) (&hs[0][0])[e] = xv_fold[i];
     }
   }
+  const int n_rows = a.st[ST_N];
+  if (n_rows == 0) return;                         // chained decode, every window finished (block-uniform)
+  WB_STAMP(1);
   __syncthreads();
   if (wave < MR) ln_row_lds<DPL>(hs[wave], d, lane, gv, bv, a.ln_eps, a.ln_inside);
   __syncthreads();
+  WB_STAMP(2);
   float acc[MR][4];
 #pragma unroll
   for (int r = 0; r < MR; r++) { acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.f; }
@@ -234,6 +328,7 @@ __global__ __launch_bounds__(512) void dec_mlp_fused_kernel(MlpFusedArgs a) {
     hid[r][c] = gelu_erf_f(v + b1v);                                    // mod.rs:377-378
   }
   __syncthreads();
+  WB_STAMP(3);
   float o[MR][4];
 #pragma unroll
   for (int r = 0; r < MR; r++) { o[r][0] = o[r][1] = o[r][2] = o[r][3] = 0.f; }
@@ -266,6 +361,15 @@ __global__ __launch_bounds__(512) void dec_mlp_fused_kernel(MlpFusedArgs a) {
         *reinterpret_cast<float4*>(&a.P[((int64_t)blockIdx.x * a.S + r) * d + cf * 4]) =
             make_float4(o[r][0], o[r][1], o[r][2], o[r][3]);
   }
+  if (blockIdx.x == 0) {                           // the folded residual stream, off the critical path
+#pragma unroll
+    for (int i = 0; i < EPT; i++) {
+      const int e = tid + NT * i;
+      if (e < n_rows * d) a.x_out[e] = xv_fold[i];
+    }
+  }
+  WB_STAMP(4);
+  WB_STAMP_FLUSH(a, 5);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -281,7 +385,8 @@ __global__ __launch_bounds__(512) void dec_attn_fused_kernel(AttnFusedArgs a) {
   constexpr int NT = 512;
   constexpr int d = 64 * DPL;
   constexpr int KW = d / 8;                        // K rows per wave (16, 48, 64)
-  constexpr int NIT = KW / 16;
+  constexpr int RK = DPL >= 8 ? 8 : 16;            // K rows per weight round (d = 512: two 16-row rounds would spill)
+  constexpr int NIT = KW / RK;
   constexpr int CF = d / 4;
   constexpr int G = CF <= 32 ? 8 : 4;              // out-projection row groups (d = 128: 8 x 8 rows, 384 / 512: 4 x 16)
   constexpr int RPG = 64 / G;
@@ -294,55 +399,73 @@ __global__ __launch_bounds__(512) void dec_attn_fused_kernel(AttnFusedArgs a) {
   __shared__ __attribute__((aligned(16))) float ored[8][64];
   __shared__ __attribute__((aligned(16))) float att[64];
   __shared__ float lsum_s;
+  WB_STAMP_DECL;
+  WB_STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // grid = (8, rows): workgroups go round-robin over the 8 XCDs by linear id, so x = head puts every beam's block of
+  // one head on the SAME XCD -- the head's weight slices cross the fabric once and are shared through that L2
   const int h = blockIdx.x, r = blockIdx.y;
-  // ---- requested first: two QKV weight rounds, LayerNorm parameters, bias, the fold operands of row r
+  if (h >= a.n_head) return;
+  // ---- requested first, in this order (loads return in order: the fold must not queue behind the weights): the fold
+  // operands of row r, LayerNorm parameters (wave 0 normalises), bias, then two QKV weight rounds.
+  // No global STORE happens before the last phase: a pending store turns every __syncthreads into vmcnt(0).
   const int seg = lane >> 4, c4 = (lane & 15) * 4;
   const bool seg_ok = seg < 3;
   const float* wq = a.Wqkv + (int64_t)(wave * KW) * a.ldqkv + (seg_ok ? seg : 0) * d + h * 64 + c4;
-  float4 wr[2][16];
-  auto load_round = [&](float4 (&w)[16], int it) {
+  float4 wr[2][RK];
+  auto load_round = [&](float4 (&w)[RK], int it) {
 #pragma unroll
-    for (int j = 0; j < 16; j++) w[j] = *reinterpret_cast<const float4*>(wq + (int64_t)(16 * it + j) * a.ldqkv);
+    for (int j = 0; j < RK; j++) w[j] = *reinterpret_cast<const float4*>(wq + (int64_t)(RK * it + j) * a.ldqkv);
   };
-  load_round(wr[0], 0);
-  if (NIT > 1) load_round(wr[1], 1);
-  float gv[DPL], bv[DPL];
-#pragma unroll
-  for (int i = 0; i < DPL; i++) { gv[i] = a.ln_g[lane + 64 * i]; bv[i] = a.ln_b[lane + 64 * i]; }
-  const float qbias = tid < 192 ? a.bqkv[(tid >> 6) * d + h * 64 + (tid & 63)] : 0.f;   // key part is zero (mod.rs:402-404)
+  float xfold;                                     // this thread's element of x + pending (kept for the final x_out store)
+  float gv[DPL], bv[DPL];                          // LayerNorm parameters (wave 0 normalises)
   {
     // x + (bias + partial planes), s ascending (mod.rs:346-348): one element per thread, all planes in flight together
     const int c = tid < d ? tid : 0;
     const float* pp = a.pend + (int64_t)r * d + c;
     const int64_t plane = (int64_t)a.S * d;
     float v = a.x_in[(int64_t)r * d + c];
+    constexpr int FP = 32;                          // planes per round: 4 d / 64 <= 32 MLP planes in ONE round trip
+    float t[FP];
+    float accp = 0.f;
     if (a.KSp > 0) {
-      float accp = a.pbias[c];
-      for (int sp = 0; sp < a.KSp; sp += 16) {
-        float t[16];
+      accp = a.pbias[c];
 #pragma unroll
-        for (int j = 0; j < 16; j++) t[j] = pp[(int64_t)min(sp + j, a.KSp - 1) * plane];
+      for (int j = 0; j < FP; j++) t[j] = pp[(int64_t)min(j, a.KSp - 1) * plane];
+    }
+    if (wave == 0) {
 #pragma unroll
-        for (int j = 0; j < 16; j++) accp += (sp + j < a.KSp) ? t[j] : 0.f;
+      for (int i = 0; i < DPL; i++) { gv[i] = a.ln_g[lane + 64 * i]; bv[i] = a.ln_b[lane + 64 * i]; }
+    }
+    load_round(wr[0], 0);
+    if (NIT > 1) load_round(wr[1], 1);
+    if (a.KSp > 0) {
+#pragma unroll
+      for (int j = 0; j < FP; j++) accp += (j < a.KSp) ? t[j] : 0.f;
+      for (int sp = FP; sp < a.KSp; sp += FP) {
+#pragma unroll
+        for (int j = 0; j < FP; j++) t[j] = pp[(int64_t)min(sp + j, a.KSp - 1) * plane];
+#pragma unroll
+        for (int j = 0; j < FP; j++) accp += (sp + j < a.KSp) ? t[j] : 0.f;
       }
       v += accp;
     }
+    xfold = v;
     const int n_rows = a.st[ST_N];
     if (r >= n_rows) return;                       // (block-uniform)
-    if (tid < d) {
-      hs[tid] = v;
-      if (h == 0) a.x_out[(int64_t)r * d + tid] = v;
-    }
+    if (tid < d) hs[tid] = v;
   }
+  const float qbias = tid < 192 ? a.bqkv[(tid >> 6) * d + h * 64 + (tid & 63)] : 0.f;   // key part is zero (mod.rs:402-404)
   const int len = a.st[a.lay.len + r];
   {
     const int* tb = a.tabs + (size_t)(a.st[ST_STEP] & 1) * a.lay.S * a.Lmax + r * a.Lmax;
     for (int p = tid; p < len; p += NT) tbs[p] = tb[p];
   }
+  WB_STAMP(1);
   __syncthreads();
   if (wave == 0) ln_row_lds<DPL>(hs, d, lane, gv, bv, a.ln_eps, a.ln_inside);
   __syncthreads();
+  WB_STAMP(2);
   // ---- QKV for head h (rolled on purpose: unrolled, every round's loads are hoisted to the top and spill)
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
@@ -350,9 +473,9 @@ __global__ __launch_bounds__(512) void dec_attn_fused_kernel(AttnFusedArgs a) {
 #pragma unroll
     for (int b = 0; b < 2; b++) {
       if (it + b < NIT) {
-        const int kb = wave * KW + 16 * (it + b);
+        const int kb = wave * KW + RK * (it + b);
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
+        for (int j = 0; j < RK; j++) {
           const float xv = hs[kb + j];
           acc[0] += xv * wr[b][j].x; acc[1] += xv * wr[b][j].y; acc[2] += xv * wr[b][j].z; acc[3] += xv * wr[b][j].w;
         }
@@ -360,6 +483,7 @@ __global__ __launch_bounds__(512) void dec_attn_fused_kernel(AttnFusedArgs a) {
       }
     }
   }
+  WB_STAMP(3);
   __syncthreads();   // (also pins the loads below -- their addresses come from LDS -- behind the FMAs)
   // ---- requested now: the cached K row of position p = tid and the Wo slice
   float4 kpre[16];
@@ -388,11 +512,7 @@ __global__ __launch_bounds__(512) void dec_attn_fused_kernel(AttnFusedArgs a) {
     qkv[tid] = v;
   }
   __syncthreads();
-  // ---- append k * s, v of the new token to the cache
-  if (tid >= 64 && tid < 192) {
-    float* dst = (tid < 128 ? a.Kc : a.Vc) + (int64_t)tbs[len - 1] * d + h * 64 + (tid & 63);
-    *dst = qkv[tid];
-  }
+  WB_STAMP(4);
   // ---- scores: thread = cached position (len <= 448 < 512); the new token attends to itself from LDS
   if (tid < len - 1) {
     float s = 0.f;
@@ -408,6 +528,7 @@ __global__ __launch_bounds__(512) void dec_attn_fused_kernel(AttnFusedArgs a) {
     sc[tid] = s;
   }
   __syncthreads();
+  WB_STAMP(5);
   // ---- V columns of this wave's positions (p = wave mod 8): requested before the softmax statistics are known
   const float* vbase = a.Vc + h * 64;              // uniform base + 32-bit lane offsets
   float vv[16];
@@ -452,6 +573,7 @@ __global__ __launch_bounds__(512) void dec_attn_fused_kernel(AttnFusedArgs a) {
     att[tid] = v / lsum_s;
   }
   __syncthreads();
+  WB_STAMP(6);
   // ---- plane h, row r = att Wo[head h rows, :]
   float ov[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -470,6 +592,14 @@ __global__ __launch_bounds__(512) void dec_attn_fused_kernel(AttnFusedArgs a) {
     }
     *reinterpret_cast<float4*>(&a.P[((int64_t)h * a.S + r) * d + cf * 4]) = make_float4(ov[0], ov[1], ov[2], ov[3]);
   }
+  // ---- the stores that are not on anybody's critical path: k * s, v of the new token into the cache, the folded stream
+  if (tid >= 64 && tid < 192) {
+    float* dst = (tid < 128 ? a.Kc : a.Vc) + (int64_t)tbs[len - 1] * d + h * 64 + (tid & 63);
+    *dst = qkv[tid];
+  }
+  if (h == 0 && tid < d) a.x_out[(int64_t)r * d + tid] = xfold;
+  WB_STAMP(7);
+  WB_STAMP_FLUSH(a, 8);
 }
 
 }  // namespace
@@ -479,7 +609,11 @@ int dec_mlp_fused_planes(int d) { return 4 * d / 64; }
 
 void launch_dec_mlp_fused(hipStream_t st, const MlpFusedArgs& a, int n_rows_hint) {
   const dim3 grid(4 * a.d / 64), block(512);
-#define WB_MLP(MR_, DPL_) WB_KLAUNCH((dec_mlp_fused_kernel<MR_, DPL_>), grid, block, 0, st, a)
+#define WB_MLP(MR_, DPL_)                                                                          \
+  do {                                                                                             \
+    if (a.n_chunks > 0) WB_KLAUNCH((dec_mlp_fused_kernel<MR_, DPL_, true>), grid, block, 0, st, a); \
+    else WB_KLAUNCH((dec_mlp_fused_kernel<MR_, DPL_, false>), grid, block, 0, st, a);               \
+  } while (0)
   if (n_rows_hint <= 4) {
     if (a.d == 128) WB_MLP(4, 2); else if (a.d == 384) WB_MLP(4, 6); else WB_MLP(4, 8);
   } else {
@@ -489,7 +623,7 @@ void launch_dec_mlp_fused(hipStream_t st, const MlpFusedArgs& a, int n_rows_hint
 }
 
 void launch_dec_attn_fused(hipStream_t st, const AttnFusedArgs& a, int n_rows_hint) {
-  const dim3 grid(a.n_head, n_rows_hint), block(512);
+  const dim3 grid(a.n_head <= 8 ? 8 : a.n_head, n_rows_hint), block(512);
   if (a.d == 128) WB_KLAUNCH((dec_attn_fused_kernel<2>), grid, block, 0, st, a);
   else if (a.d == 384) WB_KLAUNCH((dec_attn_fused_kernel<6>), grid, block, 0, st, a);
   else WB_KLAUNCH((dec_attn_fused_kernel<8>), grid, block, 0, st, a);

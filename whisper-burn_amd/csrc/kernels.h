@@ -26,16 +26,16 @@ struct MelWindow {            // one window of PCM
   int32_t reserved;
 };
 
-// log10(max(mel,1e-10)) for every (window, mel row, frame) + per-block maxima (pass 1).
-// out[w][m][t] at out + w*win_stride + m*row_stride + t.  bmax: n_windows * mel_bmax_stride(max_frames) floats.
+// (log10(max(mel,1e-10)) + 4) / 4 for every (window, mel row, frame), zeros for the frames [n_emit, n_emit + pad) below
+// pad_limit, + per-tile (max, min) of the un-normalised values.
+// out[w][m][t] at out + w*win_stride + m*row_stride + t.  bmax: n_windows * mel_bmax_stride(max_frames) * 2 floats.
 int mel_bmax_stride(int max_frames);
 void launch_mel_spectrogram(hipStream_t st, const float* pcm, const MelWindow* wins_dev, int n_windows,
                             int max_frames, const MelTables* tabs_dev, float* out, int64_t win_stride,
-                            int row_stride, float* bmax_dev);
-// pass 2: max(x, gmax-8), (x+4)/4 ; frames [n_frames, n_frames+pad) := 0   (audio.rs:52-53, transcribe.rs:171-177)
-void launch_mel_finalize(hipStream_t st, const MelWindow* wins_dev, int n_windows, int max_frames_padded,
-                         int pad, float* out, int64_t win_stride, int row_stride, const float* bmax_dev,
-                         int max_frames);
+                            int row_stride, float* bmax_dev, int pad, int pad_limit);
+// clamp fix-up: max(x, gmax - 8) (audio.rs:52) on the tiles that need it (normally none: the log-mel is written once)
+void launch_mel_finalize(hipStream_t st, const MelWindow* wins_dev, int n_windows, float* out, int64_t win_stride,
+                         int row_stride, const float* bmax_dev, int max_frames);
 void launch_fill_f32(hipStream_t st, float* p, int64_t n, float v);
 // 16-bit PCM -> f32 with the reference's scale s / 32767 (bin/transcribe/main.rs:45-52), correctly rounded division
 void launch_pcm_s16_to_f32(hipStream_t st, const int16_t* src, int64_t n, float* dst);

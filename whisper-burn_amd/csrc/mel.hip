@@ -2,7 +2,7 @@
 //
 // Replaces /root/reference/src/audio.rs:34-56 (prep_audio) + :284-367 (stfft: dense DFT by
 // two [201x400]x[400xT] f32 matmuls, ~60 tiny launches and 3 blocking D2H reads per window)
-// with one launch per batch of windows plus a small finalize pass:
+// with one launch per batch of windows plus a clamp fix-up launch that normally touches no tile:
 //   stage 0  interior blocks copy their 32 frame rows as 16-byte pieces (overlaps served by L1); blocks at a
 //            window edge read their contiguous PCM span (5360 samples) once with reflect indexing
 //            (audio.rs:297-306; no materialised padded copy) and scatter each sample to its <= 3 frame rows
@@ -15,7 +15,8 @@
 //            unpredicated 4-tap chunks of broadcast LDS reads), relu(x-1e-10)+1e-10, ln(x)/ln10
 //            (helper.rs:8-10, :24-27), block maximum (no atomics)
 //   stage 5  16-byte stores of the [80][32] tile
-// finalize: window max over the block maxima (audio.rs:50), max(x, max-8), (x+4)/4, zero padding frames.
+//            of (x + 4) / 4 (audio.rs:53); zero padding frames (transcribe.rs:171-177)
+// fix-up:  window max over the tile maxima (audio.rs:50); tiles whose minimum is below max - 8 are clamped (audio.rs:52).
 // Bound: HBM (640 B PCM in + 320 B mel out per frame); ~11 kFLOP per frame of f32 VALU.
 //
 // Geometry: block = 320 threads = 16 pairs x 20 lanes; a pair transforms frames (2p, 2p+1) of the
@@ -29,10 +30,6 @@
 
 #include "kernels.h"
 #include "wave_ops.h"
-
-#ifndef MEL_STAGE_LIMIT
-#define MEL_STAGE_LIMIT 99   // developer probe (tools/mel_probe.cpp): cut the kernel after stage N
-#endif
 
 namespace wb {
 
@@ -110,15 +107,26 @@ __device__ __forceinline__ void dft20(cpx (&x)[20]) {
 
 __global__ __launch_bounds__(MEL_THREADS, 4) void mel_spectrogram_kernel(
     const float* __restrict__ pcm, const MelWindow* __restrict__ wins, const MelTables* __restrict__ tabs,
-    float* __restrict__ out, int64_t win_stride, int row_stride, float* __restrict__ gmax, int bmax_stride) {
+    float* __restrict__ out, int64_t win_stride, int row_stride, float* __restrict__ gmax, int bmax_stride, int pad,
+    int pad_limit) {
   // 16 x 852 floats = 54 528 B: three blocks per CU (163 584 B of the 160 KiB); every stage aliases the same
   // pair-private regions (frame rows -> U -> Z -> power spectra + this pair's 2 x 80 outputs)
   __shared__ __attribute__((aligned(16))) float lds[PAIRS * 2 * FROW];
 
   const MelWindow w = wins[blockIdx.y];
   const int f0 = blockIdx.x * FPB;
-  if (f0 >= w.n_frames) return;
   const int tid = threadIdx.x;
+  const int zend = min(w.n_emit + pad, pad_limit);            // frames [n_emit, zend) := 0  (transcribe.rs:171-177)
+  if (f0 >= w.n_frames) {
+    // past the last frame: at most the zero padding frames fall into this tile
+    if (tid == 0) { gmax[((int64_t)blockIdx.y * bmax_stride + blockIdx.x) * 2] = -INFINITY; gmax[((int64_t)blockIdx.y * bmax_stride + blockIdx.x) * 2 + 1] = INFINITY; }
+    float* oz = out + (int64_t)blockIdx.y * win_stride;
+    for (int e = tid; e < MEL_N_MELS * FPB; e += MEL_THREADS) {
+      const int m = e / FPB, f = f0 + (e - m * FPB);
+      if (f >= w.n_emit && f < zend) oz[(int64_t)m * row_stride + f] = 0.f;
+    }
+    return;
+  }
   const int N = w.n_samples;
   const float* x = pcm + w.pcm_off;
   static_assert(MEL_N_MELS * MEL_MAX_TAPS == MEL_THREADS * 4, "one float4 of taps per thread");
@@ -175,7 +183,6 @@ __global__ __launch_bounds__(MEL_THREADS, 4) void mel_spectrogram_kernel(
   }
   __syncthreads();
 
-  if constexpr (MEL_STAGE_LIMIT <= 0) { if (lds[tid] == 123.456f) out[0] = 1.f; return; }
   const int p = tid / 20, q = tid - p * 20;
   float* reg = lds + p * 2 * FROW;   // this pair's private region
   // this lane's constants (twiddles W400^{q k1}, filterbank rows q, q+20, q+40, q+60): one batch of loads
@@ -200,7 +207,6 @@ __global__ __launch_bounds__(MEL_THREADS, 4) void mel_spectrogram_kernel(
     U[k1 * UROW + q] = make_float2(v.re, v.im);
   }
   __syncthreads();
-  if constexpr (MEL_STAGE_LIMIT <= 1) { if (lds[tid] == 123.456f) out[0] = 1.f; return; }
   // ---- stage 2: 20-point DFT over n2 for k1 = q: Z[q + 20 k2] ----
 #pragma unroll
   for (int n2 = 0; n2 < 20; n2++) {
@@ -213,7 +219,6 @@ __global__ __launch_bounds__(MEL_THREADS, 4) void mel_spectrogram_kernel(
 #pragma unroll
   for (int k2 = 0; k2 < 20; k2++) Z[q + 20 * k2] = make_float2(z[k2].re, z[k2].im);
   __syncthreads();
-  if constexpr (MEL_STAGE_LIMIT <= 2) { if (lds[tid] == 123.456f) out[0] = 1.f; return; }
   // ---- stage 3: split the packed transform, power spectrum of both frames ----
   // A[k] = (Z[k] + conj Z[400-k]) / 2,  B[k] = (Z[k] - conj Z[400-k]) / (2i)
   // this thread's 4 of the 80 x 16 filterbank taps (+ start / length of row tid): requested here, they land under
@@ -249,12 +254,11 @@ __global__ __launch_bounds__(MEL_THREADS, 4) void mel_spectrogram_kernel(
     }
   }
   __syncthreads();
-  if constexpr (MEL_STAGE_LIMIT <= 3) { if (lds[tid] == 123.456f) out[0] = 1.f; return; }
   // ---- stage 4: sparse mel filterbank, log10, local max ----
   // lane = frame, half-wave = group of 8 mel rows: the filter taps are uniform over each half-wave
   // (broadcast LDS reads), the power spectra are the lane's own frame
   const float INV_LN10 = 0.43429448190325182765f;   // 1 / ln 10 (helper.rs:24-27 divides by ln 10)
-  float lmax = -INFINITY;
+  float lmax = -INFINITY, lmin = INFINITY;
   {
     const int f = tid & (FPB - 1), grp = tid >> 5;            // 10 groups x 8 rows
     float* fr_reg = lds + (f >> 1) * 2 * FROW;
@@ -272,7 +276,6 @@ __global__ __launch_bounds__(MEL_THREADS, 4) void mel_spectrogram_kernel(
       const int m = grp * 8 + r;
       const int s0 = s0v[r], len = lenv[r];
       float acc = 0.f;
-#if !defined(MEL_DBG_NOTAPS)
       const float* tw = lds + (m / 5) * 2 * FROW + TAP_OFF + (m % 5) * MEL_MAX_TAPS;   // uniform over the half-wave
       // taps past len are stored as zeros and Pf[s0 + t] stays inside the pair's region (finite FFT leftovers),
       // so a chunk of four needs no predicate: its eight LDS reads are in flight together
@@ -281,31 +284,28 @@ __global__ __launch_bounds__(MEL_THREADS, 4) void mel_spectrogram_kernel(
         const float p0 = Pf[s0 + t0], p1 = Pf[s0 + t0 + 1], p2 = Pf[s0 + t0 + 2], p3 = Pf[s0 + t0 + 3];
         acc += w4.x * p0; acc += w4.y * p1; acc += w4.z * p2; acc += w4.w * p3;
       }
-#else
-      acc = Pf[s0] + (float)len;
-#endif
       // tensor_max_scalar(x, 1e-10) = relu(x - 1e-10) + 1e-10 (helper.rs:8-10); log10 = ln/ln10 (:24-27)
-#if !defined(MEL_DBG_NOLOG)
       const float v = logf(fmaxf(acc - 1.0e-10f, 0.f) + 1.0e-10f) * INV_LN10;   // (x / ln10 up to 1 ulp; tolerance class "mel")
-#else
-      const float v = acc;
-#endif
-      fr_reg[OT_OFF + 2 * m + (f & 1)] = v;
+      // stored already normalised, (x + 4) / 4 (audio.rs:53); the clamp max(x, max - 8) (audio.rs:52) needs the window
+      // maximum and is applied by the fix-up pass -- only to tiles whose minimum is below it (rare: 80 dB down)
+      fr_reg[OT_OFF + 2 * m + (f & 1)] = (v + 4.0f) / 4.0f;
       if (live) lmax = fmaxf(lmax, v);
+      if (f0 + f < w.n_emit) lmin = fminf(lmin, v);
     }
   }
   lmax = wave_max(lmax);
-  if ((tid & 63) == 0) lds[BMAX_OFF + (tid >> 6)] = lmax;   // free tail of pair 0's region
+  lmin = -wave_max(-lmin);
+  if ((tid & 63) == 0) { lds[BMAX_OFF + (tid >> 6)] = lmax; lds[BMAX_OFF + 8 + (tid >> 6)] = lmin; }   // free tail of pair 0's region
   __syncthreads();
-  // one value per block, reduced by the finalize pass: no atomics (235 of them per window would
+  // one (max, min) pair per block, reduced by the fix-up pass: no atomics (235 of them per window would
   // serialise on one L2 word)
   if (tid == 0) {
-    float bm = lds[BMAX_OFF];
+    float bm = lds[BMAX_OFF], bn = lds[BMAX_OFF + 8];
 #pragma unroll
-    for (int i = 1; i < MEL_THREADS / 64; i++) bm = fmaxf(bm, lds[BMAX_OFF + i]);
-    gmax[(int64_t)blockIdx.y * bmax_stride + blockIdx.x] = bm;
+    for (int i = 1; i < MEL_THREADS / 64; i++) { bm = fmaxf(bm, lds[BMAX_OFF + i]); bn = fminf(bn, lds[BMAX_OFF + 8 + i]); }
+    gmax[((int64_t)blockIdx.y * bmax_stride + blockIdx.x) * 2] = bm;
+    gmax[((int64_t)blockIdx.y * bmax_stride + blockIdx.x) * 2 + 1] = bn;
   }
-  if constexpr (MEL_STAGE_LIMIT <= 4) { if (lds[tid] == 123.456f) out[0] = 1.f; return; }
   // ---- stage 5: coalesced store of the [80][32] tile ----
   float* o = out + (int64_t)blockIdx.y * win_stride + f0;
   const int nf = min(FPB, w.n_emit - f0);
@@ -321,39 +321,41 @@ __global__ __launch_bounds__(MEL_THREADS, 4) void mel_spectrogram_kernel(
     for (int e = tid; e < MEL_N_MELS * FPB; e += MEL_THREADS) {
       int m = e / FPB, f = e - m * FPB;
       if (f < nf) o[(int64_t)m * row_stride + f] = lds[(f >> 1) * 2 * FROW + OT_OFF + 2 * m + (f & 1)];
+      else if (f0 + f >= w.n_emit && f0 + f < zend) o[(int64_t)m * row_stride + f] = 0.f;
     }
   }
 }
 
-// one block per (mel row, window): the window maximum is reduced once per block, the row is rewritten in
-// 16-byte pieces
-__global__ __launch_bounds__(256) void mel_finalize_kernel(const MelWindow* __restrict__ wins, int max_frames_padded,
-                                                           int pad, float* __restrict__ out, int64_t win_stride,
-                                                           int row_stride, const float* __restrict__ bmax,
-                                                           int bmax_stride) {
+// Clamp fix-up (audio.rs:50-52): one block per (tile, window).  The window maximum is the maximum over the tiles'
+// maxima; a tile whose minimum is not below max - 8 needs nothing (the main kernel already stored (x + 4) / 4) and
+// its block exits after reading the per-tile (max, min) pairs -- for ordinary audio that is every tile, so the log-mel
+// is written ONCE.  A tile that does dip below (digital silence, 80 dB under the loudest bin of the window) is
+// rewritten: x < max - 8 gives (relu(x - m8) + m8 + 4) / 4 = (m8 + 4) / 4 exactly as the reference computes it.
+__global__ __launch_bounds__(256) void mel_clamp_fixup_kernel(const MelWindow* __restrict__ wins, float* __restrict__ out,
+                                                              int64_t win_stride, int row_stride,
+                                                              const float* __restrict__ bmm, int bmax_stride) {
   __shared__ float wmax;
-  const int m = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
-  if (tid < 64) {   // global max of the window (audio.rs:50) = max over its blocks' maxima
-    const int nblk = (wins[w].n_frames + FPB - 1) / FPB;
+  const int blk = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
+  const int nblk = (wins[w].n_frames + FPB - 1) / FPB;
+  if (blk >= nblk) return;
+  if (tid < 64) {   // global max of the window (audio.rs:50) = max over its tiles' maxima
     float v = -INFINITY;
-    for (int i = tid; i < nblk; i += 64) v = fmaxf(v, bmax[(int64_t)w * bmax_stride + i]);
+    for (int i = tid; i < nblk; i += 64) v = fmaxf(v, bmm[((int64_t)w * bmax_stride + i) * 2]);
     v = wave_max(v);
     if (tid == 0) wmax = v;
   }
   __syncthreads();
-  const int nf = wins[w].n_emit, end = min(nf + pad, max_frames_padded);
-  float* row = out + (int64_t)w * win_stride + (int64_t)m * row_stride;
   // audio.rs:50-53: max computed as f64 from the f32 max, (max - 8.0) handed back as f32
   const float m8 = (float)((double)wmax - 8.0);
-  auto norm = [&](float x) { return (fmaxf(x - m8, 0.f) + m8 + 4.0f) / 4.0f; };
-  const bool vec = (reinterpret_cast<uintptr_t>(row) & 15) == 0;
-  for (int t = tid * 4; t < end; t += 256 * 4) {
-    if (vec && t + 4 <= nf) {
-      float4 v = *reinterpret_cast<float4*>(row + t);
-      *reinterpret_cast<float4*>(row + t) = make_float4(norm(v.x), norm(v.y), norm(v.z), norm(v.w));
-    } else {
-      for (int k = t; k < min(t + 4, end); k++)
-        row[k] = k < nf ? norm(row[k]) : 0.f;   // k >= nf: transcribe.rs:171-177, zero frames in normalised log-mel space
+  if (bmm[((int64_t)w * bmax_stride + blk) * 2 + 1] >= m8) return;      // nothing in this tile is clamped
+  const float yfloor = (m8 + 4.0f) / 4.0f;                               // (relu(x - m8) + m8 + 4) / 4 for x < m8
+  const int f0 = blk * FPB, nf = min(FPB, wins[w].n_emit - f0);
+  float* o = out + (int64_t)w * win_stride + f0;
+  for (int e = tid; e < MEL_N_MELS * FPB; e += 256) {
+    const int m = e / FPB, f = e - m * FPB;
+    if (f < nf) {
+      float* q = o + (int64_t)m * row_stride + f;
+      *q = fmaxf(*q, yfloor);
     }
   }
 }
@@ -385,22 +387,22 @@ __global__ void fill_f32_kernel(float* p, int64_t n, float v) {
 
 }  // namespace
 
-int mel_bmax_stride(int max_frames) { return (max_frames + FPB - 1) / FPB; }
+int mel_bmax_stride(int max_frames) { return (max_frames + FPB - 1) / FPB + 48; }   // (+48: tiles that hold padding frames only)
 
 void launch_mel_spectrogram(hipStream_t st, const float* pcm, const MelWindow* wins_dev, int n_windows,
                             int max_frames, const MelTables* tabs_dev, float* out, int64_t win_stride,
-                            int row_stride, float* bmax_dev) {
-  dim3 grid((max_frames + FPB - 1) / FPB, n_windows);
+                            int row_stride, float* bmax_dev, int pad, int pad_limit) {
+  // tiles up to the last frame OR the last zero-padding frame of the longest window
+  dim3 grid((std::min(max_frames + pad, std::max(pad_limit, max_frames)) + FPB - 1) / FPB, n_windows);
   hipLaunchKernelGGL(mel_spectrogram_kernel, grid, dim3(MEL_THREADS), 0, st, pcm, wins_dev, tabs_dev, out,
-                     win_stride, row_stride, bmax_dev, mel_bmax_stride(max_frames));
+                     win_stride, row_stride, bmax_dev, mel_bmax_stride(max_frames), pad, pad_limit);
 }
 
-void launch_mel_finalize(hipStream_t st, const MelWindow* wins_dev, int n_windows, int max_frames_padded,
-                         int pad, float* out, int64_t win_stride, int row_stride, const float* bmax_dev,
-                         int max_frames) {
-  dim3 grid(MEL_N_MELS, n_windows);
-  hipLaunchKernelGGL(mel_finalize_kernel, grid, dim3(256), 0, st, wins_dev, max_frames_padded, pad, out,
-                     win_stride, row_stride, bmax_dev, mel_bmax_stride(max_frames));
+void launch_mel_finalize(hipStream_t st, const MelWindow* wins_dev, int n_windows, float* out, int64_t win_stride,
+                         int row_stride, const float* bmax_dev, int max_frames) {
+  dim3 grid((max_frames + FPB - 1) / FPB, n_windows);
+  hipLaunchKernelGGL(mel_clamp_fixup_kernel, grid, dim3(256), 0, st, wins_dev, out, win_stride, row_stride, bmax_dev,
+                     mel_bmax_stride(max_frames));
 }
 
 void launch_pcm_s16_to_f32(hipStream_t st, const int16_t* src, int64_t n, float* dst) {

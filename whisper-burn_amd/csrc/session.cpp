@@ -99,7 +99,7 @@ void session_pool_purge(wb_model* m) {
 static size_t session_device_bytes(const wb_session* s) {
   size_t n = 0;
   for (const DevMem* b : {&s->pcm, &s->mel, &s->wins, &s->gmax, &s->enc_out, &s->ckv, &s->win_meta, &s->kc, &s->vc,
-                          &s->tabs, &s->state, &s->x, &s->h, &s->att, &s->Pqkv, &s->Po, &s->Pq, &s->P1, &s->P2, &s->Pa, &s->ca,
+                          &s->tabs, &s->state, &s->x, &s->h, &s->att, &s->Pqkv, &s->Po, &s->Pq, &s->P1, &s->P2, &s->Pa, &s->carec, &s->ca,
                           &s->logits, &s->tstats, &s->row_stats, &s->mask, &s->lp_tmp, &s->gctl, &s->gtok, &s->hm,
                           &s->ws.x1, &s->ws.x, &s->ws.h, &s->ws.qkv, &s->ws.att, &s->ws.hm, &s->ws.desc1, &s->ws.desc2,
                           &s->ws.auxidx, &s->ws.segs, &s->ws.misc})
@@ -202,7 +202,7 @@ int session_encode_pcm(wb_session* s, const float* pcm, int64_t n_pcm, const int
   WB_TRY(get_mel_tables(m->device, s->sample_rate, &tabs));
   if (!pcm_on_device) WB_TRY(s->pcm.ensure((size_t)(hi - lo) * 4));
   WB_TRY(s->wins.ensure(wins.size() * sizeof(MelWindow)));
-  WB_TRY(s->gmax.ensure((size_t)s->W * mel_bmax_stride(maxF) * 4));
+  WB_TRY(s->gmax.ensure((size_t)s->W * mel_bmax_stride(maxF) * 2 * 4));
   WB_TRY(s->mel.ensure((size_t)s->W * 80 * Ts * 4));
   if (!pcm_on_device) WB_HIP(hipMemcpyAsync(s->pcm.p, pcm + lo, (size_t)(hi - lo) * 4, hipMemcpyHostToDevice, s->st));
   const float* pcm_dev = pcm_on_device ? pcm : s->pcm.as<float>();
@@ -211,9 +211,9 @@ int session_encode_pcm(wb_session* s, const float* pcm, int64_t n_pcm, const int
   {
     ScopedTimer tm(s->st, 0);
     launch_mel_spectrogram(s->st, pcm_dev, s->wins.as<MelWindow>(), s->W, maxF, tabs, s->mel.as<float>(),
-                           (int64_t)80 * Ts, Ts, s->gmax.as<float>());
-    launch_mel_finalize(s->st, s->wins.as<MelWindow>(), s->W, Ts, s->padding, s->mel.as<float>(), (int64_t)80 * Ts,
-                        Ts, s->gmax.as<float>(), maxF);
+                           (int64_t)80 * Ts, Ts, s->gmax.as<float>(), s->padding, Ts);
+    launch_mel_finalize(s->st, s->wins.as<MelWindow>(), s->W, s->mel.as<float>(), (int64_t)80 * Ts, Ts,
+                        s->gmax.as<float>(), maxF);
     tm.stop();
     if (tm.on) { WB_HIP(hipStreamSynchronize(s->st)); tm.collect(); profile().ms[5] += 1; }
   }
@@ -267,6 +267,7 @@ int session_reserve(wb_session* s, int max_len) {
   WB_TRY(s->P1.ensure((size_t)s->ks_1 * S * 4 * d * 4));
   WB_TRY(s->P2.ensure(((size_t)std::max(s->ks_2, dec_mlp_fused_planes(d)) * S + 8) * d * 4));
   WB_TRY(s->Pa.ensure(((size_t)D.n_text_head * S + 8) * d * 4));
+  WB_TRY(s->carec.ensure(((size_t)D.n_text_head * std::max(1, s->n_chunks) * S + 8) * (d + 2) * 4));
   WB_TRY(s->ca.ensure((size_t)S * D.n_text_head * std::max(1, s->n_chunks) * CA_STRIDE * 4));
   WB_TRY(s->logits.ensure((size_t)S * V * 4));
   WB_TRY(s->tstats.ensure((size_t)S * s->n_tiles_v * TS_STRIDE * 4));
@@ -286,6 +287,8 @@ void wb_session::clear_graphs() {
 wb_session::~wb_session() {
   clear_graphs();
   if (host_block) (void)hipHostFree(host_block);
+  if (ev_seg) (void)hipEventDestroy(ev_seg);
+  if (st2) (void)hipStreamDestroy(st2);
   if (st) (void)hipStreamDestroy(st);
 }
 
@@ -483,6 +486,10 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
   // sublayer fusion (decode_fused.hip): self-attention block and MLP block are ONE launch each
   static const bool fuse_sub_enabled = []() { const char* e = getenv("WHISPER_HIP_FUSE_SUB"); return !(e && e[0] == '0'); }();
   const bool fuse_sub = fuse_sub_enabled && dec_fused_supported(d) && m->compute_dtype != WB_BF16 && d == 64 * H;
+  // ... and the cross-attention blocks apply their head's rows of the out-projection (needs both fusions above)
+  // (opt-in: with 128-key chunks the MLP prologue has 6 H records per row to combine and loses what the launch saves)
+  static const bool fuse_co_enabled = []() { const char* e = getenv("WHISPER_HIP_FUSE_CO"); return e && e[0] == '1'; }();
+  const bool fuse_co = fuse_co_enabled && fuse_sub && fuse_q && H * s->n_chunks <= 48;
   const int nb_mlp = dec_mlp_fused_planes(d);
   const int ks_mlp = fuse_sub ? nb_mlp : s->ks_2;            // planes the MLP leaves pending
   for (int l = 0; l < NL; l++) {   // ResidualDecoderAttentionBlock::forward, mod.rs:345-350
@@ -520,7 +527,8 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
       fz.x_in = xb[xi]; fz.pend = att_planes; fz.KSp = att_ks; fz.pbias = b.out.b; fz.x_out = xb[xi ^ 1];
       fz.ln_g = b.ln2.g; fz.ln_b = b.ln2.b; fz.ln_eps = b.ln2.eps; fz.ln_inside = m->ln_eps_inside_sqrt;
       fz.Wq = b.cq.w;
-      prof_tag(KC_CROSS_ATTN, ckv_bytes + 4.0 * dd);
+      if (fuse_co) { fz.Wo = b.cout.w; fz.rec = s->carec.as<float>(); }
+      prof_tag(KC_CROSS_ATTN, ckv_bytes + 4.0 * dd * (fuse_co ? 2 : 1));
       launch_dec_cross_attn(st, dst, L, s->W, H, s->n_chunks, nullptr, 0, b.cq.b, d, s->ckv.as<float>(), ldkv,
                             l * 2 * d, win_row0, win_C, m->qk_scale, s->ca.as<float>(), max_nb, &fz);
       xi ^= 1;
@@ -532,7 +540,7 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
       launch_dec_cross_attn(st, dst, L, s->W, H, s->n_chunks, s->Pq.as<float>(), s->ks_o, b.cq.b, d,
                             s->ckv.as<float>(), ldkv, l * 2 * d, win_row0, win_C, m->qk_scale, s->ca.as<float>(), max_nb);
     }
-    {
+    if (!fuse_co) {
       GemvArgs a = gemv(b.cout, s->ks_o, s->ksl_o, PRO_ATTN, s->ca.as<float>(), 0, s->Po.as<float>());
       a.n_head = H; a.n_chunks = s->n_chunks;
       prof_tag(KC_GEMV_COUT, wsz * dd);
@@ -542,6 +550,9 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
       MlpFusedArgs ma;
       ma.st = dst; ma.S = S; ma.d = d;
       ma.x_in = xb[xi]; ma.pend = s->Po.as<float>(); ma.KSp = s->ks_o; ma.pbias = b.cout.b; ma.x_out = xb[xi ^ 1];
+      if (fuse_co) {   // the cross-attention blocks applied Wo themselves: fold their chunk records
+        ma.pend = s->carec.as<float>(); ma.KSp = H * s->n_chunks; ma.n_head = H; ma.n_chunks = s->n_chunks;
+      }
       ma.ln_g = b.ln3.g; ma.ln_b = b.ln3.b; ma.ln_eps = b.ln3.eps; ma.ln_inside = m->ln_eps_inside_sqrt;
       ma.W1 = b.mlp1.w; ma.ld1 = b.mlp1.n; ma.b1 = b.mlp1.b; ma.W2 = b.mlp2.w; ma.P = s->P2.as<float>();
       prof_tag(KC_MLP_FUSED, 4.0 * dd * 8);
@@ -597,7 +608,7 @@ static int launch_step(wb_session* s, int n_launch, int k, int use_mask, bool fu
   uint64_t sig = 1469598103934665603ull;
   auto mix = [&](uint64_t v) { sig = (sig ^ v) * 1099511628211ull; };
   for (const wb::DevMem* b : {&s->kc, &s->vc, &s->tabs, &s->state, &s->x, &s->h, &s->att, &s->Pqkv, &s->Po, &s->Pq,
-                              &s->P1, &s->P2, &s->Pa, &s->ca, &s->logits, &s->tstats, &s->row_stats, &s->mask, &s->ckv,
+                              &s->P1, &s->P2, &s->Pa, &s->carec, &s->ca, &s->logits, &s->tstats, &s->row_stats, &s->mask, &s->ckv,
                               &s->win_meta, &s->gctl, &s->gtok, &s->hm})
     mix((uint64_t)(uintptr_t)b->p);
   mix((uint64_t)(uintptr_t)s->host_block_dev);
@@ -665,7 +676,7 @@ int session_greedy_chain(wb_session* s, int first_token, int eot, int max_depth,
   static const bool graphs_enabled = []() { const char* e = getenv("WHISPER_HIP_GRAPH"); return !(e && e[0] == '0'); }();
   const bool use_graph = graphs_enabled && !profile().on;
   const int chunk = 16;
-  int depth = 0;
+  int depth = 0;                                   // steps enqueued so far
   ScopedTimer tm(st, 3);
   if (fuse_ln)   // first step of the chain; every later one is prepared by its predecessor's merge kernel
     launch_dec_prepare(st, reinterpret_cast<const int*>(s->host_block_dev), s->state.as<int>(), s->lay, n_launch,
@@ -673,26 +684,74 @@ int session_greedy_chain(wb_session* s, int first_token, int eot, int max_depth,
                        s->gctl.as<int>());
   // masked steps (the first two, transcribe.rs:271-275) and the tail shorter than a chunk go one step per
   // graph launch; in between, a whole chunk of steps is ONE graph launch (two multi-step shapes are never
-  // needed: only {1 step masked, 1 step, chunk steps} are captured).  Finished flags are read after each chunk.
-  int since_check = 0;
-  while (depth < max_depth) {
-    const int use_mask = (prompt_len + depth) <= mask_until_len ? 1 : 0;
-    const int run = (!use_mask && max_depth - depth >= chunk) ? chunk : 1;
-    WB_TRY(launch_step(s, n_launch, 1, use_mask, fuse_ln, 1, use_graph, true, eot, run));
-    if (profile().on) profile().ms[4] += run;
-    depth += run;
-    since_check += run;
-    if (since_check >= chunk || depth >= max_depth) {
-      since_check = 0;
+  // needed: only {1 step masked, 1 step, chunk steps} are captured).
+  //
+  // Small batches (the fused-LayerNorm path) run one segment AHEAD of the finished flags: segment k + 1 is enqueued
+  // before the flags of segment k are read (on a second stream, behind an event), so the GPU never idles across
+  // the host round trip (~60-400 us per check in round 1's timeline).  If every window turns out to be finished,
+  // the merge kernel has already blanked the step state (ST_N = 0) and the kernels of the speculative segment exit
+  // at their first instruction.  Batch mode (> 8 rows: MFMA GEMMs that do not look at ST_N) keeps the blocking check.
+  // (opt-in: measured 1417x vs 1543x -- a graph launched behind a running graph starts later than one launched on an
+  // idle stream saves)
+  static const bool spec_enabled = []() { const char* e = getenv("WHISPER_HIP_SPECULATE"); return e && e[0] == '1'; }();
+  const bool speculate = fuse_ln && spec_enabled;
+  if (speculate && !s->st2) {
+    WB_HIP(hipStreamCreateWithFlags(&s->st2, hipStreamNonBlocking));
+    WB_HIP(hipEventCreateWithFlags(&s->ev_seg, hipEventDisableTiming));
+  }
+  auto enqueue_segment = [&](int* enq) -> int {   // >= `chunk` steps (or what is left); returns steps enqueued via *enq
+    int n = 0;
+    while (depth + n < max_depth && n < chunk) {
+      const int d0 = depth + n;
+      const int use_mask = (prompt_len + d0) <= mask_until_len ? 1 : 0;
+      const int run = (!use_mask && max_depth - d0 >= chunk) ? chunk : 1;
+      WB_TRY(launch_step(s, n_launch, 1, use_mask, fuse_ln, 1, use_graph, true, eot, run));
+      if (profile().on) profile().ms[4] += run;
+      n += run;
+    }
+    *enq = n;
+    return WB_OK;
+  };
+  auto read_flags = [&](bool behind_event) -> int {
+    if (behind_event) {
+      WB_HIP(hipStreamWaitEvent(s->st2, s->ev_seg, 0));
+      WB_HIP(hipMemcpyAsync(ctl.data(), s->gctl.p, ctl_ints * 4, hipMemcpyDeviceToHost, s->st2));
+      WB_HIP(hipStreamSynchronize(s->st2));
+    } else {
       WB_HIP(hipMemcpyAsync(ctl.data(), s->gctl.p, ctl_ints * 4, hipMemcpyDeviceToHost, st));
       WB_HIP(hipStreamSynchronize(st));
-      bool all_done = true;
-      for (int i = 0; i < W; i++) all_done = all_done && ctl[GC_HDR + S + i] != 0;
-      if (all_done) break;
     }
+    return WB_OK;
+  };
+  auto all_done = [&]() {
+    bool d = true;
+    for (int i = 0; i < W; i++) d = d && ctl[GC_HDR + S + i] != 0;
+    return d;
+  };
+  if (!speculate) {
+    while (depth < max_depth) {
+      int n = 0;
+      WB_TRY(enqueue_segment(&n));
+      depth += n;
+      WB_TRY(read_flags(false));
+      if (all_done()) break;
+    }
+  } else {
+    int n_cur = 0;
+    WB_TRY(enqueue_segment(&n_cur));
+    depth += n_cur;
+    while (true) {
+      WB_HIP(hipEventRecord(s->ev_seg, st));        // end of the segment whose flags are read next
+      int n_next = 0;
+      if (depth < max_depth) { WB_TRY(enqueue_segment(&n_next)); depth += n_next; }
+      WB_TRY(read_flags(true));
+      if (all_done() || n_next == 0) break;
+    }
+    WB_HIP(hipStreamSynchronize(st));
   }
   tm.stop();
   std::vector<int> toks((size_t)S * s->Lmax + 1);
+  WB_HIP(hipMemcpyAsync(ctl.data(), s->gctl.p, ctl_ints * 4, hipMemcpyDeviceToHost, st));
   WB_HIP(hipMemcpyAsync(toks.data(), s->gtok.p, toks.size() * 4, hipMemcpyDeviceToHost, st));
   WB_HIP(hipStreamSynchronize(st));
   tm.collect();

@@ -9,6 +9,8 @@ struct wb_session {
   wb_model* m = nullptr;
   int device = 0;               // m->device, kept so that a session can be destroyed after its model
   hipStream_t st = nullptr;
+  hipStream_t st2 = nullptr;       // reads the chained decode's finished flags behind ev_seg while `st` runs ahead
+  hipEvent_t ev_seg = nullptr;
   int W = 0, max_beams = 0, S = 0, padding = 0;
   double sample_rate = 16000.0;   // only feeds the mel filterbank (audio.rs:44)
   int Lmax = 0;                 // capacity (positions) of the self-KV cache / tables
@@ -24,7 +26,7 @@ struct wb_session {
   int* state_host = nullptr;            // views into host_block
   int32_t* topk_id_host = nullptr;      // [S][TOPK_MAX]
   float* topk_lp_host = nullptr;
-  wb::DevMem x, h, att, Pqkv, Po, Pq, P1, P2, Pa, ca, logits, tstats, row_stats, mask, lp_tmp, gctl, gtok, hm;
+  wb::DevMem x, h, att, Pqkv, Po, Pq, P1, P2, Pa, carec, ca, logits, tstats, row_stats, mask, lp_tmp, gctl, gtok, hm;
   int n_tiles_v = 0, ct_v = 128;
   int ks_qkv = 1, ksl_qkv = 0, ks_o = 1, ksl_o = 0, ks_1 = 1, ksl_1 = 0, ks_2 = 1, ksl_2 = 0, ks_v = 1, ksl_v = 0;
   std::vector<int> prev_len, prev_win;

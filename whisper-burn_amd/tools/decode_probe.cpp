@@ -1,6 +1,6 @@
 // Developer probe (not part of the library): per-kernel latency of the decode-step kernels at
 // tiny.en geometry, launched back to back, warm vs rotating (cold) weights, eager vs hipGraph.
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/decode_probe.cpp csrc/build/decode.hip.o csrc/build/decode_fused.hip.o -o tools/decode_probe
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/decode_probe.cpp csrc/build/decode.hip.o <decode_fused.hip built with -DWB_STAMPS> -o tools/decode_probe
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
@@ -114,6 +114,26 @@ int main(int argc, char** argv) {
     a.x_out = x + (size_t)S * d; a.ln_g = g; a.ln_b = b; a.ln_eps = 1e-5f; a.mask = mask; a.topk = 1; a.tstats = tstats;
     launch_dec_gemv(st, a, n, true); }});
   cases.push_back({"topk merge", [&](int) { launch_dec_topk_merge(st, stdev, n, tstats, (V + GV_CT_LOGITS - 1) / GV_CT_LOGITS, 1, (int32_t*)att, att + 64, att + 128, L, nullptr, nullptr, Lmax, -1, NextPrep()); }});
+  {
+    unsigned long long* stamps = (unsigned long long*)dmalloc(16 * 8);
+    unsigned long long hs2[16];
+    auto timeline = [&](const char* name, int n_st, const std::function<void()>& f) {
+      for (int rep = 0; rep < 3; rep++) { f(); hipStreamSynchronize(st); }
+      hipMemcpy(hs2, stamps, 16 * 8, hipMemcpyDeviceToHost);
+      printf("%s phase timeline (us since block start):", name);
+      for (int i = 1; i < n_st; i++) printf(" %.2f", (double)(hs2[i] - hs2[0]) * 0.01);
+      printf("\n");
+    };
+    timeline("FUSED mlp ", 5, [&]() {
+      MlpFusedArgs ma; ma.st = stdev; ma.S = S; ma.d = d; ma.x_in = x; ma.pend = P; ma.KSp = ks_o; ma.pbias = bias; ma.x_out = x + (size_t)S * d;
+      ma.ln_g = g; ma.ln_b = b; ma.ln_eps = 1e-5f; ma.W1 = W1; ma.ld1 = 4 * d; ma.b1 = bias; ma.W2 = W2m; ma.P = Pa; ma.stamps = stamps;
+      launch_dec_mlp_fused(st, ma, n); });
+    timeline("FUSED attn", 8, [&]() {
+      AttnFusedArgs fa; fa.st = stdev; fa.lay = L; fa.S = S; fa.d = d; fa.n_head = H; fa.x_in = x; fa.pend = Pa; fa.KSp = 4 * d / 64; fa.pbias = bias;
+      fa.x_out = x + (size_t)S * d; fa.ln_g = g; fa.ln_b = b; fa.ln_eps = 1e-5f; fa.Wqkv = Wqkv; fa.ldqkv = 3 * d;
+      fa.bqkv = bias; fa.scale = 0.35f; fa.Kc = Kc; fa.Vc = Vc; fa.tabs = tabs; fa.Lmax = Lmax; fa.Wo = Wdd; fa.P = P2; fa.stamps = stamps;
+      launch_dec_attn_fused(st, fa, n); });
+  }
   for (auto& c : cases) {
     double e = bench(1000, c.f, false), gph = bench(1000, c.f, true);
     printf("%-28s eager %6.2f us   graph %6.2f us\n", c.name, e, gph);
