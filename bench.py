@@ -159,7 +159,7 @@ def main() -> None:
         # corrected per MI355X_MICROARCH.md (profiles/summarize_pmc.py), keyed by kernel class; only used when the
         # file was collected on this workload (it records the command line)
         pmc = {}
-        pmc_json = os.path.join(ROOT, "profiles", "r02_pmc_traffic_tiny_en_30s.json")
+        pmc_json = os.path.join(ROOT, "profiles", "r02_b_pmc_traffic_tiny_en_30s.json")
         if args.model in ("tiny.en", "tiny_en") and args.dtype == "f32" and args.beam == 1 and args.seconds == 30.0 \
                 and os.path.exists(pmc_json):
             pmc = json.load(open(pmc_json))
