@@ -57,3 +57,21 @@ def test_two_rank_sharding_equals_single_process():
         for _, toks, pw in res:
             assert pw == ref_pw
             assert toks == ref_toks
+
+
+def test_bench_self_launches_its_ranks_without_a_launcher():
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment must become its own launcher (round 1 exited with
+    SystemExit there).  On this GPU-less machine both ranks come up under torch.distributed.run and stop at the GPU check."""
+    import subprocess
+    import sys
+
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("CPU-only check of the launcher path")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode != 0
+    assert (p.stdout + p.stderr).count("bench.py needs a GPU") == 2

@@ -151,6 +151,19 @@ struct AttnFusedArgs {
   float* P = nullptr;                                                    // out: planes [n_head][S][d] (out bias NOT added)
   unsigned long long* stamps = nullptr;                                  // developer probe (-DWB_STAMPS): phase clock of block 0
 };
+struct CrossFusedArgs {
+  const int* st = nullptr; StepLayout lay; int S = 0, d = 0, n_head = 0;
+  const float* x_in = nullptr; const float* pend = nullptr; int KSp = 0; const float* pbias = nullptr; float* x_out = nullptr;
+  const float* ln_g = nullptr; const float* ln_b = nullptr; float ln_eps = 0.f; int ln_inside = 0;
+  const float* Wq = nullptr; const float* bq = nullptr; float scale = 0.f;         // [d][d], [d]
+  const float* ckv = nullptr; int ldkv = 0, koff = 0;                             // cached cross K|V rows (K pre-scaled)
+  const int* win_row0 = nullptr; const int* win_C = nullptr;
+  const float* Wo = nullptr;                                                      // [d][d]
+  float* P = nullptr;                                                             // out: planes [n_head][S][d] (out bias NOT added)
+  unsigned long long* stamps = nullptr;
+};
+constexpr int CROSS_FUSED_MAX_C = 768;   // keys per window the fused cross-attention block handles (n_audio_ctx / 2 = 750)
+void launch_dec_cross_fused(hipStream_t st, const CrossFusedArgs& a, int n_rows_hint);
 bool dec_fused_supported(int d);
 int dec_mlp_fused_planes(int d);
 void launch_dec_mlp_fused(hipStream_t st, const MlpFusedArgs& a, int n_rows_hint);

@@ -602,6 +602,186 @@ __global__ __launch_bounds__(512) void dec_attn_fused_kernel(AttnFusedArgs a) {
   WB_STAMP_FLUSH(a, 8);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Cross-attention block.  block = 512 threads, grid = (8, rows): block (h, r) owns head h of beam r (x = head keeps a
+// head's blocks on one XCD: the Wq / Wo slices and, for beams of the same window, the cached K/V cross the fabric once).
+//   LN(x + pending) -> q = . Wq[:, head h] + bq, * s -> scores against the window's cached K (all C <= 768 keys in this
+//   block: thread = key) -> softmax -> . V -> . Wo[head h rows, :] -> plane h of [H][S][d]        (mod.rs:482-490)
+// One launch instead of cross-attention (per 128-key chunk) + chunk combine + out-projection GEMV.
+template <int DPL>
+__global__ __launch_bounds__(512) void dec_cross_fused_kernel(CrossFusedArgs a) {
+  constexpr int NT = 512;
+  constexpr int d = 64 * DPL;
+  constexpr int NWQ = d / 32;                      // Wq rows per thread
+  constexpr int CF = d / 4;
+  constexpr int G = CF <= 32 ? 8 : 4;
+  constexpr int RPG = 64 / G;
+  constexpr int NV = CROSS_FUSED_MAX_C / 8;        // V values per lane (wave g owns keys j = g mod 8)
+  __shared__ __attribute__((aligned(16))) float hs[d];
+  __shared__ __attribute__((aligned(16))) float red[8][64];
+  __shared__ __attribute__((aligned(16))) float qv[64];
+  __shared__ float sc[CROSS_FUSED_MAX_C];
+  __shared__ __attribute__((aligned(16))) float ored[8][64];
+  __shared__ __attribute__((aligned(16))) float att[64];
+  __shared__ __attribute__((aligned(16))) float obuf[(G - 1) * d];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.x, r = blockIdx.y;
+  if (h >= a.n_head) return;
+  // ---- requested first (in order of use): fold operands, LayerNorm parameters, bias, the Wq slice
+  float xfold;
+  float gv[DPL], bv[DPL];
+  const int rg = tid >> 4, c4 = (tid & 15) * 4;
+  float4 wqr[NWQ];
+  {
+    const int c = tid < d ? tid : 0;
+    const float* pp = a.pend + (int64_t)r * d + c;
+    const int64_t plane = (int64_t)a.S * d;
+    float v = a.x_in[(int64_t)r * d + c];
+    constexpr int FP = 16;
+    float t[FP];
+    float accp = 0.f;
+    if (a.KSp > 0) {
+      accp = a.pbias[c];
+#pragma unroll
+      for (int j = 0; j < FP; j++) t[j] = pp[(int64_t)min(j, a.KSp - 1) * plane];
+    }
+    if (wave == 0) {
+#pragma unroll
+      for (int i = 0; i < DPL; i++) { gv[i] = a.ln_g[lane + 64 * i]; bv[i] = a.ln_b[lane + 64 * i]; }
+    }
+    {
+      const float* wp = a.Wq + (int64_t)rg * d + h * 64 + c4;
+#pragma unroll
+      for (int i = 0; i < NWQ; i++) wqr[i] = *reinterpret_cast<const float4*>(wp + (int64_t)(32 * i) * d);
+    }
+    if (a.KSp > 0) {
+#pragma unroll
+      for (int j = 0; j < FP; j++) accp += (j < a.KSp) ? t[j] : 0.f;
+      for (int sp = FP; sp < a.KSp; sp += FP) {
+#pragma unroll
+        for (int j = 0; j < FP; j++) t[j] = pp[(int64_t)min(sp + j, a.KSp - 1) * plane];
+#pragma unroll
+        for (int j = 0; j < FP; j++) accp += (sp + j < a.KSp) ? t[j] : 0.f;
+      }
+      v += accp;                                   // x + (bias + partials), s ascending  (mod.rs:346-348)
+    }
+    xfold = v;
+    if (r >= a.st[ST_N]) return;                   // (block-uniform)
+    if (tid < d) hs[tid] = v;
+  }
+  const float qbias = tid < 64 ? a.bq[h * 64 + tid] : 0.f;
+  // ---- the window's cached K rows: thread = key (first 512 keys now, the rest after the first pass)
+  const int w = a.st[a.lay.win + r];
+  const int C = min(a.win_C[w], CROSS_FUSED_MAX_C);
+  const float* Kb = a.ckv + (int64_t)a.win_row0[w] * a.ldkv + a.koff + h * 64;   // K pre-scaled at projection time
+  const float* Vb = Kb + d;
+  float4 kpre[16];
+  if (tid < C) {
+    const float4* kr = reinterpret_cast<const float4*>(Kb + (int64_t)tid * a.ldkv);
+#pragma unroll
+    for (int c = 0; c < 16; c++) kpre[c] = kr[c];
+  }
+  __syncthreads();
+  if (wave == 0) ln_row_lds<DPL>(hs, d, lane, gv, bv, a.ln_eps, a.ln_inside);
+  __syncthreads();
+  // ---- q = (cross_attn_ln(x) Wq + bq) * s for head h  (mod.rs:483, :506-509)
+  {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NWQ; i++) {
+      const float xv = hs[rg + 32 * i];
+      acc[0] += xv * wqr[i].x; acc[1] += xv * wqr[i].y; acc[2] += xv * wqr[i].z; acc[3] += xv * wqr[i].w;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) { acc[c] = xor16_sum(acc[c]); acc[c] = xor32_sum(acc[c]); }
+    if (lane < 16) *reinterpret_cast<float4*>(&red[wave][c4]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  }
+  __syncthreads();   // (also keeps the loads below behind the Wq registers' last use)
+  // ---- requested now: the Wo slice (consumed last)
+  const int cf = tid % CF, jg = tid / CF;
+  const bool p5 = jg < G;
+  const int jb = (p5 ? jg : 0) * RPG;
+  float4 wo[RPG];
+  {
+    const float* wp = a.Wo + (int64_t)(h * 64 + jb) * d + cf * 4;
+#pragma unroll
+    for (int i = 0; i < RPG; i++) wo[i] = *reinterpret_cast<const float4*>(wp + (int64_t)i * d);
+  }
+  if (tid < 64) {
+    float v = 0.f;
+#pragma unroll
+    for (int w8 = 0; w8 < 8; w8++) v += red[w8][tid];                   // wave order fixed
+    qv[tid] = (v + qbias) * a.scale;
+  }
+  __syncthreads();
+  // ---- scores
+  for (int k0 = 0; k0 < C; k0 += NT) {
+    const int key = k0 + tid;
+    if (k0 > 0 && key < C) {
+      const float4* kr = reinterpret_cast<const float4*>(Kb + (int64_t)key * a.ldkv);
+#pragma unroll
+      for (int c = 0; c < 16; c++) kpre[c] = kr[c];
+    }
+    if (key < C) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        const float4 q4 = *reinterpret_cast<const float4*>(&qv[4 * c]);
+        s += q4.x * kpre[c].x + q4.y * kpre[c].y + q4.z * kpre[c].z + q4.w * kpre[c].w;
+      }
+      sc[key] = s;
+    }
+  }
+  // ---- V columns of this wave's keys (j = wave mod 8): requested before the softmax statistics are known
+  float vv[NV];
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    const int j = wave + 8 * i;
+    vv[i] = j < C ? Vb[(int64_t)j * a.ldkv + lane] : 0.f;
+  }
+  __syncthreads();
+  // softmax statistics, redundantly per wave (no extra barrier)
+  float m = -INFINITY;
+  for (int j = lane; j < C; j += 64) m = fmaxf(m, sc[j]);
+  m = wave_max(m);
+  float l = 0.f;
+  for (int j = lane; j < C; j += 64) l += expf(sc[j] - m);
+  l = wave_sum(l);
+  float o = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    const int j = wave + 8 * i;
+    if (j < C) o += expf(sc[j] - m) * vv[i];
+  }
+  ored[wave][lane] = o;
+  __syncthreads();
+  if (tid < 64) {
+    float v = 0.f;
+#pragma unroll
+    for (int g8 = 0; g8 < 8; g8++) v += ored[g8][tid];
+    att[tid] = v / l;
+  }
+  __syncthreads();
+  // ---- plane h, row r = att Wo[head h rows, :]
+  float ov[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < RPG; i++) {
+    const float av = att[jb + i];
+    ov[0] += av * wo[i].x; ov[1] += av * wo[i].y; ov[2] += av * wo[i].z; ov[3] += av * wo[i].w;
+  }
+  if (p5 && jg > 0) *reinterpret_cast<float4*>(&obuf[(jg - 1) * d + cf * 4]) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+  __syncthreads();
+  if (jg == 0) {
+#pragma unroll
+    for (int g2 = 1; g2 < G; g2++) {
+      const float4 t = *reinterpret_cast<const float4*>(&obuf[(g2 - 1) * d + cf * 4]);
+      ov[0] += t.x; ov[1] += t.y; ov[2] += t.z; ov[3] += t.w;
+    }
+    *reinterpret_cast<float4*>(&a.P[((int64_t)h * a.S + r) * d + cf * 4]) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+  }
+  if (h == 0 && tid < d) a.x_out[(int64_t)r * d + tid] = xfold;      // the folded stream, off the critical path
+}
+
 }  // namespace
 
 bool dec_fused_supported(int d) { return d == 128 || d == 384 || d == 512; }
@@ -620,6 +800,13 @@ void launch_dec_mlp_fused(hipStream_t st, const MlpFusedArgs& a, int n_rows_hint
     if (a.d == 128) WB_MLP(8, 2); else if (a.d == 384) WB_MLP(8, 6); else WB_MLP(8, 8);
   }
 #undef WB_MLP
+}
+
+void launch_dec_cross_fused(hipStream_t st, const CrossFusedArgs& a, int n_rows_hint) {
+  const dim3 grid(a.n_head <= 8 ? 8 : a.n_head, n_rows_hint), block(512);
+  if (a.d == 128) WB_KLAUNCH((dec_cross_fused_kernel<2>), grid, block, 0, st, a);
+  else if (a.d == 384) WB_KLAUNCH((dec_cross_fused_kernel<6>), grid, block, 0, st, a);
+  else WB_KLAUNCH((dec_cross_fused_kernel<8>), grid, block, 0, st, a);
 }
 
 void launch_dec_attn_fused(hipStream_t st, const AttnFusedArgs& a, int n_rows_hint) {

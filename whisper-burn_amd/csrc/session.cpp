@@ -99,7 +99,7 @@ void session_pool_purge(wb_model* m) {
 static size_t session_device_bytes(const wb_session* s) {
   size_t n = 0;
   for (const DevMem* b : {&s->pcm, &s->mel, &s->wins, &s->gmax, &s->enc_out, &s->ckv, &s->win_meta, &s->kc, &s->vc,
-                          &s->tabs, &s->state, &s->x, &s->h, &s->att, &s->Pqkv, &s->Po, &s->Pq, &s->P1, &s->P2, &s->Pa, &s->carec, &s->ca,
+                          &s->tabs, &s->state, &s->x, &s->h, &s->att, &s->Pqkv, &s->Po, &s->Pq, &s->P1, &s->P2, &s->Pa, &s->Pc, &s->carec, &s->ca,
                           &s->logits, &s->tstats, &s->row_stats, &s->mask, &s->lp_tmp, &s->gctl, &s->gtok, &s->hm,
                           &s->ws.x1, &s->ws.x, &s->ws.h, &s->ws.qkv, &s->ws.att, &s->ws.hm, &s->ws.desc1, &s->ws.desc2,
                           &s->ws.auxidx, &s->ws.segs, &s->ws.misc})
@@ -267,6 +267,7 @@ int session_reserve(wb_session* s, int max_len) {
   WB_TRY(s->P1.ensure((size_t)s->ks_1 * S * 4 * d * 4));
   WB_TRY(s->P2.ensure(((size_t)std::max(s->ks_2, dec_mlp_fused_planes(d)) * S + 8) * d * 4));
   WB_TRY(s->Pa.ensure(((size_t)D.n_text_head * S + 8) * d * 4));
+  WB_TRY(s->Pc.ensure(((size_t)D.n_text_head * S + 8) * d * 4));
   WB_TRY(s->carec.ensure(((size_t)D.n_text_head * std::max(1, s->n_chunks) * S + 8) * (d + 2) * 4));
   WB_TRY(s->ca.ensure((size_t)S * D.n_text_head * std::max(1, s->n_chunks) * CA_STRIDE * 4));
   WB_TRY(s->logits.ensure((size_t)S * V * 4));
@@ -486,10 +487,15 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
   // sublayer fusion (decode_fused.hip): self-attention block and MLP block are ONE launch each
   static const bool fuse_sub_enabled = []() { const char* e = getenv("WHISPER_HIP_FUSE_SUB"); return !(e && e[0] == '0'); }();
   const bool fuse_sub = fuse_sub_enabled && dec_fused_supported(d) && m->compute_dtype != WB_BF16 && d == 64 * H;
-  // ... and the cross-attention blocks apply their head's rows of the out-projection (needs both fusions above)
+  // the whole cross-attention sublayer (LN + Wq + attention over the window's cached K/V + Wo) as one launch per
+  // (head, beam): opt-in -- 25.9 us vs 15.8 us for chunked cross-attention + out-projection GEMV (H x rows blocks cannot
+  // stream 384 KB of K/V each as fast as 6x as many chunk blocks stream 64 KB each)
+  static const bool fuse_x_enabled = []() { const char* e = getenv("WHISPER_HIP_FUSE_X"); return e && e[0] == '1'; }();
+  const bool fuse_x = fuse_x_enabled && fuse_sub && s->maxC <= CROSS_FUSED_MAX_C;
+  // ... or (older, opt-in) the chunked cross-attention blocks apply their head's rows of the out-projection
   // (opt-in: with 128-key chunks the MLP prologue has 6 H records per row to combine and loses what the launch saves)
   static const bool fuse_co_enabled = []() { const char* e = getenv("WHISPER_HIP_FUSE_CO"); return e && e[0] == '1'; }();
-  const bool fuse_co = fuse_co_enabled && fuse_sub && fuse_q && H * s->n_chunks <= 48;
+  const bool fuse_co = fuse_co_enabled && fuse_sub && fuse_q && H * s->n_chunks <= 48 && !fuse_x;
   const int nb_mlp = dec_mlp_fused_planes(d);
   const int ks_mlp = fuse_sub ? nb_mlp : s->ks_2;            // planes the MLP leaves pending
   for (int l = 0; l < NL; l++) {   // ResidualDecoderAttentionBlock::forward, mod.rs:345-350
@@ -521,7 +527,18 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
       launch_dec_gemv(st, gemv(b.out, s->ks_o, s->ksl_o, PRO_PLAIN, att, d, s->Po.as<float>()), n, false);
       att_planes = s->Po.as<float>(); att_ks = s->ks_o;
     }
-    if (fuse_q) {
+    if (fuse_x) {
+      CrossFusedArgs ca;
+      ca.st = dst; ca.lay = L; ca.S = S; ca.d = d; ca.n_head = H;
+      ca.x_in = xb[xi]; ca.pend = att_planes; ca.KSp = att_ks; ca.pbias = b.out.b; ca.x_out = xb[xi ^ 1];
+      ca.ln_g = b.ln2.g; ca.ln_b = b.ln2.b; ca.ln_eps = b.ln2.eps; ca.ln_inside = m->ln_eps_inside_sqrt;
+      ca.Wq = b.cq.w; ca.bq = b.cq.b; ca.scale = m->qk_scale;
+      ca.ckv = s->ckv.as<float>(); ca.ldkv = ldkv; ca.koff = l * 2 * d; ca.win_row0 = win_row0; ca.win_C = win_C;
+      ca.Wo = b.cout.w; ca.P = s->Pc.as<float>();
+      prof_tag(KC_CROSS_ATTN, ckv_bytes + 4.0 * dd * 2);
+      launch_dec_cross_fused(st, ca, n);
+      xi ^= 1;
+    } else if (fuse_q) {
       // cross_attn_ln + the query projection inside the cross-attention blocks (one launch less per layer)
       CaFuse fz;
       fz.x_in = xb[xi]; fz.pend = att_planes; fz.KSp = att_ks; fz.pbias = b.out.b; fz.x_out = xb[xi ^ 1];
@@ -540,7 +557,7 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
       launch_dec_cross_attn(st, dst, L, s->W, H, s->n_chunks, s->Pq.as<float>(), s->ks_o, b.cq.b, d,
                             s->ckv.as<float>(), ldkv, l * 2 * d, win_row0, win_C, m->qk_scale, s->ca.as<float>(), max_nb);
     }
-    if (!fuse_co) {
+    if (!fuse_co && !fuse_x) {
       GemvArgs a = gemv(b.cout, s->ks_o, s->ksl_o, PRO_ATTN, s->ca.as<float>(), 0, s->Po.as<float>());
       a.n_head = H; a.n_chunks = s->n_chunks;
       prof_tag(KC_GEMV_COUT, wsz * dd);
@@ -550,7 +567,8 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
       MlpFusedArgs ma;
       ma.st = dst; ma.S = S; ma.d = d;
       ma.x_in = xb[xi]; ma.pend = s->Po.as<float>(); ma.KSp = s->ks_o; ma.pbias = b.cout.b; ma.x_out = xb[xi ^ 1];
-      if (fuse_co) {   // the cross-attention blocks applied Wo themselves: fold their chunk records
+      if (fuse_x) { ma.pend = s->Pc.as<float>(); ma.KSp = H; }
+      else if (fuse_co) {   // the cross-attention blocks applied Wo themselves: fold their chunk records
         ma.pend = s->carec.as<float>(); ma.KSp = H * s->n_chunks; ma.n_head = H; ma.n_chunks = s->n_chunks;
       }
       ma.ln_g = b.ln3.g; ma.ln_b = b.ln3.b; ma.ln_eps = b.ln3.eps; ma.ln_inside = m->ln_eps_inside_sqrt;
@@ -608,7 +626,7 @@ static int launch_step(wb_session* s, int n_launch, int k, int use_mask, bool fu
   uint64_t sig = 1469598103934665603ull;
   auto mix = [&](uint64_t v) { sig = (sig ^ v) * 1099511628211ull; };
   for (const wb::DevMem* b : {&s->kc, &s->vc, &s->tabs, &s->state, &s->x, &s->h, &s->att, &s->Pqkv, &s->Po, &s->Pq,
-                              &s->P1, &s->P2, &s->Pa, &s->carec, &s->ca, &s->logits, &s->tstats, &s->row_stats, &s->mask, &s->ckv,
+                              &s->P1, &s->P2, &s->Pa, &s->Pc, &s->carec, &s->ca, &s->logits, &s->tstats, &s->row_stats, &s->mask, &s->ckv,
                               &s->win_meta, &s->gctl, &s->gtok, &s->hm})
     mix((uint64_t)(uintptr_t)b->p);
   mix((uint64_t)(uintptr_t)s->host_block_dev);

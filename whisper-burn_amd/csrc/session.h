@@ -26,7 +26,7 @@ struct wb_session {
   int* state_host = nullptr;            // views into host_block
   int32_t* topk_id_host = nullptr;      // [S][TOPK_MAX]
   float* topk_lp_host = nullptr;
-  wb::DevMem x, h, att, Pqkv, Po, Pq, P1, P2, Pa, carec, ca, logits, tstats, row_stats, mask, lp_tmp, gctl, gtok, hm;
+  wb::DevMem x, h, att, Pqkv, Po, Pq, P1, P2, Pa, Pc, carec, ca, logits, tstats, row_stats, mask, lp_tmp, gctl, gtok, hm;
   int n_tiles_v = 0, ct_v = 128;
   int ks_qkv = 1, ksl_qkv = 0, ks_o = 1, ksl_o = 0, ks_1 = 1, ksl_1 = 0, ks_2 = 1, ksl_2 = 0, ks_v = 1, ksl_v = 0;
   std::vector<int> prev_len, prev_win;
