@@ -112,6 +112,9 @@ struct NextPrep {
   const float* pos = nullptr;   // decoder positional embedding [n_text_ctx][d]
   int* tabs = nullptr;       // position tables, double-buffered by step parity
   int d = 0;
+  // mapped host memory, int[S][2] = (steps completed, finished) per row: the host polls it instead of copying the
+  // control block back and synchronising the stream after every chunk of chained steps
+  int* hflags = nullptr;
 };
 void launch_dec_topk_merge(hipStream_t st, int* state, int n_max, const float* tstats, int n_tiles, int k,
                            int32_t* out_id, float* out_lp, float* row_stats, const StepLayout& lay, int* gctl, int* gtok,

@@ -407,6 +407,11 @@ __device__ __forceinline__ void chained_update(int* st, const StepLayout& lay, i
   }
   if (r == 0) gctl[GC_STEP] = st[ST_STEP] + 1;
 }
+// host-visible progress of row r (mapped pinned memory): finished flag first, then the step counter the host waits for
+__device__ __forceinline__ void chained_publish(const int* st, const StepLayout& lay, const int* gctl, int* hflags, int r) {
+  __hip_atomic_store(&hflags[2 * r + 1], gctl[GC_HDR + lay.S + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&hflags[2 * r], st[ST_STEP] + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // ---- merge the per-tile statistics of one beam's logits row: log_softmax + top-k ------------------
 // Device-chained greedy decode (gctl != nullptr) with `nx.x` set: the block of row r also PREPARES row r of the
@@ -472,7 +477,10 @@ __global__ __launch_bounds__(256) void dec_topk_merge_kernel(int* __restrict__ s
     if (tid == 0) {
       out_id[r * TOPK_MAX + round] = gi;
       out_lp[r * TOPK_MAX + round] = (gv - M) - lse;   // log_softmax, transcribe.rs:276
-      if (gctl && round == 0) chained_update(st, lay, gctl, gtok, Lmax, eot, r, gi);
+      if (gctl && round == 0) {
+        chained_update(st, lay, gctl, gtok, Lmax, eot, r, gi);
+        if (nx.hflags) chained_publish(st, lay, gctl, nx.hflags, r);
+      }
     }
     if (round == 0) first = gi;
     if (ti[0] == gi) {   // the winner pops its head

@@ -74,7 +74,10 @@ int run_encoder(wb_model* m, hipStream_t st, Workspace& ws, const MelBatch& mb, 
     maxC = std::max(maxC, eo->C[w]);
   }
   eo->rows = rows2;
-  // ---- per-row descriptors of the two implicit-GEMM convolutions ----
+  // ---- per-row descriptors of the two implicit-GEMM convolutions (cached per geometry) ----
+  const bool same_geom = ws.enc_T == mb.T && ws.enc_win_stride == mb.win_stride && ws.enc_row_stride == mb.row_stride &&
+                         ws.enc_d == d && ws.desc1.p && ws.desc2.p && ws.auxidx.p && ws.segs.p;
+  if (!same_geom) {
   std::vector<RowDesc> d1(rows1), d2(rows2);
   std::vector<int32_t> aidx(rows2);
   std::vector<AttnSeg> segs(nw);
@@ -100,6 +103,8 @@ int run_encoder(wb_model* m, hipStream_t st, Workspace& ws, const MelBatch& mb, 
   WB_TRY(upload(st, ws.auxidx, aidx.data(), aidx.size() * sizeof(int32_t)));
   WB_TRY(upload(st, ws.segs, segs.data(), segs.size() * sizeof(AttnSeg)));
   WB_HIP(hipStreamSynchronize(st));   // host vectors die at scope exit
+  ws.enc_T = mb.T; ws.enc_win_stride = mb.win_stride; ws.enc_row_stride = mb.row_stride; ws.enc_d = d;
+  }
   WB_TRY(ws.x1.ensure((size_t)rows1 * d * 4));
   WB_TRY(ws.x.ensure((size_t)rows2 * d * 4));
   WB_TRY(ws.h.ensure((size_t)rows2 * d * 4));
@@ -162,6 +167,7 @@ int run_decoder_stateless(wb_model* m, hipStream_t st, Workspace& ws, const int3
   }
   WB_TRY(upload(st, ws.segs, segs.data(), segs.size() * sizeof(AttnSeg)));
   WB_HIP(hipStreamSynchronize(st));
+  ws.enc_T.clear();                   // (ws.segs no longer holds the encoder's segments)
   WB_TRY(ws.x.ensure((size_t)rows * d * 4));
   WB_TRY(ws.h.ensure((size_t)rows * d * 4));
   WB_TRY(ws.qkv.ensure((size_t)rows * 3 * d * 4));

@@ -170,8 +170,11 @@ static int session_finish_encode(wb_session* s, const MelBatch& mb) {
   std::vector<int> meta(2 * s->W);
   for (int w = 0; w < s->W; w++) { meta[w] = s->row0[w]; meta[s->W + w] = s->C[w]; }
   WB_TRY(s->win_meta.ensure(meta.size() * 4));
-  WB_HIP(hipMemcpyAsync(s->win_meta.p, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, s->st));
-  WB_HIP(hipStreamSynchronize(s->st));
+  if (meta != s->meta_host || s->meta_dev_ptr != s->win_meta.p) {   // (same geometry as last time: already on the device)
+    WB_HIP(hipMemcpyAsync(s->win_meta.p, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, s->st));
+    WB_HIP(hipStreamSynchronize(s->st));
+    s->meta_host = meta; s->meta_dev_ptr = s->win_meta.p;
+  }
   return WB_OK;
 }
 
@@ -206,8 +209,16 @@ int session_encode_pcm(wb_session* s, const float* pcm, int64_t n_pcm, const int
   WB_TRY(s->mel.ensure((size_t)s->W * 80 * Ts * 4));
   if (!pcm_on_device) WB_HIP(hipMemcpyAsync(s->pcm.p, pcm + lo, (size_t)(hi - lo) * 4, hipMemcpyHostToDevice, s->st));
   const float* pcm_dev = pcm_on_device ? pcm : s->pcm.as<float>();
-  WB_HIP(hipMemcpyAsync(s->wins.p, wins.data(), wins.size() * sizeof(MelWindow), hipMemcpyHostToDevice, s->st));
-  WB_HIP(hipStreamSynchronize(s->st));   // `wins` is a stack vector
+  // the window table on the device is re-used when this (pooled) session saw the same windows last time
+  const bool same_wins = s->wins_host.size() == wins.size() && s->wins_dev_ptr == s->wins.p &&
+                         memcmp(s->wins_host.data(), wins.data(), wins.size() * sizeof(MelWindow)) == 0;
+  if (!same_wins) {
+    WB_HIP(hipMemcpyAsync(s->wins.p, wins.data(), wins.size() * sizeof(MelWindow), hipMemcpyHostToDevice, s->st));
+    WB_HIP(hipStreamSynchronize(s->st));   // `wins` is a stack vector
+    s->wins_host = wins; s->wins_dev_ptr = s->wins.p;
+  } else if (!pcm_on_device) {
+    WB_HIP(hipStreamSynchronize(s->st));   // the caller's PCM buffer may go away
+  }
   {
     ScopedTimer tm(s->st, 0);
     launch_mel_spectrogram(s->st, pcm_dev, s->wins.as<MelWindow>(), s->W, maxF, tabs, s->mel.as<float>(),
@@ -239,7 +250,7 @@ int session_reserve(wb_session* s, int max_len) {
   WB_TRY(s->state.ensure((size_t)s->lay.total * 4));
   // step state and top-k results live in mapped pinned host memory: the prepare kernel pulls the
   // state over PCIe, the merge kernel pushes the k (id, log-prob) pairs -- no copy launches per step
-  const size_t host_bytes = (size_t)s->lay.total * 4 + (size_t)S * TOPK_MAX * 8;
+  const size_t host_bytes = (size_t)s->lay.total * 4 + (size_t)S * TOPK_MAX * 8 + (size_t)S * 2 * 4;   // + chain flags
   if (s->host_bytes < host_bytes) {
     if (s->host_block) { (void)hipHostFree(s->host_block); s->host_block = nullptr; s->host_bytes = 0; }
     WB_HIP(hipHostMalloc((void**)&s->host_block, host_bytes, hipHostMallocMapped));
@@ -249,6 +260,7 @@ int session_reserve(wb_session* s, int max_len) {
   s->state_host = reinterpret_cast<int*>(s->host_block);
   s->topk_id_host = reinterpret_cast<int32_t*>(s->host_block + (size_t)s->lay.total * 4);
   s->topk_lp_host = reinterpret_cast<float*>(s->host_block + (size_t)s->lay.total * 4 + (size_t)S * TOPK_MAX * 4);
+  s->chain_flags_off = (size_t)s->lay.total * 4 + (size_t)S * TOPK_MAX * 8;
   gemv_plan(d, 3 * d, &s->ks_qkv, &s->ksl_qkv);
   gemv_plan(d, d, &s->ks_o, &s->ksl_o);
   gemv_plan(d, 4 * d, &s->ks_1, &s->ksl_1);
@@ -599,6 +611,7 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
     tm_logits.stop();
     NextPrep nx;
     if (merge_prepares) { nx.x = xb[0]; nx.E = m->tok_emb; nx.pos = m->dec_pos; nx.tabs = tabs; nx.d = d; }
+    if (chained) nx.hflags = reinterpret_cast<int*>(s->host_block_dev + s->chain_flags_off);
     prof_tag(KC_TOPK_MERGE, 4.0 * n * s->n_tiles_v * TS_STRIDE);
     launch_dec_topk_merge(st, s->state.as<int>(), n, s->tstats.as<float>(), s->n_tiles_v, k, out_id_dev, out_lp_dev,
                           s->row_stats.as<float>(), L, gctl, s->gtok.as<int>(), s->Lmax, eot, nx);
@@ -746,13 +759,54 @@ int session_greedy_chain(wb_session* s, int first_token, int eot, int max_depth,
     for (int i = 0; i < W; i++) d = d && ctl[GC_HDR + S + i] != 0;
     return d;
   };
+  // small batches: the merge kernel publishes (steps completed, finished) per row into mapped host memory; the host
+  // spins on it (a few us) instead of a D2H copy + stream synchronisation (30-190 us of idle GPU per check in round 1)
+  static const bool poll_enabled = []() { const char* e = getenv("WHISPER_HIP_POLL"); return !(e && e[0] == '0'); }();
+  const bool poll = fuse_ln && poll_enabled && !profile().on;
+  volatile int* hfl = reinterpret_cast<volatile int*>(s->host_block + s->chain_flags_off);
+  if (poll) for (int i = 0; i < 2 * S; i++) hfl[i] = 0;
+  auto wait_flags = [&](int want_step, bool* done) -> int {
+    for (long spins = 0;; spins++) {
+      bool ready = true;
+      for (int i = 0; i < W && ready; i++) ready = hfl[2 * i] >= want_step;
+      if (ready) break;
+      bool fin = true;
+      for (int i = 0; i < W && fin; i++) fin = hfl[2 * i + 1] != 0;
+      if (fin) break;                              // every window finished: the rest of the chunk is blanked
+      if ((spins & 0xfff) == 0xfff) {             // every 4096 spins: is the stream still alive / busy?
+        const hipError_t q = hipStreamQuery(st);
+        if (q == hipSuccess) {                     // stream drained: the flags are final (or the chain ended early)
+          bool r2 = true;
+          for (int i = 0; i < W && r2; i++) r2 = hfl[2 * i] >= want_step;
+          if (r2) break;
+          bool all = true;
+          for (int i = 0; i < W; i++) all = all && hfl[2 * i + 1] != 0;
+          if (all) break;                          // every window finished: later steps were blanked
+          set_error("chained decode: the device stopped at step %d of %d", (int)hfl[0], want_step);
+          return WB_ERR_HIP;
+        }
+        if (q != hipErrorNotReady) { set_error("chained decode: %s", hipGetErrorString(q)); return WB_ERR_HIP; }
+      }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    bool all = true;
+    for (int i = 0; i < W; i++) all = all && hfl[2 * i + 1] != 0;
+    *done = all;
+    return WB_OK;
+  };
   if (!speculate) {
     while (depth < max_depth) {
       int n = 0;
       WB_TRY(enqueue_segment(&n));
       depth += n;
-      WB_TRY(read_flags(false));
-      if (all_done()) break;
+      if (poll) {
+        bool done = false;
+        WB_TRY(wait_flags(s->step + depth, &done));
+        if (done) break;
+      } else {
+        WB_TRY(read_flags(false));
+        if (all_done()) break;
+      }
     }
   } else {
     int n_cur = 0;

@@ -15,6 +15,8 @@ struct wb_session {
   double sample_rate = 16000.0;   // only feeds the mel filterbank (audio.rs:44)
   int Lmax = 0;                 // capacity (positions) of the self-KV cache / tables
   std::vector<int> T, C, row0;  // per window: mel frames (padded), encoder positions, first packed row
+  std::vector<wb::MelWindow> wins_host; void* wins_dev_ptr = nullptr;   // what the device window table holds
+  std::vector<int> meta_host; void* meta_dev_ptr = nullptr;             // ... and the window meta table
   int enc_rows = 0, maxC = 0, n_chunks = 0;
   wb::Workspace ws;
   wb::DevMem pcm, mel, wins, gmax, enc_out, ckv, win_meta;
@@ -23,6 +25,7 @@ struct wb_session {
   char* host_block = nullptr;           // mapped pinned host memory: step state | top-k ids | top-k log-probs
   char* host_block_dev = nullptr;       // its device-visible address
   size_t host_bytes = 0;
+  size_t chain_flags_off = 0;           // offset of the chained decode's per-row progress flags in host_block
   int* state_host = nullptr;            // views into host_block
   int32_t* topk_id_host = nullptr;      // [S][TOPK_MAX]
   float* topk_lp_host = nullptr;

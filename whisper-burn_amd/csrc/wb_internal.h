@@ -103,6 +103,9 @@ struct DecBlockW {
 // Grow-only device workspace shared by the forward passes of one owner (model scratch or session).
 struct Workspace {
   DevMem x1, x, h, qkv, att, hm, desc1, desc2, auxidx, segs, misc;
+  // geometry the encoder descriptors on the device were built for: a transcription loop over equally shaped batches
+  // (the common case) re-uses them instead of paying four uploads and a stream synchronisation per batch
+  std::vector<int> enc_T; int64_t enc_win_stride = -1; int enc_row_stride = -1; int enc_d = -1;
 };
 
 }  // namespace wb
