@@ -257,7 +257,7 @@ __global__ __launch_bounds__(MEL_THREADS, 4) void mel_spectrogram_kernel(
   // ---- stage 4: sparse mel filterbank, log10, local max ----
   // lane = frame, half-wave = group of 8 mel rows: the filter taps are uniform over each half-wave
   // (broadcast LDS reads), the power spectra are the lane's own frame
-  const float INV_LN10 = 0.43429448190325182765f;   // 1 / ln 10 (helper.rs:24-27 divides by ln 10)
+  const float LOG10_2 = 0.30102999566398119521f;    // log10(2)
   float lmax = -INFINITY, lmin = INFINITY;
   {
     const int f = tid & (FPB - 1), grp = tid >> 5;            // 10 groups x 8 rows
@@ -285,7 +285,9 @@ __global__ __launch_bounds__(MEL_THREADS, 4) void mel_spectrogram_kernel(
         acc += w4.x * p0; acc += w4.y * p1; acc += w4.z * p2; acc += w4.w * p3;
       }
       // tensor_max_scalar(x, 1e-10) = relu(x - 1e-10) + 1e-10 (helper.rs:8-10); log10 = ln/ln10 (:24-27)
-      const float v = logf(fmaxf(acc - 1.0e-10f, 0.f) + 1.0e-10f) * INV_LN10;   // (x / ln10 up to 1 ulp; tolerance class "mel")
+      // ln(x) / ln 10 (helper.rs:24-27) through the hardware log2 (v_log_f32, <= 1 ulp; the argument is >= 1e-10, normal):
+      // log10 x = log2 x * log10 2 -- within 2e-7 of the reference's two-step form, tolerance class "mel"
+      const float v = __log2f(fmaxf(acc - 1.0e-10f, 0.f) + 1.0e-10f) * LOG10_2;
       // stored already normalised, (x + 4) / 4 (audio.rs:53); the clamp max(x, max - 8) (audio.rs:52) needs the window
       // maximum and is applied by the fix-up pass -- only to tiles whose minimum is below it (rare: 80 dB down)
       fr_reg[OT_OFF + 2 * m + (f & 1)] = (v + 4.0f) / 4.0f;
