@@ -236,6 +236,11 @@ int wb_stitch_windows(const int32_t* win_tokens, int32_t row_stride, const int32
                       int n_windows, int max_n_offsets, int min_n_overlaps, int32_t* out,
                       int64_t cap, int64_t* n_out);
 
+/* The constant tables of the frontend, built on the host in the reference's f32 op order: periodic Hann window
+ * (hann_window_device, audio.rs:272-278) and the dense [80][201] Slaney filterbank (get_mel_filters_device,
+ * audio.rs:67-143; the kernel keeps it sparse).  No GPU needed; for table-vs-oracle tests. */
+int wb_mel_constants(double sample_rate, float* hann400, float* filters_80x201);
+
 /* ---- measurement hooks ----------------------------------------------------------- */
 
 /* Per-stage device time (ms, HIP events on the engine's stream) accumulated since the

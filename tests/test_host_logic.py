@@ -256,3 +256,27 @@ def test_end_to_end_roofline_model_of_the_bench():
     assert a["decode"] > 103 * 4 * 51864 * 384 / 8e12 * 1e3
     assert abs(a["total"] - (a["mel"] + a["encoder_and_cross_kv"] + a["decode"])) < 1e-12
     assert abs(a["_work"]["decode_bytes"] / 8e12 * 1e3 - a["decode"]) < 1e-9
+
+
+def test_mel_constant_tables_match_the_oracle():
+    """The Hann window and the Slaney filterbank the kernel uses (built once on the host in the reference's f32 op
+    order) against the oracle's restatement of audio.rs:67-143 / :272-278, element by element."""
+    import ctypes as C
+
+    import torch
+    from oracle import mel as omel
+    lib = _lib.load()
+    hann = np.zeros(400, np.float32)
+    filt = np.zeros((80, 201), np.float32)
+    assert lib.wb_mel_constants(16000.0, hann.ctypes.data_as(_lib.c_float_p), filt.ctypes.data_as(_lib.c_float_p)) == 0
+    ref_h = omel.hann_window(400).numpy()
+    ref_f = omel.get_mel_filters(16000.0, 400, 80).numpy()
+    assert ref_f.shape == (80, 201)
+    assert np.abs(hann - ref_h).max() <= 2e-7                         # sin() of libm vs torch: a few ulp at most
+    scale = np.abs(ref_f).max()
+    assert np.abs(filt - ref_f).max() <= 4e-7 * scale, np.abs(filt - ref_f).max()
+    # the sparsity pattern: a tap is zero in one table only if it is tiny in the other (triangle edges)
+    assert np.abs(ref_f[(filt == 0)]).max() <= 4e-7 * scale and np.abs(filt[(ref_f == 0)]).max() <= 4e-7 * scale
+    nz = (filt != 0).sum(1)
+    assert nz.min() >= 1 and nz.max() <= 16 and 380 <= (filt != 0).sum() <= 400   # SURVEY 8a-4: 391 non-zeros, 1-14 per row
+    del C

@@ -95,6 +95,19 @@ void wb_model_free(wb_model* m) {
   delete m;
 }
 
+int wb_mel_constants(double sample_rate, float* hann400, float* filters_80x201) {
+  // host only: the tables the mel kernel uses (hann_window_device audio.rs:272-278, get_mel_filters_device :67-143)
+  WB_REQUIRE(hann400 && filters_80x201, WB_ERR_ARG, "wb_mel_constants: null argument");
+  auto t = std::make_unique<MelTables>();
+  WB_REQUIRE(mel_tables_build(sample_rate, t.get()) == 0, WB_ERR_SHAPE,
+             "mel filterbank for sample_rate %g has a row wider than %d taps", sample_rate, MEL_MAX_TAPS);
+  memcpy(hann400, t->hann, sizeof(t->hann));
+  memset(filters_80x201, 0, sizeof(float) * MEL_N_MELS * MEL_N_BINS);
+  for (int m = 0; m < MEL_N_MELS; m++)
+    for (int k = 0; k < t->tap_len[m]; k++) filters_80x201[m * MEL_N_BINS + t->tap_start[m] + k] = t->tap_w[m * MEL_MAX_TAPS + k];
+  return WB_OK;
+}
+
 int64_t wb_max_waveform_samples(int64_t n_frame_max) {
   // audio.rs:12-17 with N_FFT = 400 (even)
   return MEL_HOP * (n_frame_max + 1) + (MEL_N_FFT % 2) - 1;

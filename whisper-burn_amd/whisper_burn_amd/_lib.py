@@ -84,6 +84,7 @@ SIGNATURES = {
                                         c_int64_p, c_int64_p]),
     "wb_stitch_windows": (C.c_int, [c_int32_p, C.c_int32, c_int32_p, C.c_int, C.c_int, C.c_int, c_int32_p,
                                     C.c_int64, c_int64_p]),
+    "wb_mel_constants": (C.c_int, [C.c_double, c_float_p, c_float_p]),
     "wb_profile_enable": (C.c_int, [C.c_int]),
     "wb_profile_read": (C.c_int, [c_double_p, C.c_int]),
     "wb_profile_kernels": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
