@@ -108,6 +108,22 @@ int wb_wav_info(const char* path, int64_t* n_samples, int32_t* sample_rate, int3
  * float as stored (main.rs:48).  A sample rate other than 16 000 Hz or more than one channel ->
  * WB_ERR_SHAPE (the asserts of main.rs:42-43); capacity < samples -> WB_ERR_ARG. */
 int wb_wav_read_f32(const char* path, float* out, int64_t capacity, int64_t* n_samples);
+/* wb_wav_read_f32 without the 16 kHz assert (still mono): the input of wb_resample_dev. */
+int wb_wav_read_f32_any_rate(const char* path, float* out, int64_t capacity, int64_t* n_samples);
+
+/* Sample-rate conversion in HBM for inputs the reference's CLI rejects (main.rs:42; its README sends them through
+ * `sox`, README.md:69-74 -- the bundled audio.wav is 22 050 Hz).  Rational polyphase resampler with the design of
+ * SciPy's resample_poly(x, up, down): up/down = rate_out/rate_in reduced, Kaiser(beta 5) windowed sinc of half
+ * length 10*max(up,down), cut-off 1/max(up,down) of Nyquist, zero extension; taps designed in f64, f32 arithmetic.
+ *   wb_resample_len     ceil(n_in*up/down), or -1 on a bad argument / a reduced ratio above 1600
+ *   wb_resample_filter  the taps (host only; taps may be NULL to query n_taps = 20*max(up,down)+1, up, down)
+ *   wb_resample_dev     src_dev[n_in] -> dst_dev[*n_out] (DEVICE pointers), one pass, synchronises before returning */
+int64_t wb_resample_len(int64_t n_in, int32_t rate_in, int32_t rate_out);
+int wb_resample_filter(int32_t rate_in, int32_t rate_out, float* taps, int32_t capacity, int32_t* n_taps, int32_t* up,
+                       int32_t* down);
+int wb_resample_dev(int device, const float* src_dev, int64_t n_in, int32_t rate_in, int32_t rate_out, float* dst_dev,
+                    int64_t capacity, int64_t* n_out);
+
 /* The same scaling for 16-bit PCM already resident in HBM: dst_dev[i] = src_dev[i] / 32767 (correctly
  * rounded, bit-identical to the host path); halves the host->device bytes of wb_waveform_to_tokens_dev. */
 int wb_pcm_s16_to_f32_dev(int device, const int16_t* src_dev, int64_t n, float* dst_dev);

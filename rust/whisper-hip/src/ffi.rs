@@ -86,6 +86,10 @@ extern "C" {
                              out_lens: *mut i32) -> c_int;
     pub fn wb_session_free(s: *mut wb_session);
     pub fn wb_wav_read_f32(path: *const c_char, out: *mut c_float, capacity: i64, n_samples: *mut i64) -> c_int;
+    pub fn wb_wav_read_f32_any_rate(path: *const c_char, out: *mut c_float, capacity: i64, n_samples: *mut i64) -> c_int;
+    pub fn wb_resample_len(n_in: i64, rate_in: i32, rate_out: i32) -> i64;
+    pub fn wb_resample_dev(device: c_int, src_dev: *const c_float, n_in: i64, rate_in: i32, rate_out: i32,
+                           dst_dev: *mut c_float, capacity: i64, n_out: *mut i64) -> c_int;
     pub fn wb_last_error() -> *const c_char;
     pub fn wb_version() -> *const c_char;
 }

@@ -103,3 +103,34 @@ def test_cli_end_to_end(tmp_path, monkeypatch):
     assert cli.main(["transcribe", "micro", "a.wav", "en", "out.txt"]) == 0
     text = open(tmp_path / "out.txt").read()
     assert "<|" not in text and len(text.split()) >= 2
+
+
+@pytest.mark.gpu
+def test_cli_resamples_a_22050_hz_file_on_request(tmp_path, monkeypatch, capsys):
+    """The bundled audio.wav is 22 050 Hz: the reference's CLI refuses it (main.rs:42) and so does this one, unless
+    WHISPER_HIP_RESAMPLE=1 routes it through the device resampler first."""
+    import wave
+    import whisper_burn_amd as wb
+    from whisper_burn_amd import dumpdir
+    from whisper_burn_amd import transcribe as cli
+    monkeypatch.chdir(tmp_path)
+    write_synthetic_tokenizer_json(str(tmp_path / "tokenizer.json"))
+    dims = synth.micro_dims(n_state=128, n_head=2, n_layer=2, n_vocab=N_VOCAB)
+    weights = synth.synth_weights(dims, seed=4242)
+    dumpdir.write_dump_dir(weights, str(tmp_path / "micro"))
+    from scipy.signal import resample_poly
+    hi = resample_poly(synth.synth_audio(16000 * 6, 52).astype(np.float64), 441, 320)       # a 22 050 Hz recording
+    pcm = np.clip(np.round(hi * 32767.0), -32768, 32767).astype("<i2")
+    with wave.open(str(tmp_path / "a22.wav"), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(22050); w.writeframes(pcm.tobytes())
+    monkeypatch.delenv("WHISPER_HIP_RESAMPLE", raising=False)
+    assert cli.main(["transcribe", "micro", "a22.wav", "en", "out.txt"]) == 1
+    assert "must be 16k" in capsys.readouterr().err
+    monkeypatch.setenv("WHISPER_HIP_RESAMPLE", "1")
+    assert cli.main(["transcribe", "micro", "a22.wav", "en", "out.txt"]) == 0
+    text = open(tmp_path / "out.txt").read()
+    # the same transcript as resampling by hand and calling the library
+    x16 = wb.resample(pcm.astype(np.float32) / np.float32(32767.0), 22050, 16000)
+    bpe = TokenizerAdapter.from_file(str(tmp_path / "tokenizer.json"))
+    ref_text, _ = wb.waveform_to_text(wb.Whisper.from_tensors(weights), bpe, "en", x16, 16000)
+    assert text == ref_text and len(text.split()) >= 2

@@ -82,6 +82,10 @@ def test_reference_asserts(tmp_path):
             wb.load_audio_waveform(p)
         assert e.value.status == -2 and msg in str(e.value)     # main.rs:42-43 asserts
     assert wb.wav_info(p1)["sample_rate"] == 44100               # the header query does not judge
+    x, sr = wb.load_audio_waveform(p1, any_rate=True)            # the resampler's reader: same scaling, no rate assert
+    assert sr == 44100 and x.shape == (100,) and not x.any()
+    with pytest.raises(wb.WbError):
+        wb.load_audio_waveform(p2, any_rate=True)                # still mono only
     with pytest.raises(wb.WbError) as e:
         wb.load_audio_waveform(str(tmp_path / "missing.wav"))
     assert e.value.status == -3

@@ -100,7 +100,17 @@ int wb_wav_info(const char* path, int64_t* n_samples, int32_t* sample_rate, int3
   return WB_OK;
 }
 
+static int read_wav_f32(const char* path, float* out, int64_t capacity, int64_t* n_samples, bool require_16k);
+
 int wb_wav_read_f32(const char* path, float* out, int64_t capacity, int64_t* n_samples) {
+  return read_wav_f32(path, out, capacity, n_samples, true);
+}
+
+int wb_wav_read_f32_any_rate(const char* path, float* out, int64_t capacity, int64_t* n_samples) {
+  return read_wav_f32(path, out, capacity, n_samples, false);
+}
+
+static int read_wav_f32(const char* path, float* out, int64_t capacity, int64_t* n_samples, bool require_16k) {
   WB_REQUIRE(path && out, WB_ERR_ARG, "wb_wav_read_f32: null argument");
   FILE* f = fopen(path, "rb");
   WB_REQUIRE(f, WB_ERR_IO, "cannot open %s", path);
@@ -108,7 +118,7 @@ int wb_wav_read_f32(const char* path, float* out, int64_t capacity, int64_t* n_s
   int rc = parse_header(f, path, &w);
   if (rc != WB_OK) { fclose(f); return rc; }
   struct Closer { FILE* f; ~Closer() { fclose(f); } } closer{f};
-  WB_REQUIRE(w.sample_rate == 16000, WB_ERR_SHAPE, "The audio sample rate must be 16k.");     // main.rs:42
+  WB_REQUIRE(!require_16k || w.sample_rate == 16000, WB_ERR_SHAPE, "The audio sample rate must be 16k.");   // main.rs:42
   WB_REQUIRE(w.channels == 1, WB_ERR_SHAPE, "The audio must be single-channel.");            // main.rs:43
   WB_REQUIRE(w.n_samples <= capacity, WB_ERR_ARG, "wb_wav_read_f32: %lld samples > capacity %lld",
              (long long)w.n_samples, (long long)capacity);

@@ -52,6 +52,10 @@ SIGNATURES = {
     "wb_burn_record_read": (C.c_int, [C.c_char_p, C.c_char_p, TENSOR_FN, C.c_void_p]),
     "wb_wav_info": (C.c_int, [C.c_char_p, c_int64_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p]),
     "wb_wav_read_f32": (C.c_int, [C.c_char_p, c_float_p, C.c_int64, c_int64_p]),
+    "wb_wav_read_f32_any_rate": (C.c_int, [C.c_char_p, c_float_p, C.c_int64, c_int64_p]),
+    "wb_resample_len": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
+    "wb_resample_filter": (C.c_int, [C.c_int32, C.c_int32, c_float_p, C.c_int32, c_int32_p, c_int32_p, c_int32_p]),
+    "wb_resample_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, c_int64_p]),
     "wb_pcm_s16_to_f32_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "wb_waveform_to_mels_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_double, c_int64_p, c_int64_p, C.c_int32,
                                           C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, c_int32_p, C.c_int32,

@@ -75,15 +75,43 @@ def burn_record_tensors(mpk_gz_path: str, cfg_path: Optional[str] = None) -> Dic
     return out
 
 
-def load_audio_waveform(path: str):
-    """bin/transcribe/main.rs:31-55: (f32 samples, sample_rate); 16 kHz mono only, like the reference."""
+def load_audio_waveform(path: str, any_rate: bool = False):
+    """bin/transcribe/main.rs:31-55: (f32 samples, sample_rate); 16 kHz mono only, like the reference, unless
+    `any_rate` (then the caller resamples: `resample`)."""
     lib = _lib.load()
     n, sr = C.c_int64(0), C.c_int32(0)
     check(lib.wb_wav_info(path.encode(), C.byref(n), C.byref(sr), None, None, None))
     out = np.empty(int(n.value), dtype=np.float32)
     got = C.c_int64(0)
-    check(lib.wb_wav_read_f32(path.encode(), _fp(out), int(n.value), C.byref(got)))
+    read = lib.wb_wav_read_f32_any_rate if any_rate else lib.wb_wav_read_f32
+    check(read(path.encode(), _fp(out), int(n.value), C.byref(got)))
     return out[:int(got.value)], int(sr.value)
+
+
+def resample_filter(rate_in: int, rate_out: int = 16000):
+    """(taps f32 [20*max(up,down)+1], up, down) of the device resampler (host only)."""
+    lib = _lib.load()
+    n, up, down = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    check(lib.wb_resample_filter(rate_in, rate_out, None, 0, C.byref(n), C.byref(up), C.byref(down)))
+    taps = np.empty(int(n.value), dtype=np.float32)
+    check(lib.wb_resample_filter(rate_in, rate_out, _fp(taps), int(n.value), None, None, None))
+    return taps, int(up.value), int(down.value)
+
+
+def resample(pcm, rate_in: int, rate_out: int = 16000, device: int = 0) -> np.ndarray:
+    """Polyphase resampling on the GPU (wb_resample_dev): f32 [n] -> f32 [ceil(n*rate_out/rate_in)]."""
+    import torch
+    lib = _lib.load()
+    x = torch.as_tensor(np.ascontiguousarray(pcm, dtype=np.float32)).to(f"cuda:{device}")
+    n_out = int(lib.wb_resample_len(x.numel(), rate_in, rate_out))
+    if n_out < 0:
+        raise ValueError(f"unsupported sample-rate pair {rate_in} -> {rate_out}")
+    y = torch.empty(max(n_out, 1), dtype=torch.float32, device=x.device)
+    torch.cuda.synchronize(x.device)
+    got = C.c_int64(0)
+    check(lib.wb_resample_dev(device, C.c_void_p(x.data_ptr()), x.numel(), rate_in, rate_out, C.c_void_p(y.data_ptr()),
+                              y.numel(), C.byref(got)))
+    return y[:int(got.value)].cpu().numpy()
 
 
 def wav_info(path: str) -> dict:

@@ -5,6 +5,10 @@ The reference's CLI (/root/reference/src/bin/transcribe/main.rs:85-157) over the
 directory (load.rs:295), the audio must be a 16 kHz mono WAV (main.rs:41-42; 16-bit PCM is scaled by 1 / 32767 as
 hound does, :44-51), `tokenizer.json` is read from the working directory (token.rs:13-19), the transcript is
 written to `<transcription file>` (main.rs:151-154).  Exit code 1 with the reference's messages on bad input.
+
+One addition: with `WHISPER_HIP_RESAMPLE=1` in the environment a mono WAV of another sample rate (the bundled
+22 050 Hz audio.wav, which the reference sends through `sox`, README.md:69-74) is resampled to 16 kHz on the GPU
+(wb_resample_dev) instead of being rejected.
 """
 from __future__ import annotations
 
@@ -30,7 +34,13 @@ def main(argv=None) -> int:
 
     print("Loading waveform...")
     try:
-        waveform, sample_rate = wb.load_audio_waveform(wav_file)          # asserts 16 kHz mono like main.rs:41-42
+        if os.environ.get("WHISPER_HIP_RESAMPLE", "0") == "1":
+            waveform, sample_rate = wb.load_audio_waveform(wav_file, any_rate=True)
+            if sample_rate != 16000:
+                print(f"Resampling {sample_rate} Hz -> 16000 Hz...")
+                waveform, sample_rate = wb.resample(waveform, sample_rate, 16000), 16000
+        else:
+            waveform, sample_rate = wb.load_audio_waveform(wav_file)      # asserts 16 kHz mono like main.rs:41-42
     except Exception as e:                                                 # noqa: BLE001
         print(f"Failed to load audio file: {e}", file=sys.stderr)
         return 1
