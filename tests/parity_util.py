@@ -23,14 +23,24 @@ def ost(st) -> otr.SpecialTokens:
                              st.end_of_text, np.asarray(st.is_special).astype(bool))
 
 
-def window_mels(oracle: OracleWhisper, audio: np.ndarray, sample_rate: int = 16000, padding: int = 10):
+def window_mels(oracle: OracleWhisper, audio: np.ndarray, sample_rate: int = 16000, padding: int = 10, frontend=None):
     """Per reference window: the clipped + zero-padded log-mel the decode driver feeds the encoder
-    (transcribe.rs:120-128, :134, :171-177)."""
+    (transcribe.rs:120-128, :134, :171-177).
+
+    `frontend` (window f32 [N] -> log-mel [1, 80, N // 160]) replaces the oracle's own prep_audio: the model-parity
+    tests at 1e-3 hand BOTH sides the same log-mel, because the oracle's f32 dense DFT is itself 2e-5 away from the
+    exact (f64) log-mel -- 3x further than the HIP frontend -- and the synthetic checkpoints amplify a log-mel
+    difference ~25x into the logits (tools/diag_stage_error.py: 5.7e-4 of logit difference from the oracle's mel
+    rounding alone, against 6e-5 for each side's whole decoder).  The frontend has its own tests and tolerance."""
     n_ctx = oracle.encoder_ctx_size()
     wlen = omel.max_waveform_samples(n_ctx - padding)
     out = []
     for start, end in otr.window_extents(len(audio), sample_rate, wlen):
-        mel = omel.prep_audio(torch.from_numpy(np.asarray(audio[start:end], np.float32))[None], float(sample_rate))
+        win = np.asarray(audio[start:end], np.float32)
+        if frontend is not None:
+            mel = torch.from_numpy(np.asarray(frontend(win), np.float32).reshape(1, 80, -1))
+        else:
+            mel = omel.prep_audio(torch.from_numpy(win)[None], float(sample_rate))
         mel = torch.cat([mel[:, :, :min(mel.shape[2], n_ctx - padding)], torch.zeros(1, 80, padding)], 2)
         out.append(mel)
     return out

@@ -12,6 +12,8 @@
 // gathered with the matching kv permutation.  Row max / sum are per lane (+ one xor-32 exchange).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "kernels.h"
 #include "wave_ops.h"
 
@@ -162,13 +164,203 @@ __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(const float* __r
   }
 }
 
+// The same arithmetic for SMALL grids (a few windows: the 128-query blocks above leave most of the 256 CUs idle and
+// every wave walks the whole key range alone).  One block per 32 queries; its NW waves split the KEY tiles
+// (wave w takes tiles w, w+NW, ...), so nothing is shared between waves: K and V go straight from global memory
+// into the MFMA operand layout (a lane's K operand is 32 contiguous floats of one key row, its V operands are
+// 128-byte row segments) -- no LDS, no barrier in the loop.  The NW partial (max, sum, O) triples are merged once
+// through LDS in a fixed order (deterministic; differs from the single-chain result only by f32 rounding).
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attention_f32_kvsplit_kernel(const float* __restrict__ Q, int ldq,
+                                                                          const float* __restrict__ K,
+                                                                          const float* __restrict__ V, int ldkv,
+                                                                          float* __restrict__ O, int ldo,
+                                                                          const AttnSeg* __restrict__ segs, float scale,
+                                                                          int causal) {
+  __shared__ float part[NW][34][64];
+  const AttnSeg seg = segs[blockIdx.z];
+  const int head = blockIdx.y;
+  const int q_base = blockIdx.x * 32;
+  if (q_base >= seg.q_len) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, hh = lane >> 5;
+  const int qi = q_base + li;
+  const int qrow = min(qi, seg.q_len - 1);
+
+  float qreg[32];
+  {
+    const float4* qp = reinterpret_cast<const float4*>(Q + (int64_t)(seg.q_row0 + qrow) * ldq + head * 64 + hh * 32);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      float4 v = qp[i];
+      qreg[4 * i + 0] = v.x * scale; qreg[4 * i + 1] = v.y * scale;
+      qreg[4 * i + 2] = v.z * scale; qreg[4 * i + 3] = v.w * scale;
+    }
+  }
+  int kv_end = seg.kv_len;
+  if (causal) kv_end = min(kv_end, q_base + 32);
+  const int n_tiles = (kv_end + KV_TILE - 1) / KV_TILE;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);                     // wave-uniform on the scalar side
+  const float* Kh = K + (int64_t)seg.kv_row0 * ldkv + head * 64;              // uniform bases; lane parts are 32-bit offsets
+  const float* Vh = V + (int64_t)seg.kv_row0 * ldkv + head * 64;
+  const int koff_lane = li * ldkv + hh * 32;                                   // this lane's half of key row li
+  const int voff_lane = 4 * hh * ldkv + li;                                    // this lane's column, rows 4hh + perm(s)
+
+  auto load_tile = [&](int t, float4 (&kr)[8], float (&vr)[32]) {
+    const bool full = (t + 1) * KV_TILE <= seg.kv_len;
+    const float* kt = Kh + (int64_t)t * KV_TILE * ldkv;
+    const float* vt = Vh + (int64_t)t * KV_TILE * ldkv;
+    if (full) {
+      const float4* kp = reinterpret_cast<const float4*>(kt + koff_lane);
+#pragma unroll
+      for (int i = 0; i < 8; i++) kr[i] = kp[i];
+#pragma unroll
+      for (int s = 0; s < 16; s++) {
+        const float* vp = vt + ((s & 3) + 8 * (s >> 2)) * ldkv;              // uniform row base
+        vr[s] = vp[voff_lane];
+        vr[16 + s] = vp[voff_lane + 32];
+      }
+    } else {                                                                   // the last tile of a segment: rows past the end are zeros
+      const bool kok = t * KV_TILE + li < seg.kv_len;
+#pragma unroll
+      for (int i = 0; i < 8; i++) kr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kok) {
+        const float4* kp = reinterpret_cast<const float4*>(kt + koff_lane);
+#pragma unroll
+        for (int i = 0; i < 8; i++) kr[i] = kp[i];
+      }
+#pragma unroll
+      for (int s = 0; s < 16; s++) {
+        const int r = t * KV_TILE + 4 * hh + (s & 3) + 8 * (s >> 2);
+        const float* vp = vt + ((s & 3) + 8 * (s >> 2)) * ldkv;
+        vr[s] = 0.f; vr[16 + s] = 0.f;                                         // P is exactly 0 there, but 0 * garbage must stay 0
+        if (r < seg.kv_len) { vr[s] = vp[voff_lane]; vr[16 + s] = vp[voff_lane + 32]; }
+      }
+    }
+  };
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int t = 0; t < 2; t++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) oacc[t][r] = 0.f;
+  float m_run = -1.0e30f, l_run = 0.f;
+
+  auto compute = [&](int t, float4 (&kr)[8], float (&vr)[32]) {
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) sacc[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[i].x * scale, qreg[4 * i + 0], sacc, 0, 0, 0);   // mod.rs:510-514
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[i].y * scale, qreg[4 * i + 1], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[i].z * scale, qreg[4 * i + 2], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[i].w * scale, qreg[4 * i + 3], sacc, 0, 0, 0);
+    }
+    const int kv0 = t * KV_TILE + 4 * hh;
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int kv = kv0 + (r & 3) + 8 * (r >> 2);
+      const bool ok = kv < seg.kv_len && (!causal || kv <= qi);
+      sacc[r] = ok ? sacc[r] : -INFINITY;
+      tmax = fmaxf(tmax, sacc[r]);
+    }
+    tmax = xor32_max(tmax);
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      sacc[r] = expf(sacc[r] - m_new);
+      psum += sacc[r];
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) oacc[tt][r] *= alpha;
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+      for (int s = 0; s < 16; s++)
+        oacc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[16 * tt + s], sacc[s], oacc[tt], 0, 0, 0);
+  };
+
+  {
+    float4 k0[8], k1[8];
+    float v0[32], v1[32];
+    int t = wave_u;
+    if (t < n_tiles) load_tile(t, k0, v0);
+    while (t < n_tiles) {
+      if (t + NW < n_tiles) load_tile(t + NW, k1, v1);
+      compute(t, k0, v0);
+      t += NW;
+      if (t >= n_tiles) break;
+      if (t + NW < n_tiles) load_tile(t + NW, k0, v0);
+      compute(t, k1, v1);
+      t += NW;
+    }
+  }
+
+  // ---- merge the NW partial results (fixed order w = 0 .. NW-1) ----
+#pragma unroll
+  for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) part[wave][16 * tt + r][lane] = oacc[tt][r];
+  part[wave][32][lane] = m_run;
+  part[wave][33][lane] = l_run;
+  __syncthreads();
+  float m_all = -1.0e30f;
+#pragma unroll
+  for (int w = 0; w < NW; w++) m_all = fmaxf(m_all, part[w][32][lane]);
+  float sc[NW], l_all = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; w++) {
+    sc[w] = expf(part[w][32][lane] - m_all);
+    l_all += part[w][33][lane] * sc[w];
+  }
+  const float l_tot = xor32_sum(l_all);
+  if (qi < seg.q_len) {
+    // wave w finishes accumulator registers [32/NW * w, 32/NW * (w+1)): whole float4 groups of the output row
+    constexpr int GPW = 8 / NW;                 // float4 groups per wave
+    static_assert(8 % NW == 0, "NW must divide the 8 output groups");
+    float* op = O + (int64_t)(seg.q_row0 + qi) * ldo + head * 64;
+#pragma unroll
+    for (int gi = 0; gi < GPW; gi++) {
+      const int gg = wave * GPW + gi, tt = gg >> 2, g = gg & 3;
+      float o[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; w++) a += part[w][16 * tt + 4 * g + c][lane] * sc[w];
+        o[c] = a / l_tot;
+      }
+      *reinterpret_cast<float4*>(op + 32 * tt + 8 * g + 4 * hh) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
 }  // namespace
+
+static bool attention_kvsplit_enabled() {
+  static const bool on = [] { const char* e = getenv("WHISPER_HIP_ATTN_KVSPLIT"); return !(e && e[0] == '0'); }();
+  return on;
+}
 
 void launch_attention_f32(hipStream_t st, const float* Q, int ldq, const float* K, const float* V, int ldkv,
                           float* O, int ldo, const AttnSeg* segs_dev, int n_segs, int max_q_len, int n_head,
                           float scale, int causal) {
   if (n_segs <= 0 || max_q_len <= 0) return;
-  if (max_q_len <= 64) {
+  const int64_t blocks128 = (int64_t)((max_q_len + 127) / 128) * n_head * n_segs;
+  if (!causal && max_q_len >= 256 && blocks128 < 384 && attention_kvsplit_enabled()) {
+    // a few windows: 128-query blocks cannot fill 256 CUs; split the keys over the waves instead
+    dim3 grid((max_q_len + 31) / 32, n_head, n_segs);
+    hipLaunchKernelGGL((attention_f32_kvsplit_kernel<4>), grid, dim3(256), 0, st, Q, ldq, K, V, ldkv, O, ldo, segs_dev,
+                       scale, causal);
+  } else if (max_q_len <= 64) {
     dim3 grid((max_q_len + 63) / 64, n_head, n_segs);
     hipLaunchKernelGGL((attention_f32_kernel<2>), grid, dim3(128), 0, st, Q, ldq, K, V, ldkv, O, ldo, segs_dev,
                        scale, causal);

@@ -99,16 +99,10 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
       for (int i = 0; i < A_F4; i++) {
         int idx = tid + i * NT, kq = (idx % KQ) * 4;
         int k = k0 + kq;
+        // the load only: masking of a partially valid quad happens in store_tile, when the registers are consumed --
+        // touching the value here would put an s_waitcnt vmcnt(0) behind every prefetch
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a_row[i] != nullptr && k + 3 >= a_klo[i] && k < a_khi[i]) {
-          v = *reinterpret_cast<const float4*>(a_row[i] + k);
-          if (k < a_klo[i] || k + 3 >= a_khi[i]) {   // partially masked quad (not hit by aligned callers)
-            if (k + 0 < a_klo[i] || k + 0 >= a_khi[i]) v.x = 0.f;
-            if (k + 1 < a_klo[i] || k + 1 >= a_khi[i]) v.y = 0.f;
-            if (k + 2 < a_klo[i] || k + 2 >= a_khi[i]) v.z = 0.f;
-            if (k + 3 < a_klo[i] || k + 3 >= a_khi[i]) v.w = 0.f;
-          }
-        }
+        if (a_row[i] != nullptr && k + 3 >= a_klo[i] && k < a_khi[i]) v = *reinterpret_cast<const float4*>(a_row[i] + k);
         ra[i] = v;
       }
     } else {
@@ -130,12 +124,19 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
       rb[i] = v;
     }
   };
-  auto store_tile = [&](int buf, auto& ra, auto& rc1, auto& rb) {
+  auto store_tile = [&](int buf, int k0, auto& ra, auto& rc1, auto& rb) {
     if constexpr (AMODE == AMODE_ROWS) {
 #pragma unroll
       for (int i = 0; i < A_F4; i++) {
         int idx = tid + i * NT, r = idx / KQ, kq = (idx % KQ) * 4;
         if (r < BM) {
+          const int k = k0 + kq;
+          if (k < a_klo[i] || k + 3 >= a_khi[i]) {   // partially masked quad (not hit by aligned callers)
+            if (k + 0 < a_klo[i] || k + 0 >= a_khi[i]) ra[i].x = 0.f;
+            if (k + 1 < a_klo[i] || k + 1 >= a_khi[i]) ra[i].y = 0.f;
+            if (k + 2 < a_klo[i] || k + 2 >= a_khi[i]) ra[i].z = 0.f;
+            if (k + 3 < a_klo[i] || k + 3 >= a_khi[i]) ra[i].w = 0.f;
+          }
           As[buf][kq + 0][r] = ra[i].x; As[buf][kq + 1][r] = ra[i].y;
           As[buf][kq + 2][r] = ra[i].z; As[buf][kq + 3][r] = ra[i].w;
         }
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
   for (int u = 0; u < PF; u++)
     if (u < nk) load_tile(kbeg + u * BK, ra_[u], rc1_[u], rb_[u]);
   if (nk > 0) {
-    store_tile(0, ra_[0], rc1_[0], rb_[0]);
+    store_tile(0, kbeg, ra_[0], rc1_[0], rb_[0]);
     if (PF < nk) load_tile(kbeg + PF * BK, ra_[0], rc1_[0], rb_[0]);
   }
   __syncthreads();
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     if (t + 1 < nk) {
-      store_tile(buf ^ 1, ra_[(u + 1) % PF], rc1_[(u + 1) % PF], rb_[(u + 1) % PF]);
+      store_tile(buf ^ 1, kbeg + (t + 1) * BK, ra_[(u + 1) % PF], rc1_[(u + 1) % PF], rb_[(u + 1) % PF]);
       if (t + 1 + PF < nk) load_tile(kbeg + (t + 1 + PF) * BK, ra_[(u + 1) % PF], rc1_[(u + 1) % PF], rb_[(u + 1) % PF]);
     }
     __syncthreads();
@@ -202,25 +203,44 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
   }
 
   // ---- epilogue ----
+  // Straight-line per 32x32 sub-tile: all residual / positional reads of its 16 rows are issued back to back from
+  // clamped addresses (a per-row branch would serialise them into 16 dependent round trips), then the arithmetic,
+  // then predicated stores.
 #pragma unroll
   for (int i = 0; i < RM; i++)
 #pragma unroll
     for (int j = 0; j < RN; j++) {
       const int col = n0 + wn * TN + j * 32 + li;
-      if (col >= N) continue;
-      const float bias = g.bias ? g.bias[col] : 0.f;
+      const bool col_ok = col < N;
+      const int colc = col_ok ? col : N - 1;
+      const float bias = g.bias ? g.bias[colc] : 0.f;
       float cs = 1.f;
-      if (g.col_scale_period > 0 && (col % g.col_scale_period) < g.col_scale_width) cs = g.col_scale;
+      if (g.col_scale_period > 0 && (colc % g.col_scale_period) < g.col_scale_width) cs = g.col_scale;
+      const int rbase = m0 + wm * TM + i * 32 + 4 * lh;
+      float res[16], ax[16];
+      if (g.residual) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row = min(rbase + (r & 3) + 8 * (r >> 2), M - 1);
+          res[r] = g.residual[(int64_t)row * g.ldr + colc];
+        }
+      }
+      if (g.aux) {
+        int ai[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) ai[r] = g.aux_idx[min(rbase + (r & 3) + 8 * (r >> 2), M - 1)];
+#pragma unroll
+        for (int r = 0; r < 16; r++) ax[r] = g.aux[(int64_t)ai[r] * g.ld_aux + colc];
+      }
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row >= M) continue;
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
         float v = acc[i][j][r] + bias;
         if (g.act == ACT_GELU) v = gelu_erf(v);
         if (g.col_scale_period > 0) v *= cs;
-        if (g.residual) v = g.residual[(int64_t)row * g.ldr + col] + v;
-        if (g.aux) v = v + g.aux[(int64_t)g.aux_idx[row] * g.ld_aux + col];
-        Cout[(int64_t)row * g.ldc + col] = v;
+        if (g.residual) v = res[r] + v;
+        if (g.aux) v = v + ax[r];
+        if (col_ok && row < M) Cout[(int64_t)row * g.ldc + col] = v;
       }
     }
 }
@@ -230,6 +250,30 @@ void launch_cfg(hipStream_t st, const GemmArgs& a) {
   dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.ksplit > 1 ? a.ksplit : 1);
   hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, AMODE, BK, PF>), grid, dim3(NT), 0, st, a);
 }
+
+#ifdef WB_GEMM_PROBE
+// tools/gemm_probe.cpp: one tile / k-depth / prefetch configuration by number
+int launch_gemm_f32_cfg(hipStream_t st, const GemmArgs& a, int cfg) {
+  switch (cfg) {
+    case 0: launch_cfg<64, 64, 2, 2, AMODE_ROWS, 16, 1>(st, a); break;
+    case 1: launch_cfg<64, 64, 2, 2, AMODE_ROWS, 16, 2>(st, a); break;
+    case 2: launch_cfg<64, 64, 2, 2, AMODE_ROWS, 16, 4>(st, a); break;
+    case 3: launch_cfg<64, 64, 2, 2, AMODE_ROWS, 32, 1>(st, a); break;
+    case 4: launch_cfg<64, 64, 2, 2, AMODE_ROWS, 32, 2>(st, a); break;
+    case 5: launch_cfg<64, 64, 2, 2, AMODE_ROWS, 32, 3>(st, a); break;
+    case 6: launch_cfg<128, 128, 2, 2, AMODE_ROWS, 16, 1>(st, a); break;
+    case 7: launch_cfg<128, 128, 2, 2, AMODE_ROWS, 16, 2>(st, a); break;
+    case 8: launch_cfg<128, 128, 2, 2, AMODE_ROWS, 16, 3>(st, a); break;
+    case 9: launch_cfg<128, 64, 2, 2, AMODE_ROWS, 16, 2>(st, a); break;
+    case 10: launch_cfg<128, 64, 2, 2, AMODE_ROWS, 32, 2>(st, a); break;
+    case 11: launch_cfg<64, 128, 2, 2, AMODE_ROWS, 32, 2>(st, a); break;
+    case 12: launch_cfg<32, 128, 1, 4, AMODE_ROWS, 32, 2>(st, a); break;
+    case 13: launch_cfg<32, 128, 1, 4, AMODE_ROWS, 32, 3>(st, a); break;
+    default: return -1;
+  }
+  return 0;
+}
+#endif
 
 }  // namespace
 
@@ -246,11 +290,21 @@ int launch_gemm_f32(hipStream_t st, const GemmArgs& a) {
     return 0;
   }
   if (a.ksplit > 1 && a.K % 32 != 0) return -1;
-  if (a.M <= 32 && a.ksplit > 1) launch_cfg<32, 128, 1, 4, AMODE_ROWS, 32, 3>(st, a);
-  else if (a.M <= 32) launch_cfg<32, 128, 1, 4, AMODE_ROWS>(st, a);
-  else if (a.ksplit > 1) launch_cfg<64, 64, 2, 2, AMODE_ROWS, 32, 3>(st, a);
-  else if (blocks(128, 128) >= 384) launch_cfg<128, 128, 2, 2, AMODE_ROWS>(st, a);
-  else launch_cfg<64, 64, 2, 2, AMODE_ROWS>(st, a);
+  // Measured on MI355X with tools/gemm_probe.cpp (bit-identical results across configurations: the k order of
+  // the accumulation chain never changes).  Many-block shapes (>= 3 blocks per CU at 128x128) are fastest on
+  // 128x128 tiles with two k-tiles in flight; everything smaller -- the bench's 3-window encoder, the N = d
+  // projections of `small` -- on 32x128 tiles (1x4 waves), 32-deep k-tiles, two in flight.
+  if (a.ksplit > 1) {
+    if (a.M <= 32) launch_cfg<32, 128, 1, 4, AMODE_ROWS, 32, 3>(st, a);
+    else launch_cfg<64, 64, 2, 2, AMODE_ROWS, 32, 3>(st, a);
+  } else if (a.K % 32 != 0) {
+    if (a.M <= 32) launch_cfg<32, 128, 1, 4, AMODE_ROWS>(st, a);
+    else launch_cfg<64, 64, 2, 2, AMODE_ROWS>(st, a);
+  } else if (blocks(128, 128) >= 768) {
+    launch_cfg<128, 128, 2, 2, AMODE_ROWS, 16, 2>(st, a);
+  } else {
+    launch_cfg<32, 128, 1, 4, AMODE_ROWS, 32, 2>(st, a);
+  }
   return 0;
 }
 

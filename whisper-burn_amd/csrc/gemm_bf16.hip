@@ -76,7 +76,9 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs g, const u16* __
       }
     }
   }
-  uint4 ra[A_IT], rb[B_IT];
+  // A stays f32 in registers until store_tile: converting here would wait for the load right behind its issue
+  float4 ra_lo[A_IT], ra_hi[A_IT];
+  uint4 rb[B_IT];
   auto load_tile = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < A_IT; i++) {
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs g, const u16* __
         lo = *reinterpret_cast<const float4*>(a_row[i] + k);
         hi = *reinterpret_cast<const float4*>(a_row[i] + k + 4);
       }
-      ra[i] = pack8(lo, hi);
+      ra_lo[i] = lo; ra_hi[i] = hi;
     }
 #pragma unroll
     for (int i = 0; i < B_IT; i++) {
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs g, const u16* __
 #pragma unroll
     for (int i = 0; i < A_IT; i++) {
       const int idx = tid + i * NT, r = idx / (BK / 8), ko = (idx % (BK / 8)) * 8;
-      if (r < BM) *reinterpret_cast<uint4*>(&As[buf][r][ko]) = ra[i];
+      if (r < BM) *reinterpret_cast<uint4*>(&As[buf][r][ko]) = pack8(ra_lo[i], ra_hi[i]);
     }
 #pragma unroll
     for (int i = 0; i < B_IT; i++) {
@@ -143,25 +145,43 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs g, const u16* __
     __syncthreads();
   }
 
+  // epilogue: batched residual / positional reads from clamped addresses, then arithmetic, then predicated stores
+  // (same structure as gemm.hip)
 #pragma unroll
   for (int i = 0; i < RM; i++)
 #pragma unroll
     for (int j = 0; j < RN; j++) {
       const int col = n0 + wn * TN + j * 32 + li;
-      if (col >= N) continue;
-      const float bias = g.bias ? g.bias[col] : 0.f;
+      const bool col_ok = col < N;
+      const int colc = col_ok ? col : N - 1;
+      const float bias = g.bias ? g.bias[colc] : 0.f;
       float cs = 1.f;
-      if (g.col_scale_period > 0 && (col % g.col_scale_period) < g.col_scale_width) cs = g.col_scale;
+      if (g.col_scale_period > 0 && (colc % g.col_scale_period) < g.col_scale_width) cs = g.col_scale;
+      const int rbase = m0 + wm * TM + i * 32 + 4 * lh;
+      float res[16], ax[16];
+      if (g.residual) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row = min(rbase + (r & 3) + 8 * (r >> 2), M - 1);
+          res[r] = g.residual[(int64_t)row * g.ldr + colc];
+        }
+      }
+      if (g.aux) {
+        int ai[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) ai[r] = g.aux_idx[min(rbase + (r & 3) + 8 * (r >> 2), M - 1)];
+#pragma unroll
+        for (int r = 0; r < 16; r++) ax[r] = g.aux[(int64_t)ai[r] * g.ld_aux + colc];
+      }
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row >= M) continue;
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
         float v = acc[i][j][r] + bias;
         if (g.act == ACT_GELU) v = gelu_erf(v);
         if (g.col_scale_period > 0) v *= cs;
-        if (g.residual) v = g.residual[(int64_t)row * g.ldr + col] + v;
-        if (g.aux) v = v + g.aux[(int64_t)g.aux_idx[row] * g.ld_aux + col];
-        Cout[(int64_t)row * g.ldc + col] = v;
+        if (g.residual) v = res[r] + v;
+        if (g.aux) v = v + ax[r];
+        if (col_ok && row < M) Cout[(int64_t)row * g.ldc + col] = v;
       }
     }
 }
