@@ -252,6 +252,16 @@ int wb_stitch_windows(const int32_t* win_tokens, int32_t row_stride, const int32
                       int n_windows, int max_n_offsets, int min_n_overlaps, int32_t* out,
                       int64_t cap, int64_t* n_out);
 
+/* The reference's retired greedy decoder kept its repetition detectors (transcribe.rs:385-447, dead code there):
+ *   wb_first_repetition_end        :385-393   (period > n, a usize underflow panic there -> WB_ERR_ARG)
+ *   wb_repetition_period           :395-417   returns the period, 0 for None
+ *   wb_find_repeated_tokens_index  :419-447   returns 1 and the (first, second) window indices, else 0
+ * They serve the optional legacy greedy mode (whisper_burn_amd.legacy.legacy_greedy over the session API). */
+int64_t wb_first_repetition_end(const int32_t* tokens, int64_t n, int64_t period);
+int64_t wb_repetition_period(const int32_t* tokens, int64_t n, int64_t min_repetitions);
+int wb_find_repeated_tokens_index(const int32_t* tokens, int64_t n, int64_t window_size, int64_t min_repeat_count,
+                                  int64_t* first_repeat_index, int64_t* end);
+
 /* The constant tables of the frontend, built on the host in the reference's f32 op order: periodic Hann window
  * (hann_window_device, audio.rs:272-278) and the dense [80][201] Slaney filterbank (get_mel_filters_device,
  * audio.rs:67-143; the kernel keeps it sparse).  No GPU needed; for table-vs-oracle tests. */

@@ -12,6 +12,7 @@ per layer per call (transcribe.rs:270, mod.rs:482-490), logits for all positions
 """
 from __future__ import annotations
 
+import math
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -131,3 +132,83 @@ def stitch(tokens: List[int], new_tokens: List[int]) -> List[int]:
         prev_index, curr_index = ov
         return tokens[:prev_index] + list(new_tokens[curr_index:])
     return tokens + list(new_tokens)
+
+
+# ---- the reference's retired greedy decoder (dead code there; an optional mode here) ---------------------
+
+def first_repetition_end(tokens: Sequence[int], period: int) -> int:
+    """transcribe.rs:385-393.  (usize arithmetic: len < period would panic in the reference -> ValueError.)"""
+    n = len(tokens)
+    if n < period:
+        raise ValueError("tokens.len() - period underflows")
+    for i in reversed(range(period, n - period)):
+        if list(tokens[i - period:i]) != list(tokens[i:i + period]):
+            return i + 1
+    return period
+
+
+def repetition_period(tokens: Sequence[int], min_repetitions: int) -> Optional[int]:
+    """transcribe.rs:395-417."""
+    n = len(tokens)
+    for i in reversed(range(n)):
+        period = n - i
+        if i // period < min_repetitions:
+            return None
+        ok = True
+        for j in range(min_repetitions):
+            e = i - period * j
+            s = e - period
+            if list(tokens[s:e]) != list(tokens[i:i + period]):
+                ok = False
+                break
+        if ok:
+            return period
+    return None
+
+
+def find_repeated_tokens_index(tokens: Sequence[int], window_size: int, min_repeat_count: int) -> Optional[Tuple[int, int]]:
+    """transcribe.rs:419-447: (index of the first window equal to the last one, index of the second)."""
+    n = len(tokens)
+    if 2 * window_size > n:
+        return None                                              # :425-427
+    last_index = n - window_size
+    last_window = list(tokens[last_index:])
+    repeats = [i for i in range(0, last_index - window_size + 1)          # 0..=(last_index - window_size), :432
+               if list(tokens[i:i + window_size]) == last_window]
+    if len(repeats) >= min_repeat_count:                          # :439-443 (min_repeat_count >= 2 or .unwrap() panics)
+        return repeats[0], repeats[1]
+    return None
+
+
+def legacy_greedy(whisper: OracleWhisper, st: SpecialTokens, mels: torch.Tensor, padding: int = 10,
+                  repeat_window_size: int = 5, min_n_repeats: int = 4, max_tokens: Optional[int] = None) -> List[int]:
+    """The commented-out loop of mels_to_text (transcribe.rs:314-378): argmax of the RAW last-row logits (no special-token
+    mask, no log-softmax), stop when exp(eot_logit - token_logit) > 0.5 (:351) or when the last 5 tokens already
+    occurred >= 4 times (:369-377, truncating to the second occurrence), or at n_text_ctx tokens (:317-320).
+    `max_tokens` (not in the reference) bounds the loop for tests."""
+    n_ctx_max_encoder = whisper.encoder_ctx_size()
+    n_mel = mels.shape[2]
+    mels = torch.cat([mels[:, :, :min(n_mel, n_ctx_max_encoder - padding)], torch.zeros(1, mels.shape[1], padding)], 2)
+    enc = whisper.forward_encoder(mels)
+    n_ctx = whisper.decoder_ctx_size() if max_tokens is None else min(max_tokens, whisper.decoder_ctx_size())
+    tokens = [st.start_of_transcript, st.language, st.transcribe, st.no_timestamps]
+    while True:
+        if len(tokens) >= n_ctx:
+            tokens.append(st.end_of_text)
+            break
+        out = whisper.forward_decoder(torch.tensor([tokens], dtype=torch.long), enc)
+        last = out[0, len(tokens) - 1]
+        token_id = int(torch.argmax(last))                       # burn argmax: first maximum
+        token_logit = float(last[token_id])
+        eot_logit = float(last[st.end_of_text])
+        tokens.append(token_id)
+        if math.exp(eot_logit - token_logit) > 0.5:
+            if token_id != st.end_of_text:
+                tokens.append(st.end_of_text)
+            break
+        hit = find_repeated_tokens_index(tokens, repeat_window_size, min_n_repeats)
+        if hit is not None:
+            tokens = tokens[:hit[1]]
+            tokens.append(st.end_of_text)
+            break
+    return tokens

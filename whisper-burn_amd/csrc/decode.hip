@@ -427,18 +427,53 @@ __global__ __launch_bounds__(256) void dec_topk_merge_kernel(int* __restrict__ s
   __shared__ int redi[4];
   __shared__ float bc[2];
   const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (r >= st[ST_N]) return;
+  const int n_live = st[ST_N], len_now = st[lay.len + r];      // requested together with the tile records below
   const float* ts = tstats + (int64_t)r * n_tiles * TS_STRIDE;
+  // Ordinary vocabularies give <= 512 tiles: each thread pulls the whole record of its (at most) two tiles -- max,
+  // sum-exp and the k candidates -- in ONE batch of loads, so the row costs one global round trip instead of three
+  // dependent passes over the same records.
+  constexpr int TPT = 2;
+  const bool fast = n_tiles <= 256 * TPT;
+  float pm[TPT], psum[TPT], pcv[TPT][TOPK_MAX];
+  int pci[TPT][TOPK_MAX];
+  if (fast) {
+#pragma unroll
+    for (int j = 0; j < TPT; j++) {
+      const int t = tid + 256 * j;
+      const bool ok = t < n_tiles;
+      const float* rec = ts + (int64_t)(ok ? t : 0) * TS_STRIDE;
+      pm[j] = ok ? rec[0] : -INFINITY;
+      psum[j] = ok ? rec[1] : 0.f;
+#pragma unroll
+      for (int q = 0; q < TOPK_MAX; q++) {
+        const bool okq = ok && q < k;
+        pcv[j][q] = okq ? rec[2 + 2 * q] : -INFINITY;
+        pci[j][q] = okq ? __float_as_int(rec[3 + 2 * q]) : 0x7fffffff;
+      }
+    }
+  }
+  if (r >= n_live) return;
   float m = -INFINITY;
-  for (int t = tid; t < n_tiles; t += 256) m = fmaxf(m, ts[t * TS_STRIDE]);
+  if (fast) {
+#pragma unroll
+    for (int j = 0; j < TPT; j++) m = fmaxf(m, pm[j]);
+  } else {
+    for (int t = tid; t < n_tiles; t += 256) m = fmaxf(m, ts[t * TS_STRIDE]);
+  }
   m = wave_max(m);
   if (lane == 0) redv[wave] = m;
   __syncthreads();
   const float M = fmaxf(fmaxf(redv[0], redv[1]), fmaxf(redv[2], redv[3]));
   float s = 0.f;
-  for (int t = tid; t < n_tiles; t += 256) {
-    const float mt = ts[t * TS_STRIDE];
-    if (mt > -INFINITY) s += expf(mt - M) * ts[t * TS_STRIDE + 1];
+  if (fast) {
+#pragma unroll
+    for (int j = 0; j < TPT; j++)
+      if (pm[j] > -INFINITY) s += expf(pm[j] - M) * psum[j];
+  } else {
+    for (int t = tid; t < n_tiles; t += 256) {
+      const float mt = ts[t * TS_STRIDE];
+      if (mt > -INFINITY) s += expf(mt - M) * ts[t * TS_STRIDE + 1];
+    }
   }
   s = wave_sum(s);
   __syncthreads();
@@ -448,22 +483,31 @@ __global__ __launch_bounds__(256) void dec_topk_merge_kernel(int* __restrict__ s
     bc[0] = logf((redv[0] + redv[1]) + (redv[2] + redv[3]));
     row_stats[2 * r] = M; row_stats[2 * r + 1] = bc[0];
   }
-  // local top-k over this thread's candidates (value desc, id asc)
+  // local top-k over this thread's candidates (value desc, id asc): a strict total order, so the merged result does
+  // not depend on how the candidates are dealt to the threads
   float tv[TOPK_MAX]; int ti[TOPK_MAX];
 #pragma unroll
   for (int j = 0; j < TOPK_MAX; j++) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
-  for (int c = tid; c < n_tiles * k; c += 256) {
-    const int t = c / k, j = c - t * k;
-    float cv = ts[t * TS_STRIDE + 2 + 2 * j]; int ci = __float_as_int(ts[t * TS_STRIDE + 3 + 2 * j]);
+  auto insert = [&](float cv, int ci) {
     if (cv > -INFINITY) {
 #pragma unroll
       for (int q = 0; q < TOPK_MAX; q++)
         if (better(cv, ci, tv[q], ti[q])) { float a = tv[q]; int b = ti[q]; tv[q] = cv; ti[q] = ci; cv = a; ci = b; }
     }
+  };
+  if (fast) {
+#pragma unroll
+    for (int j = 0; j < TPT; j++)
+#pragma unroll
+      for (int q = 0; q < TOPK_MAX; q++) insert(pcv[j][q], pci[j][q]);
+  } else {
+    for (int c = tid; c < n_tiles * k; c += 256) {
+      const int t = c / k, j = c - t * k;
+      insert(ts[t * TS_STRIDE + 2 + 2 * j], __float_as_int(ts[t * TS_STRIDE + 3 + 2 * j]));
+    }
   }
   __syncthreads();
   const float lse = bc[0];
-  const int len_now = st[lay.len + r];
   int first = 0;
   for (int round = 0; round < k; round++) {
     float bv = tv[0]; int bi = ti[0];

@@ -72,6 +72,53 @@ int wb_find_chunk_overlap(const int32_t* prev, int64_t n_prev, const int32_t* cu
   return 0;
 }
 
+// ---- the reference's retired repetition detectors (transcribe.rs:385-447; dead code there, optional mode here) ----
+
+int64_t wb_first_repetition_end(const int32_t* tokens, int64_t n, int64_t period) {
+  // transcribe.rs:385-393; tokens.len() - period underflows (a panic there) -> WB_ERR_ARG
+  WB_REQUIRE(tokens && period >= 0 && n >= period, WB_ERR_ARG, "wb_first_repetition_end: period %lld > %lld tokens",
+             (long long)period, (long long)n);
+  for (int64_t i = n - period - 1; i >= period; i--)
+    if (memcmp(tokens + i - period, tokens + i, (size_t)period * sizeof(int32_t)) != 0) return i + 1;
+  return period;
+}
+
+int64_t wb_repetition_period(const int32_t* tokens, int64_t n, int64_t min_repetitions) {
+  // transcribe.rs:395-417; returns the period or 0 for None (a period is >= 1)
+  if (!tokens || min_repetitions < 0) return 0;
+  for (int64_t i = n - 1; i >= 0; i--) {
+    const int64_t period = n - i;
+    if (i / period < min_repetitions) return 0;
+    bool all = true;
+    for (int64_t j = 0; j < min_repetitions && all; j++) {
+      const int64_t e = i - period * j, s = e - period;
+      all = memcmp(tokens + s, tokens + i, (size_t)period * sizeof(int32_t)) == 0;
+    }
+    if (all) return period;
+  }
+  return 0;
+}
+
+int wb_find_repeated_tokens_index(const int32_t* tokens, int64_t n, int64_t window_size, int64_t min_repeat_count,
+                                  int64_t* first_repeat_index, int64_t* end) {
+  // transcribe.rs:419-447: the windows equal to the last one, the last window itself and anything overlapping it excluded
+  WB_REQUIRE(tokens && window_size >= 1 && min_repeat_count >= 2, WB_ERR_ARG,
+             "wb_find_repeated_tokens_index: window_size >= 1 and min_repeat_count >= 2 (the reference unwraps two matches)");
+  if (2 * window_size > n) return 0;
+  const int64_t last_index = n - window_size;
+  int64_t n_repeats = 0, first = -1, second = -1;
+  for (int64_t i = 0; i + window_size <= last_index; i++)
+    if (memcmp(tokens + i, tokens + last_index, (size_t)window_size * sizeof(int32_t)) == 0) {
+      if (n_repeats == 0) first = i;
+      if (n_repeats == 1) second = i;
+      n_repeats++;
+    }
+  if (n_repeats < min_repeat_count) return 0;
+  if (first_repeat_index) *first_repeat_index = first;
+  if (end) *end = second;
+  return 1;
+}
+
 int wb_stitch_windows(const int32_t* win_tokens, int32_t row_stride, const int32_t* win_lens, int n_windows,
                       int max_n_offsets, int min_n_overlaps, int32_t* out, int64_t cap, int64_t* n_out) {
   WB_REQUIRE(win_lens && out && n_out && (win_tokens || n_windows == 0), WB_ERR_ARG, "wb_stitch_windows: null argument");

@@ -88,6 +88,9 @@ SIGNATURES = {
                                         c_int64_p, c_int64_p]),
     "wb_stitch_windows": (C.c_int, [c_int32_p, C.c_int32, c_int32_p, C.c_int, C.c_int, C.c_int, c_int32_p,
                                     C.c_int64, c_int64_p]),
+    "wb_first_repetition_end": (C.c_int64, [c_int32_p, C.c_int64, C.c_int64]),
+    "wb_repetition_period": (C.c_int64, [c_int32_p, C.c_int64, C.c_int64]),
+    "wb_find_repeated_tokens_index": (C.c_int, [c_int32_p, C.c_int64, C.c_int64, C.c_int64, c_int64_p, c_int64_p]),
     "wb_mel_constants": (C.c_int, [C.c_double, c_float_p, c_float_p]),
     "wb_profile_enable": (C.c_int, [C.c_int]),
     "wb_profile_read": (C.c_int, [c_double_p, C.c_int]),
