@@ -605,9 +605,17 @@ __global__ __launch_bounds__(512) void dec_attn_fused_kernel(AttnFusedArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 // Cross-attention block.  block = 512 threads, grid = (8, rows): block (h, r) owns head h of beam r (x = head keeps a
 // head's blocks on one XCD: the Wq / Wo slices and, for beams of the same window, the cached K/V cross the fabric once).
-//   LN(x + pending) -> q = . Wq[:, head h] + bq, * s -> scores against the window's cached K (all C <= 768 keys in this
-//   block: thread = key) -> softmax -> . V -> . Wo[head h rows, :] -> plane h of [H][S][d]        (mod.rs:482-490)
+//   LN(x + pending) -> q = . Wq[:, head h] + bq, * s -> scores against ALL of the window's cached K (C <= 768 keys)
+//   -> softmax -> . V -> . Wo[head h rows, :] -> plane h of [H][S][d]                              (mod.rs:482-490)
 // One launch instead of cross-attention (per 128-key chunk) + chunk combine + out-projection GEMV.
+//
+// A block streams ~0.6 MB (K and V of its head: 2 x C x 256 B, the Wq and Wo slices: 2 x d x 256 B) through ONE CU, so
+// the kernel is organised around bytes in flight.  K/V rows are read the coalesced way (16 lanes x 16 B = one 256-byte
+// head row, 32 rows per wave-instruction round) into a register ring that holds the WHOLE K of the head (6 tiles x 128
+// keys, 24 float4 per thread); every K register is refilled with the V row of the same key as soon as its score is
+// done, so the V stream is in flight under the softmax statistics.  Scores are 4-term partial dots reduced over the
+// 16 lanes of a row by DPP (no LDS transpose); the output is a float4 of partial sums per thread, reduced over the 32
+// row groups in a fixed order.  The Wq slice arrives under the fold + LayerNorm, the Wo slice under the scores.
 template <int DPL>
 __global__ __launch_bounds__(512) void dec_cross_fused_kernel(CrossFusedArgs a) {
   constexpr int NT = 512;
@@ -616,17 +624,20 @@ __global__ __launch_bounds__(512) void dec_cross_fused_kernel(CrossFusedArgs a) 
   constexpr int CF = d / 4;
   constexpr int G = CF <= 32 ? 8 : 4;
   constexpr int RPG = 64 / G;
-  constexpr int NV = CROSS_FUSED_MAX_C / 8;        // V values per lane (wave g owns keys j = g mod 8)
+  constexpr int KT = 128, NTILE = CROSS_FUSED_MAX_C / KT, SL = KT * 16 / NT;   // 6 tiles x 4 float4 slots per thread
+  static_assert(CROSS_FUSED_MAX_C % KT == 0 && SL * NT == KT * 16, "tile geometry");
   __shared__ __attribute__((aligned(16))) float hs[d];
   __shared__ __attribute__((aligned(16))) float red[8][64];
   __shared__ __attribute__((aligned(16))) float qv[64];
   __shared__ float sc[CROSS_FUSED_MAX_C];
-  __shared__ __attribute__((aligned(16))) float ored[8][64];
+  __shared__ float pbuf[CROSS_FUSED_MAX_C];
+  __shared__ __attribute__((aligned(16))) float part[32][64];
   __shared__ __attribute__((aligned(16))) float att[64];
   __shared__ __attribute__((aligned(16))) float obuf[(G - 1) * d];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.x, r = blockIdx.y;
   if (h >= a.n_head) return;
+  const int n_live = a.st[ST_N], w_row = a.st[a.lay.win + r];
   // ---- requested first (in order of use): fold operands, LayerNorm parameters, bias, the Wq slice
   float xfold;
   float gv[DPL], bv[DPL];
@@ -654,6 +665,7 @@ __global__ __launch_bounds__(512) void dec_cross_fused_kernel(CrossFusedArgs a) 
 #pragma unroll
       for (int i = 0; i < NWQ; i++) wqr[i] = *reinterpret_cast<const float4*>(wp + (int64_t)(32 * i) * d);
     }
+    if (r >= n_live) return;                       // (block-uniform; the first wait of the kernel)
     if (a.KSp > 0) {
 #pragma unroll
       for (int j = 0; j < FP; j++) accp += (j < a.KSp) ? t[j] : 0.f;
@@ -666,21 +678,23 @@ __global__ __launch_bounds__(512) void dec_cross_fused_kernel(CrossFusedArgs a) 
       v += accp;                                   // x + (bias + partials), s ascending  (mod.rs:346-348)
     }
     xfold = v;
-    if (r >= a.st[ST_N]) return;                   // (block-uniform)
     if (tid < d) hs[tid] = v;
   }
   const float qbias = tid < 64 ? a.bq[h * 64 + tid] : 0.f;
-  // ---- the window's cached K rows: thread = key (first 512 keys now, the rest after the first pass)
-  const int w = a.st[a.lay.win + r];
-  const int C = min(a.win_C[w], CROSS_FUSED_MAX_C);
-  const float* Kb = a.ckv + (int64_t)a.win_row0[w] * a.ldkv + a.koff + h * 64;   // K pre-scaled at projection time
-  const float* Vb = Kb + d;
-  float4 kpre[16];
-  if (tid < C) {
-    const float4* kr = reinterpret_cast<const float4*>(Kb + (int64_t)tid * a.ldkv);
+  // ---- the head's cached K, all of it, into the register ring (key = tile * 128 + rg + 32 * slot; quad c4)
+  const int C = min(a.win_C[w_row], CROSS_FUSED_MAX_C);
+  // uniform base + 32-bit per-lane offsets; keys past C re-read row C - 1 (their scores are never stored and their
+  // probabilities are zero), so every load is unconditional: no predicate sits between two requests
+  const float* Kh = a.ckv + (int64_t)a.win_row0[w_row] * a.ldkv + a.koff + h * 64;        // K pre-scaled at projection time
+  const float* Vh = Kh + d;
+  float4 kv[NTILE][SL];
 #pragma unroll
-    for (int c = 0; c < 16; c++) kpre[c] = kr[c];
-  }
+  for (int t = 0; t < NTILE; t++)
+#pragma unroll
+    for (int i = 0; i < SL; i++) {
+      const int key = min(t * KT + rg + 32 * i, C - 1);
+      kv[t][i] = *reinterpret_cast<const float4*>(Kh + (key * a.ldkv + c4));
+    }
   __syncthreads();
   if (wave == 0) ln_row_lds<DPL>(hs, d, lane, gv, bv, a.ln_eps, a.ln_inside);
   __syncthreads();
@@ -714,51 +728,52 @@ __global__ __launch_bounds__(512) void dec_cross_fused_kernel(CrossFusedArgs a) 
     qv[tid] = (v + qbias) * a.scale;
   }
   __syncthreads();
-  // ---- scores
-  for (int k0 = 0; k0 < C; k0 += NT) {
-    const int key = k0 + tid;
-    if (k0 > 0 && key < C) {
-      const float4* kr = reinterpret_cast<const float4*>(Kb + (int64_t)key * a.ldkv);
+  // ---- scores: partial dot over this thread's quad, summed over the 16 lanes of the key row; the register then
+  // takes the V row of the same key
+  {
+    const float4 q4 = *reinterpret_cast<const float4*>(&qv[c4]);
 #pragma unroll
-      for (int c = 0; c < 16; c++) kpre[c] = kr[c];
-    }
-    if (key < C) {
-      float s = 0.f;
+    for (int t = 0; t < NTILE; t++)
 #pragma unroll
-      for (int c = 0; c < 16; c++) {
-        const float4 q4 = *reinterpret_cast<const float4*>(&qv[4 * c]);
-        s += q4.x * kpre[c].x + q4.y * kpre[c].y + q4.z * kpre[c].z + q4.w * kpre[c].w;
+      for (int i = 0; i < SL; i++) {
+        const int key = t * KT + rg + 32 * i;
+        float s = q4.x * kv[t][i].x + q4.y * kv[t][i].y + q4.z * kv[t][i].z + q4.w * kv[t][i].w;
+        s += dpp_f<DPP_QUAD_XOR1, 0xF>(0.f, s);
+        s += dpp_f<DPP_QUAD_XOR2, 0xF>(0.f, s);
+        s += dpp_f<DPP_ROW_HALF_MIRROR, 0xF>(0.f, s);
+        s += dpp_f<DPP_ROW_MIRROR, 0xF>(0.f, s);
+        if ((tid & 15) == 0 && key < C) sc[key] = s;
+        kv[t][i] = *reinterpret_cast<const float4*>(Vh + (min(key, C - 1) * a.ldkv + c4));
       }
-      sc[key] = s;
-    }
-  }
-  // ---- V columns of this wave's keys (j = wave mod 8): requested before the softmax statistics are known
-  float vv[NV];
-#pragma unroll
-  for (int i = 0; i < NV; i++) {
-    const int j = wave + 8 * i;
-    vv[i] = j < C ? Vb[(int64_t)j * a.ldkv + lane] : 0.f;
   }
   __syncthreads();
-  // softmax statistics, redundantly per wave (no extra barrier)
+  // softmax statistics, redundantly per wave (no extra barrier); then the probabilities, two keys per thread
   float m = -INFINITY;
   for (int j = lane; j < C; j += 64) m = fmaxf(m, sc[j]);
   m = wave_max(m);
   float l = 0.f;
   for (int j = lane; j < C; j += 64) l += expf(sc[j] - m);
   l = wave_sum(l);
-  float o = 0.f;
+  for (int j = tid; j < C; j += NT) pbuf[j] = expf(sc[j] - m);
+  __syncthreads();
+  // ---- o[c4 .. c4 + 3] partial over this thread's keys (tile, slot ascending), then over the 32 row groups
+  {
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int i = 0; i < NV; i++) {
-    const int j = wave + 8 * i;
-    if (j < C) o += expf(sc[j] - m) * vv[i];
+    for (int t = 0; t < NTILE; t++)
+#pragma unroll
+      for (int i = 0; i < SL; i++) {
+        const int key = t * KT + rg + 32 * i;
+        const float pk = key < C ? pbuf[key] : 0.f;
+        o.x += pk * kv[t][i].x; o.y += pk * kv[t][i].y; o.z += pk * kv[t][i].z; o.w += pk * kv[t][i].w;
+      }
+    *reinterpret_cast<float4*>(&part[rg][c4]) = o;
   }
-  ored[wave][lane] = o;
   __syncthreads();
   if (tid < 64) {
     float v = 0.f;
 #pragma unroll
-    for (int g8 = 0; g8 < 8; g8++) v += ored[g8][tid];
+    for (int g2 = 0; g2 < 32; g2++) v += part[g2][tid];                 // row-group order fixed
     att[tid] = v / l;
   }
   __syncthreads();

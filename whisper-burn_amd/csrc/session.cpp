@@ -500,9 +500,9 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
   static const bool fuse_sub_enabled = []() { const char* e = getenv("WHISPER_HIP_FUSE_SUB"); return !(e && e[0] == '0'); }();
   const bool fuse_sub = fuse_sub_enabled && dec_fused_supported(d) && m->compute_dtype != WB_BF16 && d == 64 * H;
   // the whole cross-attention sublayer (LN + Wq + attention over the window's cached K/V + Wo) as one launch per
-  // (head, beam): opt-in -- 25.9 us vs 15.8 us for chunked cross-attention + out-projection GEMV (H x rows blocks cannot
-  // stream 384 KB of K/V each as fast as 6x as many chunk blocks stream 64 KB each)
-  static const bool fuse_x_enabled = []() { const char* e = getenv("WHISPER_HIP_FUSE_X"); return e && e[0] == '1'; }();
+  // (head, beam): 10.6 us against 9.5 + 5.9 us (+ a kernel boundary) for chunked cross-attention + out-projection GEMV
+  // once the block keeps its head's whole K in flight (decode_fused.hip); WHISPER_HIP_FUSE_X=0 restores the chunked pair
+  static const bool fuse_x_enabled = []() { const char* e = getenv("WHISPER_HIP_FUSE_X"); return !(e && e[0] == '0'); }();
   const bool fuse_x = fuse_x_enabled && fuse_sub && s->maxC <= CROSS_FUSED_MAX_C;
   // ... or (older, opt-in) the chunked cross-attention blocks apply their head's rows of the out-projection
   // (opt-in: with 128-key chunks the MLP prologue has 6 H records per row to combine and loses what the launch saves)
