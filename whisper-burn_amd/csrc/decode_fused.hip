@@ -377,28 +377,29 @@ __global__ __launch_bounds__(512) void dec_mlp_fused_kernel(MlpFusedArgs a) {
 // (One block per head for ALL beams keeps 4-8 accumulator sets per thread next to two weight rounds and spills;
 // per-beam blocks re-read the head's weight slices through L2 -- HBM still sees them once.)
 // QKV: wave w owns K-rows [w d / 8, (w + 1) d / 8); lane (seg = lane / 16 in {q, k, v, idle}, c4) reads a float4 of
-// the head's 64 columns of that segment; rounds of 16 rows, two rounds in flight.  Requested up front: two weight
-// rounds + the fold operands; when the weight registers free up: the cached K row of this thread's position and
-// the out-projection slice, so the attention phases and the out-projection do not wait on memory.
+// the head's 64 columns of that segment; rounds of 16 rows, two rounds in flight.  Requested up front: the fold
+// operands + two weight rounds, then (as soon as the position table is known) the cached K / V rows of the first 128
+// positions in the coalesced row layout -- they land under the QKV FMAs; when the weight registers free up: the
+// out-projection slice.  The attention phases and the out-projection do not wait on memory.
 template <int DPL>
 __global__ __launch_bounds__(512) void dec_attn_fused_kernel(AttnFusedArgs a) {
   constexpr int NT = 512;
   constexpr int d = 64 * DPL;
   constexpr int KW = d / 8;                        // K rows per wave (16, 48, 64)
-  constexpr int RK = DPL >= 8 ? 8 : 16;            // K rows per weight round (d = 512: two 16-row rounds would spill)
+  constexpr int RK = DPL >= 6 ? 8 : 16;            // K rows per weight round (sized so that two rounds + the cached K/V tile stay in registers)
   constexpr int NIT = KW / RK;
   constexpr int CF = d / 4;
   constexpr int G = CF <= 32 ? 8 : 4;              // out-projection row groups (d = 128: 8 x 8 rows, 384 / 512: 4 x 16)
   constexpr int RPG = 64 / G;
   constexpr int RED = (8 * 192 > (G - 1) * d) ? 8 * 192 : (G - 1) * d;
+  constexpr int PT = 128, PSL = PT * 16 / NT;      // cached positions per tile, float4 slots per thread per tile (4)
   __shared__ __attribute__((aligned(16))) float hs[d];
   __shared__ __attribute__((aligned(16))) float red[RED];              // QKV partials, later the out-projection partials
   __shared__ __attribute__((aligned(16))) float qkv[192];              // q * s, k * s, v of the new token (head h)
   __shared__ int tbs[FA_MAXPOS];
   __shared__ float sc[FA_MAXPOS];
-  __shared__ __attribute__((aligned(16))) float ored[8][64];
+  __shared__ __attribute__((aligned(16))) float part[32][64];
   __shared__ __attribute__((aligned(16))) float att[64];
-  __shared__ float lsum_s;
   WB_STAMP_DECL;
   WB_STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -406,7 +407,9 @@ __global__ __launch_bounds__(512) void dec_attn_fused_kernel(AttnFusedArgs a) {
   // one head on the SAME XCD -- the head's weight slices cross the fabric once and are shared through that L2
   const int h = blockIdx.x, r = blockIdx.y;
   if (h >= a.n_head) return;
-  // ---- requested first, in this order (loads return in order: the fold must not queue behind the weights): the fold
+  // the row's state words first: the position table, and through it the cached K / V addresses, hang on them
+  const int n_rows = a.st[ST_N], len = a.st[a.lay.len + r], step_par = a.st[ST_STEP] & 1;
+  // ---- then, in this order (loads return in order: the fold must not queue behind the weights): the fold
   // operands of row r, LayerNorm parameters (wave 0 normalises), bias, then two QKV weight rounds.
   // No global STORE happens before the last phase: a pending store turns every __syncthreads into vmcnt(0).
   const int seg = lane >> 4, c4 = (lane & 15) * 4;
@@ -439,6 +442,7 @@ __global__ __launch_bounds__(512) void dec_attn_fused_kernel(AttnFusedArgs a) {
     }
     load_round(wr[0], 0);
     if (NIT > 1) load_round(wr[1], 1);
+    if (r >= n_rows) return;                       // (block-uniform; the first wait of the kernel)
     if (a.KSp > 0) {
 #pragma unroll
       for (int j = 0; j < FP; j++) accp += (j < a.KSp) ? t[j] : 0.f;
@@ -451,16 +455,27 @@ __global__ __launch_bounds__(512) void dec_attn_fused_kernel(AttnFusedArgs a) {
       v += accp;
     }
     xfold = v;
-    const int n_rows = a.st[ST_N];
-    if (r >= n_rows) return;                       // (block-uniform)
     if (tid < d) hs[tid] = v;
   }
   const float qbias = tid < 192 ? a.bqkv[(tid >> 6) * d + h * 64 + (tid & 63)] : 0.f;   // key part is zero (mod.rs:402-404)
-  const int len = a.st[a.lay.len + r];
-  {
-    const int* tb = a.tabs + (size_t)(a.st[ST_STEP] & 1) * a.lay.S * a.Lmax + r * a.Lmax;
-    for (int p = tid; p < len; p += NT) tbs[p] = tb[p];
-  }
+  // ---- the cached K / V rows of the first 128 positions, the coalesced way (16 lanes x 16 B = one 256-byte head row;
+  // thread (rg, pq4) holds quad pq4 of positions rg + 32 i): requested HERE, behind the first two weight rounds, so
+  // that they arrive under the QKV FMAs instead of costing two dependent round trips after them.  Positions past the
+  // live range re-read slot 0 of the row (always valid; masked where consumed).
+  const int npast = len - 1;                       // cached positions; the new token attends to itself from LDS
+  const int rg = tid >> 4, pq4 = (tid & 15) * 4;
+  const int* tb = a.tabs + (size_t)step_par * a.lay.S * a.Lmax + r * a.Lmax;
+  int slot[PSL];
+#pragma unroll
+  for (int i = 0; i < PSL; i++) slot[i] = tb[rg + 32 * i < npast ? rg + 32 * i : 0];
+  const int slot_new = tb[npast];
+  if (npast > PT)                                  // only the tail tiles of long sequences walk the table through LDS
+    for (int p = tid; p < npast; p += NT) tbs[p] = tb[p];
+  float4 kc[PSL], vc[PSL];
+#pragma unroll
+  for (int i = 0; i < PSL; i++) kc[i] = *reinterpret_cast<const float4*>(a.Kc + (int64_t)slot[i] * d + h * 64 + pq4);
+#pragma unroll
+  for (int i = 0; i < PSL; i++) vc[i] = *reinterpret_cast<const float4*>(a.Vc + (int64_t)slot[i] * d + h * 64 + pq4);
   WB_STAMP(1);
   __syncthreads();
   if (wave == 0) ln_row_lds<DPL>(hs, d, lane, gv, bv, a.ln_eps, a.ln_inside);
@@ -484,14 +499,8 @@ __global__ __launch_bounds__(512) void dec_attn_fused_kernel(AttnFusedArgs a) {
     }
   }
   WB_STAMP(3);
-  __syncthreads();   // (also pins the loads below -- their addresses come from LDS -- behind the FMAs)
-  // ---- requested now: the cached K row of position p = tid and the Wo slice
-  float4 kpre[16];
-  if (tid < len - 1) {
-    const float4* kr = reinterpret_cast<const float4*>(a.Kc + (int64_t)tbs[tid] * d + h * 64);
-#pragma unroll
-    for (int c = 0; c < 16; c++) kpre[c] = kr[c];
-  }
+  __syncthreads();   // (also pins the loads below behind the FMAs: the weight registers are free now)
+  // ---- requested now: the Wo slice (consumed last)
   const int cf = tid % CF, jg = tid / CF;
   const bool p5 = jg < G;
   const int jb = (p5 ? jg : 0) * RPG;
@@ -513,30 +522,45 @@ __global__ __launch_bounds__(512) void dec_attn_fused_kernel(AttnFusedArgs a) {
   }
   __syncthreads();
   WB_STAMP(4);
-  // ---- scores: thread = cached position (len <= 448 < 512); the new token attends to itself from LDS
-  if (tid < len - 1) {
-    float s = 0.f;
+  // ---- scores: 4-term partial dots summed over the 16 lanes of a position's row (DPP); tail tiles (sequences longer
+  // than 128 cached positions) reload through the LDS copy of the table
+  {
+    const float4 q4 = *reinterpret_cast<const float4*>(&qkv[pq4]);
+    auto row_dot = [&](const float4& k4) {
+      float s = q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
+      s += dpp_f<DPP_QUAD_XOR1, 0xF>(0.f, s);
+      s += dpp_f<DPP_QUAD_XOR2, 0xF>(0.f, s);
+      s += dpp_f<DPP_ROW_HALF_MIRROR, 0xF>(0.f, s);
+      s += dpp_f<DPP_ROW_MIRROR, 0xF>(0.f, s);
+      return s;
+    };
 #pragma unroll
-    for (int c = 0; c < 16; c++) {
-      const float4 qv = *reinterpret_cast<const float4*>(&qkv[4 * c]);
-      s += qv.x * kpre[c].x + qv.y * kpre[c].y + qv.z * kpre[c].z + qv.w * kpre[c].w;
+    for (int i = 0; i < PSL; i++) {
+      const int p = rg + 32 * i;
+      const float s = row_dot(kc[i]);
+      if ((tid & 15) == 0 && p < npast) sc[p] = s;
     }
-    sc[tid] = s;
-  } else if (tid == len - 1) {
-    float s = 0.f;
-    for (int c = 0; c < 64; c++) s += qkv[c] * qkv[64 + c];
-    sc[tid] = s;
+    for (int t0 = PT; t0 < npast; t0 += PT) {
+      float4 kt[PSL];
+#pragma unroll
+      for (int i = 0; i < PSL; i++) {
+        const int p = min(t0 + rg + 32 * i, npast - 1);
+        kt[i] = *reinterpret_cast<const float4*>(a.Kc + (int64_t)tbs[p] * d + h * 64 + pq4);
+      }
+#pragma unroll
+      for (int i = 0; i < PSL; i++) {
+        const int p = t0 + rg + 32 * i;
+        const float s = row_dot(kt[i]);
+        if ((tid & 15) == 0 && p < npast) sc[p] = s;
+      }
+    }
+    if (wave == 7) {                                                    // the new token's own key (k * s from LDS)
+      const float s = wave_sum(qkv[lane] * qkv[64 + lane]);
+      if (lane == 0) sc[npast] = s;
+    }
   }
   __syncthreads();
   WB_STAMP(5);
-  // ---- V columns of this wave's positions (p = wave mod 8): requested before the softmax statistics are known
-  const float* vbase = a.Vc + h * 64;              // uniform base + 32-bit lane offsets
-  float vv[16];
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    const int p = wave + 8 * i;
-    vv[i] = p < len - 1 ? vbase[(unsigned)(tbs[p] * d + lane)] : 0.f;
-  }
   // softmax statistics, redundantly per wave (no extra barrier): m, l over all positions
   float m = -INFINITY;
   for (int p = lane; p < len; p += 64) m = fmaxf(m, sc[p]);
@@ -544,33 +568,37 @@ __global__ __launch_bounds__(512) void dec_attn_fused_kernel(AttnFusedArgs a) {
   float l = 0.f;
   for (int p = lane; p < len; p += 64) l += expf(sc[p] - m);
   l = wave_sum(l);
-  float o = 0.f;
+  {
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int i = 0; i < 16; i++) {
-    const int p = wave + 8 * i;
-    if (p < len - 1) o += expf(sc[p] - m) * vv[i];
-  }
-  for (int p0 = wave + 128; p0 < len - 1; p0 += 128) {
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const int p = p0 + 8 * i;
-      vv[i] = p < len - 1 ? vbase[(unsigned)(tbs[p] * d + lane)] : 0.f;
+    for (int i = 0; i < PSL; i++) {
+      const int p = rg + 32 * i;
+      const float pk = p < npast ? expf(sc[p] - m) : 0.f;
+      o.x += pk * vc[i].x; o.y += pk * vc[i].y; o.z += pk * vc[i].z; o.w += pk * vc[i].w;
     }
+    for (int t0 = PT; t0 < npast; t0 += PT) {
+      float4 vt[PSL];
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const int p = p0 + 8 * i;
-      if (p < len - 1) o += expf(sc[p] - m) * vv[i];
+      for (int i = 0; i < PSL; i++) {
+        const int p = min(t0 + rg + 32 * i, npast - 1);
+        vt[i] = *reinterpret_cast<const float4*>(a.Vc + (int64_t)tbs[p] * d + h * 64 + pq4);
+      }
+#pragma unroll
+      for (int i = 0; i < PSL; i++) {
+        const int p = t0 + rg + 32 * i;
+        const float pk = p < npast ? expf(sc[p] - m) : 0.f;
+        o.x += pk * vt[i].x; o.y += pk * vt[i].y; o.z += pk * vt[i].z; o.w += pk * vt[i].w;
+      }
     }
+    *reinterpret_cast<float4*>(&part[rg][pq4]) = o;
   }
-  if (wave == ((len - 1) & 7)) o += expf(sc[len - 1] - m) * qkv[128 + lane];
-  ored[wave][lane] = o;
-  if (tid == 0) lsum_s = l;
   __syncthreads();
   if (tid < 64) {
     float v = 0.f;
 #pragma unroll
-    for (int g8 = 0; g8 < 8; g8++) v += ored[g8][tid];
-    att[tid] = v / lsum_s;
+    for (int g2 = 0; g2 < 32; g2++) v += part[g2][tid];                 // row-group order fixed
+    v += expf(sc[npast] - m) * qkv[128 + tid];                          // the new token's own value
+    att[tid] = v / l;
   }
   __syncthreads();
   WB_STAMP(6);
@@ -594,7 +622,7 @@ __global__ __launch_bounds__(512) void dec_attn_fused_kernel(AttnFusedArgs a) {
   }
   // ---- the stores that are not on anybody's critical path: k * s, v of the new token into the cache, the folded stream
   if (tid >= 64 && tid < 192) {
-    float* dst = (tid < 128 ? a.Kc : a.Vc) + (int64_t)tbs[len - 1] * d + h * 64 + (tid & 63);
+    float* dst = (tid < 128 ? a.Kc : a.Vc) + (int64_t)slot_new * d + h * 64 + (tid & 63);
     *dst = qkv[tid];
   }
   if (h == 0 && tid < d) a.x_out[(int64_t)r * d + tid] = xfold;
