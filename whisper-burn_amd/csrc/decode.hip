@@ -393,24 +393,28 @@ __global__ __launch_bounds__(256, (MR >= 8 && DPL >= 16) ? 1 : 2) void dec_gemv_
 // device-chained greedy: the argmax feeds the next step, tokens stay on the device
 // When the last unfinished window ends, the step state is blanked (ST_N = 0): the host enqueues decode chunks ahead
 // of reading the finished flags, and every kernel of an already-enqueued step then exits at its first instruction.
-__device__ __forceinline__ void chained_update(int* st, const StepLayout& lay, int* gctl, int* gtok, int Lmax,
-                                               int eot, int r, int gi) {
-  const int len = st[lay.len + r];
+// `len`, `finished` and `step` are the row's state words as read at kernel entry (before any block of this launch has
+// written state): the update itself is stores only -- three dependent global reads by one thread used to sit between the
+// top-1 and the next step's embedding gather.
+__device__ __forceinline__ int chained_update(int* st, const StepLayout& lay, int* gctl, int* gtok, int Lmax,
+                                              int eot, int r, int gi, int len, int finished, int step) {
   gctl[GC_HDR + r] = gi;
-  if (!gctl[GC_HDR + lay.S + r]) {
+  if (!finished) {
     gtok[r * Lmax + len] = gi;
     gctl[GC_HDR + 2 * lay.S + r] = len + 1;
     if (gi == eot) {
+      finished = 1;
       gctl[GC_HDR + lay.S + r] = 1;                // finished (transcribe.rs:235-241): later tokens are ignored
       if (atomicAdd(&gctl[GC_NDONE], 1) + 1 == lay.W) { gctl[GC_ALLDONE] = 1; st[ST_N] = 0; }
     }
   }
-  if (r == 0) gctl[GC_STEP] = st[ST_STEP] + 1;
+  if (r == 0) gctl[GC_STEP] = step + 1;
+  return finished;
 }
 // host-visible progress of row r (mapped pinned memory): finished flag first, then the step counter the host waits for
-__device__ __forceinline__ void chained_publish(const int* st, const StepLayout& lay, const int* gctl, int* hflags, int r) {
-  __hip_atomic_store(&hflags[2 * r + 1], gctl[GC_HDR + lay.S + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __hip_atomic_store(&hflags[2 * r], st[ST_STEP] + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+__device__ __forceinline__ void chained_publish(int* hflags, int r, int finished, int step) {
+  __hip_atomic_store(&hflags[2 * r + 1], finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&hflags[2 * r], step + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---- merge the per-tile statistics of one beam's logits row: log_softmax + top-k ------------------
@@ -428,6 +432,8 @@ __global__ __launch_bounds__(256) void dec_topk_merge_kernel(int* __restrict__ s
   __shared__ float bc[2];
   const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_live = st[ST_N], len_now = st[lay.len + r];      // requested together with the tile records below
+  const int step_now = st[ST_STEP];
+  const int fin_now = gctl ? gctl[GC_HDR + lay.S + r] : 0;
   const float* ts = tstats + (int64_t)r * n_tiles * TS_STRIDE;
   // Ordinary vocabularies give <= 512 tiles: each thread pulls the whole record of its (at most) two tiles -- max,
   // sum-exp and the k candidates -- in ONE batch of loads, so the row costs one global round trip instead of three
@@ -522,8 +528,8 @@ __global__ __launch_bounds__(256) void dec_topk_merge_kernel(int* __restrict__ s
       out_id[r * TOPK_MAX + round] = gi;
       out_lp[r * TOPK_MAX + round] = (gv - M) - lse;   // log_softmax, transcribe.rs:276
       if (gctl && round == 0) {
-        chained_update(st, lay, gctl, gtok, Lmax, eot, r, gi);
-        if (nx.hflags) chained_publish(st, lay, gctl, nx.hflags, r);
+        const int fin = chained_update(st, lay, gctl, gtok, Lmax, eot, r, gi, len_now, fin_now, step_now);
+        if (nx.hflags) chained_publish(nx.hflags, r, fin, step_now);
       }
     }
     if (round == 0) first = gi;
@@ -993,7 +999,8 @@ __global__ __launch_bounds__(1024) void dec_topk_rows_kernel(const int* __restri
     if (tid == 0) {
       out_id[r * TOPK_MAX + round] = gi;
       out_lp[r * TOPK_MAX + round] = (gv - M) - lse;
-      if (gctl && round == 0) chained_update(const_cast<int*>(st), lay, gctl, gtok, Lmax, eot, r, gi);
+      if (gctl && round == 0)
+        chained_update(const_cast<int*>(st), lay, gctl, gtok, Lmax, eot, r, gi, st[lay.len + r], gctl[GC_HDR + lay.S + r], st[ST_STEP]);
     }
     if (ti[0] == gi) {
 #pragma unroll
