@@ -1,0 +1,65 @@
+"""Every runtime switch (DESIGN.md "runtime switches") selects another kernel path for the SAME result: each one is
+flipped in a fresh process (the switches are read once per process) and must reproduce the committed oracle tokens of
+the benchmarked workload -- greedy, tiny.en, three windows, depth 100 -- and of the beam-5 base.en workload prefix."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden", "oracle_outputs.npz")
+
+CHILD = r"""
+import json, sys
+sys.path[:0] = [%(root)r, %(pkg)r, %(tests)r]
+import whisper_burn_amd as wb
+import workloads
+out = {}
+for name in ("tiny_bench", "tiny_beam5"):
+    wl = workloads.WORKLOADS[name]
+    eng = wb.Whisper.from_tensors(wl.weights())
+    st = wb.SpecialTokens.for_vocab(eng.dims["n_vocab"])
+    toks, wins = wb.waveform_to_tokens(eng, st, wl.audio(), 16000, wl.beam, wl.depth if name == "tiny_bench" else 24)
+    out[name] = [list(map(int, w)) for w in wins]
+    eng.close()
+print("RESULT " + json.dumps(out))
+"""
+
+SWITCHES = [{}, {"WHISPER_HIP_FUSE_X": "0"}, {"WHISPER_HIP_FUSE_SUB": "0"}, {"WHISPER_HIP_FUSE_Q": "0"},
+            {"WHISPER_HIP_ATTN_KVSPLIT": "0"}, {"WHISPER_HIP_POLL": "0"}, {"WHISPER_HIP_FUSE_X": "0", "WHISPER_HIP_FUSE_CO": "1"}]
+
+
+_CACHE = {}
+
+
+def _run(env_extra):
+    key = tuple(sorted(env_extra.items()))
+    if key in _CACHE:
+        return _CACHE[key]
+    env = dict(os.environ)
+    for k in list(env):
+        if k.startswith("WHISPER_HIP_") and k != "WHISPER_HIP_LIB":
+            del env[k]
+    env.update(env_extra)
+    code = CHILD % {"root": ROOT, "pkg": os.path.join(ROOT, "whisper-burn_amd"), "tests": os.path.join(ROOT, "tests")}
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    _CACHE[key] = json.loads(line[len("RESULT "):])
+    return _CACHE[key]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("switch", SWITCHES, ids=lambda s: ",".join(f"{k[12:]}={v}" for k, v in s.items()) or "default")
+def test_switch_reproduces_the_oracle_tokens(switch):
+    g = np.load(GOLD)
+    got = _run(switch)
+    ref = [g["tiny_bench_tokens"][i][:int(g["tiny_bench_lens"][i])].tolist() for i in range(len(g["tiny_bench_lens"]))]
+    assert got["tiny_bench"] == ref
+    # beam 5, depth 24: the committed depth-100 rows are not prefixes of a shallower search, so this leg compares the
+    # switch against the default path run the same way (the default itself is pinned by test_gpu_workloads)
+    if switch:
+        assert got["tiny_beam5"] == _run({})["tiny_beam5"]
