@@ -159,7 +159,7 @@ def main() -> None:
         # corrected per MI355X_MICROARCH.md (profiles/summarize_pmc.py), keyed by kernel class; only used when the
         # file was collected on this workload (it records the command line)
         pmc = {}
-        pmc_json = os.path.join(ROOT, "profiles", "r02_b_pmc_traffic_tiny_en_30s.json")
+        pmc_json = os.path.join(ROOT, "profiles", "r02_c_pmc_traffic_tiny_en_30s.json")
         if args.model in ("tiny.en", "tiny_en") and args.dtype == "f32" and args.beam == 1 and args.seconds == 30.0 \
                 and os.path.exists(pmc_json):
             pmc = json.load(open(pmc_json))
@@ -169,6 +169,7 @@ def main() -> None:
             want = {"dec_attn_fused": lambda n: "dec_attn_fused_kernel" in n,
                     "dec_mlp_fused": lambda n: "dec_mlp_fused_kernel" in n,
                     "dec_cross_attn": lambda n: "dec_cross_attn_kernel" in n,
+                    "dec_cross_fused": lambda n: "dec_cross_fused_kernel" in n,
                     "dec_topk_merge": lambda n: "dec_topk_merge_kernel" in n,
                     "dec_gemv logits": lambda n: "dec_gemv_kernel" in n and "true, true" in n,
                     "dec_gemv cross-attn": lambda n: "dec_gemv_kernel" in n and "false, false, false" in n}

@@ -93,7 +93,7 @@ void launch_dec_cross_attn(hipStream_t st, const int* state, const StepLayout& l
 // `rocprofv3 --kernel-trace` reports.  With profiling off a tag costs one predictable branch.
 enum KernelClass {
   KC_PREPARE = 0, KC_ATTN_FUSED, KC_CROSS_ATTN, KC_GEMV_COUT, KC_MLP_FUSED, KC_LOGITS, KC_TOPK_MERGE,
-  KC_GEMV_LN_QKV, KC_SELF_ATTN, KC_GEMV_OUT, KC_GEMV_LN_CQ, KC_GEMV_LN_MLP1, KC_GEMV_MLP2, KC_BATCH, KC_COUNT
+  KC_GEMV_LN_QKV, KC_SELF_ATTN, KC_GEMV_OUT, KC_GEMV_LN_CQ, KC_GEMV_LN_MLP1, KC_GEMV_MLP2, KC_BATCH, KC_CROSS_FUSED, KC_COUNT
 };
 void prof_tag(int cls, double algo_bytes);
 bool prof_take_events(hipEvent_t* start, hipEvent_t* stop);

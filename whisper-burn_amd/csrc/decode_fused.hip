@@ -666,6 +666,11 @@ __global__ __launch_bounds__(512) void dec_cross_fused_kernel(CrossFusedArgs a) 
   const int h = blockIdx.x, r = blockIdx.y;
   if (h >= a.n_head) return;
   const int n_live = a.st[ST_N], w_row = a.st[a.lay.win + r];
+  // the window geometry of the first 8 windows rides with the state words -- as VECTOR loads (lane i holds window i; a
+  // scalar load here would stall the next kernel-argument wait, lgkmcnt being one counter): the K stream can then start
+  // one round trip after kernel entry instead of two (row -> window -> geometry)
+  const int wi8 = min(lane & 7, a.lay.W - 1);
+  const int vC8 = a.win_C[wi8], vR8 = a.win_row0[wi8];
   // ---- requested first (in order of use): fold operands, LayerNorm parameters, bias, the Wq slice
   float xfold;
   float gv[DPL], bv[DPL];
@@ -710,10 +715,16 @@ __global__ __launch_bounds__(512) void dec_cross_fused_kernel(CrossFusedArgs a) 
   }
   const float qbias = tid < 64 ? a.bq[h * 64 + tid] : 0.f;
   // ---- the head's cached K, all of it, into the register ring (key = tile * 128 + rg + 32 * slot; quad c4)
-  const int C = min(a.win_C[w_row], CROSS_FUSED_MAX_C);
+  int C_w, row0_w;
+  {
+    const int ws = __builtin_amdgcn_readfirstlane(w_row);
+    if (ws < 8) { C_w = __builtin_amdgcn_readlane(vC8, ws); row0_w = __builtin_amdgcn_readlane(vR8, ws); }
+    else { C_w = a.win_C[ws]; row0_w = a.win_row0[ws]; }
+  }
+  const int C = min(C_w, CROSS_FUSED_MAX_C);
   // uniform base + 32-bit per-lane offsets; keys past C re-read row C - 1 (their scores are never stored and their
   // probabilities are zero), so every load is unconditional: no predicate sits between two requests
-  const float* Kh = a.ckv + (int64_t)a.win_row0[w_row] * a.ldkv + a.koff + h * 64;        // K pre-scaled at projection time
+  const float* Kh = a.ckv + (int64_t)row0_w * a.ldkv + a.koff + h * 64;                  // K pre-scaled at projection time
   const float* Vh = Kh + d;
   float4 kv[NTILE][SL];
 #pragma unroll

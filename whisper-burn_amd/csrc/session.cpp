@@ -28,7 +28,8 @@ static const char* const g_kernel_names[KC_COUNT] = {
     "dec_prepare", "dec_attn_fused (LN + QKV + self-attention + out-proj)", "dec_cross_attn (LN + Wq + cross-attention)",
     "dec_gemv cross-attn out-proj", "dec_mlp_fused (LN + lin1 + GELU + lin2)", "dec_gemv logits (LN + E^T + tile stats)",
     "dec_topk_merge", "dec_gemv LN + QKV", "dec_self_attn", "dec_gemv self-attn out-proj", "dec_gemv LN + Wq",
-    "dec_gemv LN + lin1", "dec_gemv GELU + lin2", "batch-mode decode kernels"};
+    "dec_gemv LN + lin1", "dec_gemv GELU + lin2", "batch-mode decode kernels",
+    "dec_cross_fused (LN + Wq + cross-attention + out-proj)"};
 struct PendingLaunch { hipEvent_t a, b; int cls; double bytes; };
 static std::mutex g_prof_mu;
 static std::vector<PendingLaunch> g_pending;
@@ -547,7 +548,7 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
       ca.Wq = b.cq.w; ca.bq = b.cq.b; ca.scale = m->qk_scale;
       ca.ckv = s->ckv.as<float>(); ca.ldkv = ldkv; ca.koff = l * 2 * d; ca.win_row0 = win_row0; ca.win_C = win_C;
       ca.Wo = b.cout.w; ca.P = s->Pc.as<float>();
-      prof_tag(KC_CROSS_ATTN, ckv_bytes + 4.0 * dd * 2);
+      prof_tag(KC_CROSS_FUSED, ckv_bytes + 4.0 * dd * 2);
       launch_dec_cross_fused(st, ca, n);
       xi ^= 1;
     } else if (fuse_q) {
