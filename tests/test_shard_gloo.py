@@ -74,4 +74,7 @@ def test_bench_self_launches_its_ranks_without_a_launcher():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode != 0
-    assert (p.stdout + p.stderr).count("bench.py needs a GPU") == 2
+    out = p.stdout + p.stderr
+    # the elastic agent tears the second rank down as soon as the first one fails, so only one message is guaranteed
+    assert 1 <= out.count("bench.py needs a GPU") <= 2
+    assert "nproc-per-node" not in out or "error: unrecognized" not in out
