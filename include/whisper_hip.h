@@ -87,6 +87,14 @@ void wb_model_free(wb_model* m);
  *                              1 = (x-mu)/sqrt(var+eps)    [later Burn releases, HF]      */
 int wb_model_set_ln_variant(wb_model* m, int eps_inside_sqrt);
 
+/* Mel frames per window: 0 = at most n_audio_ctx FRAMES, exactly as the reference asserts (mod.rs:236-241; its
+ *                            windows are therefore 14.9 s, transcribe.rs:32-34)                     [default]
+ *                        1 = at most n_audio_ctx encoder POSITIONS = 2 n_audio_ctx frames: Whisper's own 30 s
+ *                            window ("perf geometry": T = 3000, C = 1500).  NOT reference behaviour -- the
+ *                            reference panics there; window length, clipping and padding follow the same
+ *                            formulas (transcribe.rs:32-34, :171-177) with the larger bound. */
+int wb_model_set_frame_limit(wb_model* m, int whisper_geometry);
+
 /* ---- stateless, reference-shaped entry points (the parity surface) -------------- */
 
 /* max_waveform_samples(n_frame_max), src/audio.rs:12-17 */

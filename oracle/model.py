@@ -40,10 +40,15 @@ class Dims:
 class OracleWhisper:
     """mod.rs:41-71 `Whisper` restated; `ln_eps_inside_sqrt` selects the LayerNorm variant."""
 
-    def __init__(self, weights: dict, ln_eps_inside_sqrt: bool = False, dtype=torch.float32):
+    def __init__(self, weights: dict, ln_eps_inside_sqrt: bool = False, dtype=torch.float32,
+                 frame_limit_x2: bool = False):
         self.w = {k: torch.as_tensor(np.asarray(v)).to(dtype) for k, v in weights.items()}
         self.dtype = dtype
         self.ln_eps_inside_sqrt = ln_eps_inside_sqrt
+        # NOT reference behaviour (opt-in, the checker side of wb_model_set_frame_limit): bound the encoder POSITIONS
+        # by n_audio_ctx instead of the mel frames, i.e. Whisper's own 30 s window (T = 3000 -> C = 1500).  The
+        # reference asserts T <= n_audio_ctx (mod.rs:236-241) and would panic on such a window.
+        self.frame_limit_x2 = frame_limit_x2
         w = self.w
         pe = w["encoder/positional_embedding"]
         te = w["decoder/token_embedding/weight"]
@@ -103,7 +108,7 @@ class OracleWhisper:
         mel = mel.to(self.dtype)
         _, n_mels, n_ctx = mel.shape
         assert n_mels == self.dims.n_mels                    # mod.rs:231-235
-        assert n_ctx <= self.dims.n_audio_ctx                # mod.rs:236-241
+        assert n_ctx <= self.encoder_ctx_size()              # mod.rs:236-241 (n_audio_ctx unless frame_limit_x2)
         w = self.w
         x = F.gelu(F.conv1d(mel, w["encoder/conv1/weight"], w["encoder/conv1/bias"], padding=1))
         x = F.gelu(F.conv1d(x, w["encoder/conv2/weight"], w["encoder/conv2/bias"], stride=2, padding=1))
@@ -140,7 +145,7 @@ class OracleWhisper:
         return self.forward_decoder(tokens, self.forward_encoder(mel))
 
     def encoder_ctx_size(self) -> int:
-        return self.dims.n_audio_ctx
+        return self.dims.n_audio_ctx * (2 if self.frame_limit_x2 else 1)
 
     def decoder_ctx_size(self) -> int:
         return self.dims.n_text_ctx

@@ -1,0 +1,70 @@
+"""Driven by tests/test_emu_functional.py in a subprocess with WHISPER_HIP_LIB = lib/libwhisper_hip_emu.so: the engine's
+own HIP sources, compiled for the host against the hipemu functional model (whisper-burn_amd/tools/hipemu), compared
+with the oracle at micro shapes.  This is a CHECK OF THE KERNEL SOURCES' LOGIC on a machine without a GPU (indexing,
+wave collectives, MFMA operand layouts, the host-side launch logic); it says nothing about the gfx950 build's timing
+or memory ordering -- the `-m gpu` tests remain the parity tests proper."""
+import sys
+
+import numpy as np
+import torch
+
+import parity_util as pu
+import whisper_burn_amd as wb
+from oracle import mel as omel
+from oracle import transcribe as otr
+from oracle.model import OracleWhisper
+from whisper_burn_amd import _lib, synth
+
+
+def main(which):
+    assert b"hipemu" in _lib.load().wb_version()
+    dims = synth.micro_dims(n_state=128, n_head=2, n_layer=2, n_vocab=1031)
+    w = synth.synth_weights(dims, seed=4242)
+    eng, o = wb.Whisper.from_tensors(w), OracleWhisper(w)
+    st = wb.SpecialTokens.for_vocab(1031)
+    if which == "mel":
+        for n, seed in ((400, 1), (401, 2), (16000 * 2 + 77, 3)):
+            a = synth.synth_audio(n, seed)
+            got = wb.prep_audio(a[None])[0]
+            ref = omel.prep_audio(torch.from_numpy(a)[None])[0].numpy()
+            assert got.shape == ref.shape and np.abs(got - ref).max() < 2e-4, (n, np.abs(got - ref).max())
+    elif which == "greedy":
+        a = synth.synth_audio(16000 * 3, 7)
+        got, wins = wb.waveform_to_tokens(eng, st, a, 16000, 1, 10)
+        ref, rw = otr.waveform_to_tokens(o, pu.ost(st), a, 16000, 1, 10, return_windows=True)
+        assert got == ref and wins == rw, (got, ref)
+        assert len(set(got[4:])) >= 4                                   # not a degenerate sequence
+    elif which == "beam":
+        a = synth.synth_audio(16000 * 2, 9)
+        got, _ = wb.waveform_to_tokens(eng, st, a, 16000, 3, 6)
+        ref = otr.waveform_to_tokens(o, pu.ost(st), a, 16000, 3, 6)
+        assert got == ref, (got, ref)
+    elif which == "forward":
+        a = synth.synth_audio(16000, 5)
+        mel = np.concatenate([wb.prep_audio(a[None]), np.zeros((1, 80, 10), np.float32)], 2)
+        toks = np.array([[st.start_of_transcript, st.language, st.transcribe, st.no_timestamps, 17, 300, 45]], np.int32)
+        got = eng.forward(mel, toks)
+        ref = o.forward(torch.from_numpy(mel), torch.from_numpy(toks)).numpy()
+        assert np.abs(got - ref).max() < 1e-3, np.abs(got - ref).max()
+    elif which == "geometry":
+        # wb_model_set_frame_limit(1): windows of 2 n_audio_ctx frames.  n_audio_ctx = 400 keeps the clip short while
+        # both window lengths (3.9 s and 7.9 s) stay above the 3 s overlap (below it the reference's shift is 1 sample)
+        dims = synth.micro_dims(n_state=128, n_head=2, n_layer=2, n_vocab=1031, n_audio_ctx=400)
+        w2 = synth.synth_weights(dims, seed=11)
+        e2, o2 = wb.Whisper.from_tensors(w2), OracleWhisper(w2, frame_limit_x2=True)
+        a = synth.synth_audio(16000 * 6, 41)
+        _, ref_limit_wins = wb.waveform_to_tokens(e2, st, a, 16000, 1, 6)
+        assert ref_limit_wins == otr.waveform_to_tokens(OracleWhisper(w2), pu.ost(st), a, 16000, 1, 6, return_windows=True)[1]
+        e2.set_frame_limit(True)
+        got, wins = wb.waveform_to_tokens(e2, st, a, 16000, 1, 6)
+        ref, rw = otr.waveform_to_tokens(o2, pu.ost(st), a, 16000, 1, 6, return_windows=True)
+        assert got == ref and wins == rw and len(wins) < len(ref_limit_wins), (got, ref)
+        e2.close()
+    else:
+        raise SystemExit(f"unknown check {which}")
+    eng.close()
+    print("EMU_CHECK_OK", which)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

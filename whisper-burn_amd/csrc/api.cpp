@@ -52,7 +52,11 @@ using namespace wb;
 extern "C" {
 
 const char* wb_last_error(void) { return wb::get_error(); }
+#ifdef HIPEMU   // tools/hipemu: the host build against the functional model (test infrastructure, refused by the binding)
+const char* wb_version(void) { return "whisper_hip 0.1 (hipemu functional model -- NOT a product build)"; }
+#else
 const char* wb_version(void) { return "whisper_hip 0.1 (gfx950)"; }
+#endif
 
 int wb_model_load_dump_dir(const char* dir, int device, int compute_dtype, wb_model** out) {
   WB_REQUIRE(dir && out, WB_ERR_ARG, "wb_model_load_dump_dir: null argument");
@@ -84,6 +88,12 @@ int wb_model_dims(const wb_model* m, wb_dims* out) {
 int wb_model_set_ln_variant(wb_model* m, int eps_inside_sqrt) {
   WB_REQUIRE(m, WB_ERR_ARG, "wb_model_set_ln_variant: null model");
   m->ln_eps_inside_sqrt = eps_inside_sqrt ? 1 : 0;
+  return WB_OK;
+}
+
+int wb_model_set_frame_limit(wb_model* m, int whisper_geometry) {
+  WB_REQUIRE(m, WB_ERR_ARG, "wb_model_set_frame_limit: null model");
+  m->frame_limit_x2 = whisper_geometry ? 1 : 0;
   return WB_OK;
 }
 
@@ -196,8 +206,8 @@ int wb_waveform_to_mels_dev(int device, const float* pcm_dev, int64_t n_samples,
 int wb_forward_encoder(wb_model* m, const float* mel, int B, int T, float* out) {
   WB_REQUIRE(m && mel && out && B > 0, WB_ERR_ARG, "wb_forward_encoder: bad argument");
   // mod.rs:236-241
-  WB_REQUIRE(T >= 1 && T <= m->dims.n_audio_ctx, WB_ERR_SHAPE, "Audio length %d cannot exceed %d.", T,
-             m->dims.n_audio_ctx);
+  WB_REQUIRE(T >= 1 && T <= m->max_mel_frames(), WB_ERR_SHAPE, "Audio length %d cannot exceed %d.", T,
+             m->max_mel_frames());
   std::lock_guard<std::mutex> lk(g_stateless_mu);
   WB_HIP(hipSetDevice(m->device));
   wb_model* sc = m;
@@ -251,8 +261,8 @@ int wb_forward_decoder(wb_model* m, const int32_t* tokens, int n, int L, const f
 
 int wb_forward(wb_model* m, const float* mel, int B, int T, const int32_t* tokens, int L, float* logits) {
   WB_REQUIRE(m && mel && tokens && logits && B > 0, WB_ERR_ARG, "wb_forward: bad argument");
-  WB_REQUIRE(T >= 1 && T <= m->dims.n_audio_ctx, WB_ERR_SHAPE, "Audio length %d cannot exceed %d.", T,
-             m->dims.n_audio_ctx);
+  WB_REQUIRE(T >= 1 && T <= m->max_mel_frames(), WB_ERR_SHAPE, "Audio length %d cannot exceed %d.", T,
+             m->max_mel_frames());
   std::lock_guard<std::mutex> lk(g_stateless_mu);
   WB_HIP(hipSetDevice(m->device));
   wb_model* sc = m;

@@ -66,8 +66,8 @@ int run_encoder(wb_model* m, hipStream_t st, Workspace& ws, const MelBatch& mb, 
   std::vector<int> x1row0(nw);
   for (int w = 0; w < nw; w++) {
     // mod.rs:236-241 (the reference bounds MEL FRAMES by n_audio_ctx)
-    WB_REQUIRE(mb.T[w] >= 1 && mb.T[w] <= D.n_audio_ctx, WB_ERR_SHAPE, "Audio length %d cannot exceed %d.",
-               mb.T[w], D.n_audio_ctx);
+    WB_REQUIRE(mb.T[w] >= 1 && mb.T[w] <= m->max_mel_frames(), WB_ERR_SHAPE, "Audio length %d cannot exceed %d.",
+               mb.T[w], m->max_mel_frames());
     x1row0[w] = rows1; rows1 += mb.T[w];
     eo->C[w] = (mb.T[w] - 1) / 2 + 1;
     eo->row0[w] = rows2; rows2 += eo->C[w];

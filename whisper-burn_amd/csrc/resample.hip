@@ -68,7 +68,7 @@ int reduce_rates(int32_t rate_in, int32_t rate_out, int* up, int* down) {
 __global__ __launch_bounds__(RS_THREADS) void resample_poly_kernel(const float* __restrict__ x, int64_t n_in,
                                                                     const float* __restrict__ taps, int half, int up,
                                                                     int down, float* __restrict__ y, int64_t n_out) {
-  extern __shared__ float h[];
+  HIP_DYNAMIC_SHARED(float, h)
   const int n_taps = 2 * half + 1;
   for (int k = threadIdx.x; k < n_taps; k += RS_THREADS) h[k] = taps[k];
   __syncthreads();

@@ -112,7 +112,7 @@ int session_create(wb_model* m, int n_windows, int max_beams, int padding, wb_se
   WB_REQUIRE(m && out, WB_ERR_ARG, "session: null argument");
   WB_REQUIRE(n_windows >= 1, WB_ERR_ARG, "session: n_windows must be >= 1");
   WB_REQUIRE(max_beams >= 1 && max_beams <= MAX_BEAMS, WB_ERR_ARG, "session: max_beams must be in [1, %d]", MAX_BEAMS);
-  WB_REQUIRE(padding >= 0 && padding < m->dims.n_audio_ctx, WB_ERR_ARG, "session: bad padding %d", padding);
+  WB_REQUIRE(padding >= 0 && padding < m->max_mel_frames(), WB_ERR_ARG, "session: bad padding %d", padding);
   WB_HIP(hipSetDevice(m->device));
   wb_session* s = nullptr;
   {
@@ -182,7 +182,7 @@ static int session_finish_encode(wb_session* s, const MelBatch& mb) {
 int session_encode_pcm(wb_session* s, const float* pcm, int64_t n_pcm, const int64_t* starts, const int64_t* lens,
                        bool pcm_on_device) {
   wb_model* m = s->m;
-  const int clip = m->dims.n_audio_ctx - s->padding;   // transcribe.rs:171-177
+  const int clip = m->max_mel_frames() - s->padding;   // transcribe.rs:171-177
   int64_t lo = n_pcm, hi = 0;
   for (int w = 0; w < s->W; w++) {
     WB_REQUIRE(starts[w] >= 0 && lens[w] >= 0 && starts[w] + lens[w] <= n_pcm, WB_ERR_ARG,
@@ -324,7 +324,7 @@ int wb_session_begin_mel(wb_model* m, const float* mel, const int32_t* T, int n_
   WB_REQUIRE(m && mel && T && out, WB_ERR_ARG, "wb_session_begin_mel: null argument");
   wb_session* s = nullptr;
   WB_TRY(session_create(m, n_windows, max_beams, padding, &s));
-  const int clip = m->dims.n_audio_ctx - padding;
+  const int clip = m->max_mel_frames() - padding;
   int maxT = 0;
   for (int w = 0; w < n_windows; w++) {
     if (T[w] < 1) { wb_session_free(s); set_error("window %d: empty mel", w); return WB_ERR_SHAPE; }

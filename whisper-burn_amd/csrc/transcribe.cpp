@@ -319,9 +319,9 @@ static int waveform_to_tokens_impl(wb_model* m, const float* pcm, bool pcm_on_de
                                    int32_t* win_tokens, int32_t row_stride, int32_t* win_lens, int32_t* stitched,
                                    int64_t stitched_cap, int64_t* n_stitched) {
   WB_REQUIRE(m && pcm && p && is_special && win_tokens && win_lens, WB_ERR_ARG, "wb_waveform_to_tokens: null argument");
-  WB_REQUIRE(p->padding >= 0 && p->padding < m->dims.n_audio_ctx, WB_ERR_ARG, "bad padding");
+  WB_REQUIRE(p->padding >= 0 && p->padding < m->max_mel_frames(), WB_ERR_ARG, "bad padding");
   // transcribe.rs:32-34
-  const int64_t wlen = wb_max_waveform_samples(m->dims.n_audio_ctx - p->padding);
+  const int64_t wlen = wb_max_waveform_samples(m->max_mel_frames() - p->padding);
   const int64_t n_win = wb_window_extents(n, sample_rate, wlen, p->overlap_seconds, nullptr, nullptr, 0);
   std::vector<int64_t> starts((size_t)n_win), lens((size_t)n_win);
   wb_window_extents(n, sample_rate, wlen, p->overlap_seconds, starts.data(), lens.data(), n_win);

@@ -115,6 +115,10 @@ struct wb_model {
   int device = 0;
   int compute_dtype = WB_F32;
   int ln_eps_inside_sqrt = 0;
+  // 0: mel frames per window bounded by n_audio_ctx, as the reference asserts (mod.rs:236-241);
+  // 1: ENCODER POSITIONS bounded by n_audio_ctx = 2 n_audio_ctx frames (Whisper's own 30 s geometry; opt-in)
+  int frame_limit_x2 = 0;
+  int max_mel_frames() const { return frame_limit_x2 ? 2 * dims.n_audio_ctx : dims.n_audio_ctx; }
   // all weights live in one arena allocation
   wb::DevMem arena;
   wb::DevMem arena_bf16;      // WB_BF16: bf16 copies of the GEMM weights

@@ -46,6 +46,7 @@ SIGNATURES = {
     "wb_model_dims": (C.c_int, [C.c_void_p, C.POINTER(WbDims)]),
     "wb_model_free": (None, [C.c_void_p]),
     "wb_model_set_ln_variant": (C.c_int, [C.c_void_p, C.c_int]),
+    "wb_model_set_frame_limit": (C.c_int, [C.c_void_p, C.c_int]),
     "wb_max_waveform_samples": (C.c_int64, [C.c_int64]),
     "wb_prep_audio": (C.c_int, [C.c_int, c_float_p, C.c_int64, C.c_double, c_float_p, c_int64_p]),
     "wb_model_load_burn_record": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
@@ -135,6 +136,11 @@ def load(path: str | None = None) -> C.CDLL:
         fn = getattr(lib, name)     # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if b"hipemu" in lib.wb_version() and os.environ.get("WHISPER_HIP_ALLOW_EMU") != "1":
+        # tools/hipemu builds the same sources against a functional model of the GPU for kernel development on
+        # GPU-less machines; it is test infrastructure and never a product path
+        raise OSError(f"{path} is the hipemu functional-model build, not the gfx950 library; the engine has no CPU "
+                      f"path (tests that drive the emulator set WHISPER_HIP_ALLOW_EMU=1)")
     _lib = lib
     return lib
 

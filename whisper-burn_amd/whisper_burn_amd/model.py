@@ -200,6 +200,17 @@ class Whisper:
     def set_layernorm_variant(self, eps_inside_sqrt: bool):
         check(_lib.load().wb_model_set_ln_variant(self._h, int(eps_inside_sqrt)))
 
+    def set_frame_limit(self, whisper_geometry: bool):
+        """False (default): a window holds at most n_audio_ctx MEL FRAMES, as the reference asserts (mod.rs:236-241).
+        True: at most n_audio_ctx encoder positions = 2 n_audio_ctx frames -- Whisper's own 30 s window (the "perf
+        geometry" T = 3000, C = 1500 of SURVEY 8d config 2b); the reference panics on such a window."""
+        check(_lib.load().wb_model_set_frame_limit(self._h, int(bool(whisper_geometry))))
+        self._frame_limit_x2 = bool(whisper_geometry)
+
+    def max_mel_frames(self) -> int:
+        """Mel frames one window may hold (what transcribe.rs:32 calls n_ctx_max_encoder)."""
+        return self.dims["n_audio_ctx"] * (2 if getattr(self, "_frame_limit_x2", False) else 1)
+
     # -- mod.rs:47-71 -------------------------------------------------------------------
     def encoder_ctx_size(self) -> int:
         return self.dims["n_audio_ctx"]
@@ -296,7 +307,7 @@ def waveform_to_tokens(whisper: Whisper, st: SpecialTokens, waveform, sample_rat
         wav = _f32(waveform).reshape(-1)
         n_samples = len(wav)
     p = params or decode_params(st, beam_size, max_depth)
-    wlen = max_waveform_samples(whisper.encoder_ctx_size() - p.padding)
+    wlen = max_waveform_samples(whisper.max_mel_frames() - p.padding)
     starts, _ = window_extents(n_samples, sample_rate, wlen, p.overlap_seconds)
     n_win = len(starts)
     if win_end < 0:
