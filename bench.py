@@ -29,14 +29,14 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s
 MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # dense peaks, same guide
 
 
-def e2e_roofline_ms(dims, lens, n_steps, dtype):
+def e2e_roofline_ms(dims, lens, n_steps, dtype, clip=1490):
     """Roofline time of one bench step from the algorithmic work of every stage: mel = 960 B
     per frame over HBM, encoder + cross-K/V projection = dense FLOPs over the MFMA peak of the path's dtype,
     decode = weights + cached cross-K/V streamed once per step over HBM."""
     d, L, V = dims["n_text_state"], dims["n_text_layer"], dims["n_vocab"]
     s = 2.0 if dtype == "bf16" else 4.0
     frames = [int(n) // 160 for n in lens]
-    T = [min(f, 1490) + 10 for f in frames]
+    T = [min(f, clip) + 10 for f in frames]
     C = [(t - 1) // 2 + 1 for t in T]
     mel_ms = 960.0 * sum(frames) / (HBM_PEAK_GBS * 1e9) * 1e3
     enc_flops = sum(2 * 80 * d * 3 * t + 2 * d * d * 3 * c + L * (8 * c * d * d + 4 * c * c * d + 16 * c * d * d)
@@ -55,13 +55,20 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=200, help="timed steps (default: a timed region of ~5 s)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--model", default="tiny.en")
-    ap.add_argument("--seconds", type=float, default=30.0, help="audio seconds per GPU per step")
+    ap.add_argument("--seconds", type=float, default=None,
+                    help="audio seconds per GPU per step (default 30; one full window = 29.91 with --geometry whisper30)")
+    ap.add_argument("--geometry", default="reference", choices=["reference", "whisper30"],
+                    help="reference = the reference's windows (<= n_audio_ctx mel FRAMES = 14.9 s, mod.rs:236-241; the judged "
+                         "configuration); whisper30 = the opt-in perf geometry of SURVEY 8d config 2(b): one window of "
+                         "T = 2990 + 10 frames, C = 1500 encoder positions (wb_model_set_frame_limit)")
     ap.add_argument("--beam", type=int, default=1)
     ap.add_argument("--max-depth", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 = exact-f32 MFMA parity path (the judged configuration); bf16 = speed path")
     args = ap.parse_args()
+    if args.seconds is None:
+        args.seconds = 478559 / 16000.0 if args.geometry == "whisper30" else 30.0
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU over RCCL, same flags
@@ -97,6 +104,8 @@ def main() -> None:
     weights = synth.synth_preset(args.model)
     eng = wb.Whisper.from_tensors(weights, device=local_rank,
                                   compute_dtype=wb.WB_BF16 if args.dtype == "bf16" else wb.WB_F32)
+    if args.geometry == "whisper30":
+        eng.set_frame_limit(True)
     V = eng.dims["n_vocab"]
     st = wb.SpecialTokens.for_vocab(V)
     params = wb.decode_params(st, beam_size=args.beam, max_depth=args.max_depth)
@@ -105,7 +114,7 @@ def main() -> None:
     n_total = int(round(args.seconds * sr)) * world
     audio = synth.synth_audio(n_total, synth.BENCH_AUDIO_SEED)         # seed 1234 + config#
     pcm_dev = torch.from_numpy(audio).to(dev)                           # resident in HBM before the timed region
-    wlen = wb.max_waveform_samples(eng.encoder_ctx_size() - params.padding)
+    wlen = wb.max_waveform_samples(eng.max_mel_frames() - params.padding)
     starts, lens = wb.window_extents(n_total, sr, wlen, params.overlap_seconds)
     n_win = len(starts)
     row_stride = 4 + args.max_depth + 4
@@ -161,7 +170,7 @@ def main() -> None:
         pmc = {}
         pmc_json = os.path.join(ROOT, "profiles", "r02_c_pmc_traffic_tiny_en_30s.json")
         if args.model in ("tiny.en", "tiny_en") and args.dtype == "f32" and args.beam == 1 and args.seconds == 30.0 \
-                and os.path.exists(pmc_json):
+                and args.geometry == "reference" and os.path.exists(pmc_json):
             pmc = json.load(open(pmc_json))
         def pmc_bytes(cls_name):
             """HBM bytes per launch of the rocprof kernel(s) behind one profiler class (profiles/r02_pmc_*.json is keyed
@@ -214,9 +223,9 @@ def main() -> None:
         n_mel = shift * (n_mw - 1) + int(wlen)
         big = pcm_dev.repeat((n_mel + n_total - 1) // n_total)[:n_mel].contiguous()
         m_starts, m_lens = wb.window_extents(n_mel, sr, wlen, params.overlap_seconds)
-        Ts = eng.encoder_ctx_size()
+        Ts = eng.max_mel_frames()
         mel_out = torch.empty((len(m_starts), 80, Ts), dtype=torch.float32, device=dev)
-        clip = eng.encoder_ctx_size() - params.padding
+        clip = eng.max_mel_frames() - params.padding
         wb.waveform_to_mels_dev(big.data_ptr(), n_mel, m_starts, m_lens, mel_out.data_ptr(), 80 * Ts, Ts, sr, clip,
                                 params.padding, local_rank, iters=2)                       # warm-up
         iters = 20
@@ -236,7 +245,7 @@ def main() -> None:
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import transcribe as otr
         from oracle.model import OracleWhisper
-        ow = OracleWhisper(weights)
+        ow = OracleWhisper(weights, frame_limit_x2=args.geometry == "whisper30")
         ost = otr.SpecialTokens(st.start_of_transcript, st.language, st.transcribe, st.no_timestamps,
                                 st.end_of_text, st.is_special.astype(bool))
         n_cpu = min(n_total, int(wlen))                                  # bounded sample: ONE reference window,
@@ -247,7 +256,7 @@ def main() -> None:
         cpu_rtf = (n_cpu / sr) / cpu_dt
         cpu_baseline = {"value": round(cpu_rtf, 3), "unit": "x real-time", "cores": torch.get_num_threads(),
                         "kind": "port",
-                        "sample": f"1 reference window ({n_cpu / sr:.1f} s), {args.model}, beam {args.beam}, "
+                        "sample": f"1 window ({n_cpu / sr:.1f} s, {args.geometry} geometry), {args.model}, beam {args.beam}, "
                                   f"depth {depth_cpu}, PyTorch-CPU fp32 restatement of the reference algorithm as "
                                   f"written (dense-DFT mel, no KV cache); {cpu_dt:.1f} s wall",
                         "host_cpus": os.cpu_count()}
@@ -255,7 +264,8 @@ def main() -> None:
     if rank == 0:
         audio_s = args.seconds * world * args.steps
         lo, hi = shard.partition_windows(n_win, rank, world)
-        rl = e2e_roofline_ms(eng.dims, lens[lo:hi], 3 + args.max_depth, args.dtype)      # per rank (weak scaling)
+        rl = e2e_roofline_ms(eng.dims, lens[lo:hi], 3 + args.max_depth, args.dtype,
+                             eng.max_mel_frames() - params.padding)                      # per rank (weak scaling)
         work = rl.pop("_work")
         if stages:
             # achieved rates of the two big stages from their algorithmic work: encoder + cross-K/V from the profiled
@@ -286,8 +296,11 @@ def main() -> None:
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic (seeded synthetic weights at the real shapes; seeded synthetic 16 kHz audio)",
-            "config": {"workload": f"{args.model}, {args.seconds:g} s of 16 kHz audio per GPU per step, reference "
-                                   f"windowing ({n_win} windows <= 14.9 s, 3 s overlap), HIP mel + encoder + "
+            "config": {"workload": f"{args.model}, {args.seconds:g} s of 16 kHz audio per GPU per step, "
+                                   + (f"reference windowing ({n_win} windows <= 14.9 s, 3 s overlap)" if args.geometry == "reference"
+                                      else f"opt-in Whisper geometry ({n_win} window(s) <= 29.9 s: T = 2990 + 10 frames, "
+                                           f"C = 1500; not reference behaviour)") +
+                                   f", HIP mel + encoder + "
                                    f"KV-cached decode, {'greedy (beam_size 1)' if args.beam == 1 else 'beam ' + str(args.beam)}, "
                                    f"max_depth {args.max_depth}",
                        "windows": n_win, "beam_size": args.beam, "max_depth": args.max_depth,

@@ -217,6 +217,25 @@ void wb_session_free(wb_session* s);
 int wb_session_decode(wb_session* s, const wb_decode_params* p, int32_t* out_tokens,
                       int32_t row_stride, int32_t* out_lens);
 
+/* Optional mode (not the reference's live behaviour): the same beam search from a caller-supplied initial
+ * sequence instead of the four-token prompt of transcribe.rs:203 -- the building block of the prompt
+ * conditioning the reference wrote and then disabled (transcribe.rs:188-199, shadowed at :201).  The special-token
+ * mask still applies while the sequence length is <= mask_until_len (transcribe.rs:271-275), i.e. never for a
+ * prompt longer than that.  row_stride >= prompt_len + max_depth. */
+int wb_session_decode_prompt(wb_session* s, const wb_decode_params* p, const int32_t* prompt, int32_t prompt_len,
+                             int32_t* out_tokens, int32_t row_stride, int32_t* out_lens);
+
+/* Optional mode: waveform_to_text with that prompt conditioning switched back on -- every window after the first
+ * starts from [tok_start_of_prev, the last n_prev_tokens (reference: 5) non-special tokens of the transcript so far,
+ * start_of_transcript, language, transcribe, no_timestamps] (transcribe.rs:43-50, :188-199, :203), and its row
+ * (prompt included, as mels_to_text returns it) is stitched with find_chunk_overlap (:56-63).  Windows depend on
+ * their predecessors, so they are decoded one at a time; win_tokens holds one row of `row_stride` ints per window,
+ * row_stride >= 1 + n_prev_tokens + 4 + max_depth.  PCM on the host. */
+int wb_waveform_to_tokens_prompted(wb_model* m, const float* pcm, int64_t n, int sample_rate,
+                                   const wb_decode_params* p, const uint8_t* is_special, int32_t tok_start_of_prev,
+                                   int32_t n_prev_tokens, int32_t* win_tokens, int32_t row_stride, int32_t* win_lens,
+                                   int32_t* stitched, int64_t stitched_cap, int64_t* n_stitched);
+
 /* The same beam search (src/beam.rs:9-110 driving the closure of transcribe.rs:253-307) over a
  * caller-supplied step function with wb_session_step's contract -- the host logic without the
  * GPU, e.g. for a Rust caller that owns its own model, and for CPU tests of the bookkeeping. */

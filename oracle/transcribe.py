@@ -62,15 +62,22 @@ def window_extents(n_samples: int, sample_rate: int, window_length_samples: int)
 
 
 def mels_to_tokens(whisper: OracleWhisper, st: SpecialTokens, mels: torch.Tensor, padding: int = 10,
-                   beam_size: int = 5, max_depth: int = 100) -> List[int]:
-    """transcribe.rs:148-312 (token ids instead of text). mels: [1, 80, T]."""
+                   beam_size: int = 5, max_depth: int = 100, prev_nonspecial_tokens: Sequence[int] = (),
+                   start_of_prev: Optional[int] = None) -> List[int]:
+    """transcribe.rs:148-312 (token ids instead of text). mels: [1, 80, T].
+
+    `start_of_prev` (None = the live code): the retired prompt conditioning of :188-199 -- the reference builds
+    `[start_of_prev, prev tokens...]` and then shadows it with an empty list (:201).  With an id given, that first
+    list is kept, exactly as :195-199 computes it."""
     n_ctx_max_encoder = whisper.encoder_ctx_size()
     _, n_mel, n_ctx = mels.shape
     mels = torch.cat([mels[0:1, :, 0:min(n_ctx, n_ctx_max_encoder - padding)],
                       torch.zeros(1, n_mel, padding, dtype=mels.dtype)], 2)      # :171-177
-    initial = obeam.BeamNode(
-        seq=[(t, 0.0) for t in (st.start_of_transcript, st.language, st.transcribe, st.no_timestamps)],
-        log_prob=0.0)                                                            # :203-220
+    initial_tokens: List[int] = []                                               # :201
+    if start_of_prev is not None and len(prev_nonspecial_tokens) > 0:            # :195-199 (dead in the reference)
+        initial_tokens = [start_of_prev] + list(prev_nonspecial_tokens)
+    initial_tokens += [st.start_of_transcript, st.language, st.transcribe, st.no_timestamps]   # :203
+    initial = obeam.BeamNode(seq=[(t, 0.0) for t in initial_tokens], log_prob=0.0)             # :205-220
     encoder_output = whisper.forward_encoder(mels)                               # :222
     neg_inf = float("-inf")
     maskout = torch.tensor(np.where(st.is_special, neg_inf, 0.0), dtype=torch.float32)  # :244
@@ -110,8 +117,9 @@ def mels_to_tokens(whisper: OracleWhisper, st: SpecialTokens, mels: torch.Tensor
 
 def waveform_to_tokens(whisper: OracleWhisper, st: SpecialTokens, waveform: np.ndarray,
                        sample_rate: int = 16000, beam_size: int = 5, max_depth: int = 100,
-                       return_windows: bool = False):
-    """transcribe.rs:23-74 without the tokenizer: returns the stitched token ids."""
+                       return_windows: bool = False, start_of_prev: Optional[int] = None):
+    """transcribe.rs:23-74 without the tokenizer: returns the stitched token ids.
+    `start_of_prev`: see mels_to_tokens (None = the reference's live behaviour)."""
     padding = 10
     n_per_window = max_waveform_samples(whisper.encoder_ctx_size() - padding)     # :32-34
     tokens: List[int] = []
@@ -119,7 +127,8 @@ def waveform_to_tokens(whisper: OracleWhisper, st: SpecialTokens, waveform: np.n
     wav = torch.as_tensor(np.asarray(waveform, dtype=np.float32))
     for start, end in window_extents(len(wav), sample_rate, n_per_window):
         mel = prep_audio(wav[start:end][None], float(sample_rate))                # :134
-        new_tokens = mels_to_tokens(whisper, st, mel, padding, beam_size, max_depth)
+        prev_normal_tokens = [t for t in reversed(tokens) if not st.is_special[t]][:5][::-1]   # :43-50
+        new_tokens = mels_to_tokens(whisper, st, mel, padding, beam_size, max_depth, prev_normal_tokens, start_of_prev)
         per_window.append(list(new_tokens))
         tokens = stitch(tokens, new_tokens)
     return (tokens, per_window) if return_windows else tokens

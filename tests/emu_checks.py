@@ -60,6 +60,16 @@ def main(which):
         ref, rw = otr.waveform_to_tokens(o2, pu.ost(st), a, 16000, 1, 6, return_windows=True)
         assert got == ref and wins == rw and len(wins) < len(ref_limit_wins), (got, ref)
         e2.close()
+    elif which == "prompted":
+        # optional mode: the prompt conditioning the reference disabled (transcribe.rs:43-50, :188-199)
+        from whisper_burn_amd import legacy
+        a = synth.synth_audio(16000 * 28, 13)                            # 3 windows
+        for beam in (1, 3):
+            got, rows = legacy.waveform_to_tokens_prompted(eng, st, a, 16000, beam_size=beam, max_depth=7)
+            ref, rrows = otr.waveform_to_tokens(o, pu.ost(st), a, 16000, beam, 7, return_windows=True,
+                                                start_of_prev=st.start_of_prev)
+            assert len(rows) == 3 and rows[0][0] == st.start_of_transcript and rows[1][0] == st.start_of_prev, rows
+            assert rows == rrows and got == ref, (beam, rows, rrows)
     else:
         raise SystemExit(f"unknown check {which}")
     eng.close()

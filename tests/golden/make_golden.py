@@ -117,7 +117,7 @@ def sec_workload(name):
     def run(out):
         wl = workloads.WORKLOADS[name]
         print(f"[{name}] {wl}", flush=True)
-        o = OracleWhisper(wl.weights())
+        o = OracleWhisper(wl.weights(), frame_limit_x2=wl.frame_limit_x2)
         st = SpecialTokens.for_vocab(o.dims.n_vocab)
         audio = synth.synth_audio(wl.n_samples, wl.audio_seed)
         rows = decode_windows(o, st, audio, wl.beam, wl.depth, wl.windows)

@@ -59,10 +59,10 @@ def test_every_preset_decodes_diverse_tokens():
     assert any(len(r) < 4 + 100 for r in rows_of("base_beam5_eot"))    # ... and beams that finish on EOT
 
 
-@pytest.mark.parametrize("name", ["tiny_bench", "small_10min"])
+@pytest.mark.parametrize("name", ["tiny_bench", "small_10min", "tiny_whisper30"])
 def test_golden_rows_are_the_oracles_greedy_chain(name):
     wl = workloads.WORKLOADS[name]
-    o = OracleWhisper(wl.weights())
+    o = OracleWhisper(wl.weights(), frame_limit_x2=wl.frame_limit_x2)
     st = SpecialTokens.for_vocab(o.dims.n_vocab)
     mels = pu.window_mels(o, wl.audio())
     sel = range(len(mels)) if wl.windows is None else wl.windows

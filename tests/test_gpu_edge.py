@@ -173,3 +173,35 @@ def test_max_depth_zero_returns_the_prompt(micro):
     for beam in (1, 3):
         got, wins = wb.waveform_to_tokens(eng, st, audio, 16000, beam, 0)
         assert got == [st.start_of_transcript, st.language, st.transcribe, st.no_timestamps]
+
+
+def test_whisper_window_geometry_is_opt_in():
+    """wb_model_set_frame_limit: by default a window holds at most n_audio_ctx MEL FRAMES and a longer one is the
+    reference's panic (mod.rs:236-241 -> WB_ERR_SHAPE); opted in, it holds 2 n_audio_ctx frames = n_audio_ctx encoder
+    positions (Whisper's own 30 s chunk: 12 key chunks per head in the decoder's cross-attention, the kvsplit /
+    flash encoder attention over 1500 keys).  Encoder output and beam-3 tokens against the oracle with the same
+    switch."""
+    import torch
+    dims = synth.micro_dims(n_state=128, n_head=2, n_layer=2, n_vocab=1031)           # n_audio_ctx = 1500
+    w = synth.synth_weights(dims, seed=23)
+    eng, st = wb.Whisper.from_tensors(w), wb.SpecialTokens.for_vocab(1031)
+    audio = synth.synth_audio(478559, 52)                                              # one 29.9 s window
+    mel = np.concatenate([wb.prep_audio(audio[None]), np.zeros((1, 80, 10), np.float32)], 2)
+    assert mel.shape == (1, 80, 3000) and eng.max_mel_frames() == 1500
+    with pytest.raises(wb.WbError) as e:
+        eng.forward_encoder(mel)
+    assert e.value.status == -2 and "cannot exceed 1500" in str(e.value)
+    eng.set_frame_limit(True)
+    assert eng.max_mel_frames() == 3000
+    o = OracleWhisper(w, frame_limit_x2=True)
+    enc = eng.forward_encoder(mel)
+    ref_enc = o.forward_encoder(torch.from_numpy(mel)).numpy()
+    assert enc.shape == (1, 1500, 128) and np.abs(enc - ref_enc).max() < 2e-4
+    for beam, depth in ((1, 12), (3, 8)):
+        got, wins = wb.waveform_to_tokens(eng, st, audio, 16000, beam, depth)
+        ref, rw = otr.waveform_to_tokens(o, _special(st), audio, 16000, beam, depth, return_windows=True)
+        assert len(wins) == 1 and wins == rw and got == ref, (beam, got, ref)
+    eng.set_frame_limit(False)                                                         # and back: the reference's windows
+    got, wins = wb.waveform_to_tokens(eng, st, audio[:300000], 16000, 1, 6)
+    assert len(wins) == 2 and got == otr.waveform_to_tokens(OracleWhisper(w), _special(st), audio[:300000], 16000, 1, 6)
+    eng.close()

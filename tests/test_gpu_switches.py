@@ -41,7 +41,7 @@ def _run(env_extra):
         return _CACHE[key]
     env = dict(os.environ)
     for k in list(env):
-        if k.startswith("WHISPER_HIP_") and k != "WHISPER_HIP_LIB":
+        if k.startswith("WHISPER_HIP_") and k not in ("WHISPER_HIP_LIB", "WHISPER_HIP_ALLOW_EMU"):
             del env[k]
     env.update(env_extra)
     code = CHILD % {"root": ROOT, "pkg": os.path.join(ROOT, "whisper-burn_amd"), "tests": os.path.join(ROOT, "tests")}

@@ -10,6 +10,8 @@ they are not degenerate).
   #4 small (V = 51 865, d = 768, 12 layers), 10 minutes = 51 windows: first and last window vs the oracle,
      logits of wb_forward at small's real shape <= 1e-3
   #5 large-v2, one full 14.9 s window (+ its 3 s tail window), greedy
+  #2(b) the "perf geometry": tiny.en, ONE 30 s window (T = 2990 + 10, C = 1500), greedy depth 100 -- opt-in on both
+     sides (wb_model_set_frame_limit; the reference itself panics on such a window, mod.rs:236-241)
 
 and per-step log-prob parity of the KV-cached session at tiny.en's real shape over 134 positions (the second
 112-key self-attention tile, forking / dying beams, two windows of different length).
@@ -39,10 +41,12 @@ def rows_of(name):
 
 
 @pytest.mark.parametrize("name", ["tiny_bench", "tiny_beam5", "base_beam5", "base_beam5_eot", "small_10min",
-                                  "large_window"])
+                                  "large_window", "tiny_whisper30"])
 def test_workload_tokens_match_oracle(name):
     wl = workloads.WORKLOADS[name]
     eng = wb.Whisper.from_tensors(wl.weights())
+    if wl.frame_limit_x2:          # the opt-in 30 s window (T = 2990, C = 1500: 12 key chunks per head in the decoder)
+        eng.set_frame_limit(True)
     st = wb.SpecialTokens.for_vocab(eng.dims["n_vocab"])
     full, wins = wb.waveform_to_tokens(eng, st, wl.audio(), 16000, wl.beam, wl.depth)
     eng.close()

@@ -79,3 +79,31 @@ def test_legacy_greedy_matches_the_oracle_loop():
             stops.add("ctx" if len(got) == 49 else "early")
         eng.close()
     assert stops == {"ctx", "early"}, stops                       # both the length cap and an early stop were exercised
+
+
+@pytest.mark.gpu
+def test_prompt_conditioning_matches_the_oracle():
+    """Optional mode: the prompt conditioning the reference wrote and disabled (transcribe.rs:43-50, :188-199, shadowed at
+    :201).  Every window after the first starts from [<|startofprev|>, last five non-special tokens, the four-token
+    prompt]; rows (prompt included) and the stitched stream equal the oracle's restatement, greedy and beam 3."""
+    import whisper_burn_amd as wb
+    from whisper_burn_amd import synth
+    from oracle.model import OracleWhisper
+    import parity_util as pu
+    dims = synth.micro_dims(n_state=128, n_head=2, n_layer=2, n_vocab=1031)
+    w = synth.synth_weights(dims, seed=4242)
+    eng, o = wb.Whisper.from_tensors(w), OracleWhisper(w)
+    st = wb.SpecialTokens.for_vocab(1031)
+    audio = synth.synth_audio(16000 * 28, 13)                         # three reference windows
+    plain, _ = wb.waveform_to_tokens(eng, st, audio, 16000, 1, 9)
+    for beam in (1, 3):
+        got, rows = legacy.waveform_to_tokens_prompted(eng, st, audio, 16000, beam_size=beam, max_depth=9)
+        ref, rrows = otr.waveform_to_tokens(o, pu.ost(st), audio, 16000, beam, 9, return_windows=True,
+                                            start_of_prev=st.start_of_prev)
+        assert len(rows) == 3 and rows[0][:4] == [st.start_of_transcript, st.language, st.transcribe, st.no_timestamps]
+        for r in rows[1:]:                                               # <|startofprev|> + 5 previous tokens + prompt
+            assert r[0] == st.start_of_prev and r[6:10] == rows[0][:4] and not any(st.is_special[t] for t in r[1:6])
+        assert rows == rrows and got == ref, (beam, rows, rrows)
+        if beam == 1:
+            assert got != plain                                          # the conditioning changes the transcript
+    eng.close()

@@ -22,6 +22,8 @@ class Workload:
     depth: int
     windows: Optional[Tuple[int, ...]] = None      # None = every reference window
     recipe: Tuple[Tuple[str, float], ...] = ()      # synth_weights overrides
+    # opt-in Whisper geometry (wb_model_set_frame_limit): windows of 2 n_audio_ctx frames -- NOT reference behaviour
+    frame_limit_x2: bool = False
 
     def audio(self):
         return synth.synth_audio(self.n_samples, self.audio_seed)
@@ -47,4 +49,8 @@ WORKLOADS = {
     "small_10min": Workload("small", 9600000, 1238, 1, 12, (0, 50)),
     # config #5: large-v2, one full 14.9 s window
     "large_window": Workload("large-v2", 238559, 1239, 1, 8),
+    # config #2(b), the "perf geometry" of SURVEY 8d: ONE window of T = 2990 (+10 zero) frames, C = 1500 encoder
+    # positions -- Whisper's own 30 s chunk, which the reference cannot run (mod.rs:236-241 bounds the FRAMES by
+    # n_audio_ctx); opt-in on both sides (wb_model_set_frame_limit / OracleWhisper(frame_limit_x2=True))
+    "tiny_whisper30": Workload("tiny.en", 478559, synth.BENCH_AUDIO_SEED, 1, 100, None, (), True),
 }

@@ -36,6 +36,12 @@ int DevMem::ensure(size_t n) {
   if (n <= bytes && p) return WB_OK;
   return alloc(n + n / 8);
 }
+int DevMem::ensure_zeroed(size_t n) {
+  if (n <= bytes && p) return WB_OK;
+  WB_TRY(alloc(n + n / 8));
+  WB_HIP(hipMemset(p, 0, bytes));
+  return WB_OK;
+}
 void DevMem::release() {
   if (p) (void)hipFree(p);
   p = nullptr;

@@ -244,8 +244,8 @@ int session_reserve(wb_session* s, int max_len) {
   max_len = std::max(8, std::min(max_len, std::min(D.n_text_ctx, 448)));
   s->Lmax = max_len;
   const size_t pool = (size_t)max_len * S;
-  WB_TRY(s->kc.ensure((size_t)NL * pool * d * 4));
-  WB_TRY(s->vc.ensure((size_t)NL * pool * d * 4));
+  WB_TRY(s->kc.ensure_zeroed((size_t)NL * pool * d * 4));
+  WB_TRY(s->vc.ensure_zeroed((size_t)NL * pool * d * 4));
   WB_TRY(s->tabs.ensure((size_t)2 * S * max_len * 4));
   s->lay = make_step_layout(S, s->W);
   WB_TRY(s->state.ensure((size_t)s->lay.total * 4));

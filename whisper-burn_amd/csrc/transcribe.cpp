@@ -189,24 +189,31 @@ struct Cont { int32_t tok; double score; };
 }  // namespace
 
 // Beam search over an abstract step function (the session step on the GPU, or a caller's own).
+// `prompt_in` / `P` (optional): the initial sequence of every window instead of the four-token prompt of
+// transcribe.rs:203 -- the retired prompt-conditioning mode (transcribe.rs:188-199) prepends <|startofprev|> and
+// the previous window's last non-special tokens.
 static int beam_search_windows(const wb_decode_params* p, int W, int V, int S, wb_step_fn step, void* user,
-                               int32_t* out_tokens, int32_t row_stride, int32_t* out_lens) {
+                               int32_t* out_tokens, int32_t row_stride, int32_t* out_lens,
+                               const int32_t* prompt_in = nullptr, int P = 4) {
   WB_REQUIRE(p && step && out_tokens && out_lens && W >= 1, WB_ERR_ARG, "beam search: null / bad argument");
   WB_REQUIRE(p->beam_size >= 1 && p->beam_size <= TOPK_MAX, WB_ERR_ARG, "beam_size %d outside [1, %d]", p->beam_size,
              TOPK_MAX);
   WB_REQUIRE(p->max_depth >= 0, WB_ERR_ARG, "max_depth must be >= 0");
   const int k = p->beam_size;
-  const int32_t prompt[4] = {p->tok_start_of_transcript, p->tok_language, p->tok_transcribe,
-                             p->tok_no_timestamps};   // transcribe.rs:203
-  for (int t : prompt) WB_REQUIRE(t >= 0 && t < V, WB_ERR_ARG, "prompt token %d out of range", t);
+  const int32_t prompt4[4] = {p->tok_start_of_transcript, p->tok_language, p->tok_transcribe,
+                              p->tok_no_timestamps};   // transcribe.rs:203
+  const int32_t* prompt = prompt_in ? prompt_in : prompt4;
+  if (!prompt_in) P = 4;
+  WB_REQUIRE(P >= 1, WB_ERR_ARG, "beam search: empty prompt");
+  for (int i = 0; i < P; i++) WB_REQUIRE(prompt[i] >= 0 && prompt[i] < V, WB_ERR_ARG, "prompt token %d out of range", prompt[i]);
   WB_REQUIRE(p->tok_end_of_text >= 0 && p->tok_end_of_text < V, WB_ERR_ARG, "end-of-text token out of range");
-  WB_REQUIRE(row_stride >= 4 + p->max_depth, WB_ERR_ARG, "row_stride %d < %d", row_stride, 4 + p->max_depth);
+  WB_REQUIRE(row_stride >= P + p->max_depth, WB_ERR_ARG, "row_stride %d < %d", row_stride, P + p->max_depth);
   const int32_t eot = p->tok_end_of_text;
   auto finished = [&](const Beam& b) { return !b.seq.empty() && b.seq.back() == eot; };   // transcribe.rs:235-241
 
-  // prefill: the first three prompt tokens only feed the KV cache
+  // prefill: all prompt tokens but the last only feed the KV cache
   std::vector<int32_t> tok(W), par(W), win(W);
-  for (int t = 0; t < 3; t++) {
+  for (int t = 0; t < P - 1; t++) {
     for (int w = 0; w < W; w++) { tok[w] = prompt[t]; par[w] = t == 0 ? -1 : w; win[w] = w; }
     WB_TRY(step(user, tok.data(), par.data(), win.data(), W, 0, 0, nullptr, nullptr));
   }
@@ -214,7 +221,7 @@ static int beam_search_windows(const wb_decode_params* p, int W, int V, int S, w
   std::vector<char> done(W, 0);
   for (int w = 0; w < W; w++) {
     Beam b;
-    b.seq.assign(prompt, prompt + 4); b.log_prob = 0.0; b.prev_slot = w;
+    b.seq.assign(prompt, prompt + P); b.log_prob = 0.0; b.prev_slot = P > 1 ? w : -1;
     beams[w].push_back(std::move(b));
   }
   std::vector<int32_t> top_ids((size_t)S * k);
@@ -235,7 +242,7 @@ static int beam_search_windows(const wb_decode_params* p, int W, int V, int S, w
       }
     }
     if (tok.empty()) break;
-    const int apply_mask = (4 + depth) <= p->mask_until_len;   // transcribe.rs:271-275
+    const int apply_mask = (P + depth) <= p->mask_until_len;   // transcribe.rs:271-275
     WB_TRY(step(user, tok.data(), par.data(), win.data(), (int)tok.size(), apply_mask, k, top_ids.data(),
                 top_lp.data()));
     for (int w = 0; w < W; w++) {   // beam_search_step, beam.rs:39-79
@@ -305,6 +312,77 @@ extern "C" int wb_session_decode(wb_session* s, const wb_decode_params* p, int32
                                 row_stride, out_lens);
   }
   return beam_search_windows(p, s->W, s->m->dims.n_vocab, s->S, session_step_thunk, s, out_tokens, row_stride, out_lens);
+}
+
+extern "C" int wb_session_decode_prompt(wb_session* s, const wb_decode_params* p, const int32_t* prompt,
+                                        int32_t prompt_len, int32_t* out_tokens, int32_t row_stride, int32_t* out_lens) {
+  WB_REQUIRE(s && p && prompt && out_tokens && out_lens, WB_ERR_ARG, "wb_session_decode_prompt: null argument");
+  WB_REQUIRE(prompt_len >= 1, WB_ERR_ARG, "wb_session_decode_prompt: empty prompt");
+  WB_REQUIRE(p->beam_size >= 1 && p->beam_size <= s->max_beams, WB_ERR_ARG, "beam_size %d outside [1, %d]",
+             p->beam_size, s->max_beams);
+  if (!s->decode_ready || s->Lmax < prompt_len + p->max_depth) WB_TRY(session_reserve(s, prompt_len + p->max_depth + 1));
+  return beam_search_windows(p, s->W, s->m->dims.n_vocab, s->S, session_step_thunk, s, out_tokens, row_stride, out_lens,
+                             prompt, prompt_len);
+}
+
+// transcribe.rs:23-74 with the prompt conditioning of :43-50 / :188-199 switched back on (the reference shadows it
+// with an empty list at :201 because "including the prev tokens causes whisper to hallucinate", :186).  Windows
+// depend on their predecessor's tokens here, so they are decoded one after another, one session each.
+extern "C" int wb_waveform_to_tokens_prompted(wb_model* m, const float* pcm, int64_t n, int sample_rate,
+                                              const wb_decode_params* p, const uint8_t* is_special,
+                                              int32_t tok_start_of_prev, int32_t n_prev_tokens, int32_t* win_tokens,
+                                              int32_t row_stride, int32_t* win_lens, int32_t* stitched,
+                                              int64_t stitched_cap, int64_t* n_stitched) {
+  WB_REQUIRE(m && pcm && p && is_special && win_tokens && win_lens && stitched && n_stitched, WB_ERR_ARG,
+             "wb_waveform_to_tokens_prompted: null argument");
+  const int V = m->dims.n_vocab;
+  WB_REQUIRE(tok_start_of_prev >= 0 && tok_start_of_prev < V, WB_ERR_ARG, "start-of-prev token out of range");
+  WB_REQUIRE(n_prev_tokens >= 0 && n_prev_tokens <= 64, WB_ERR_ARG, "n_prev_tokens outside [0, 64]");
+  WB_REQUIRE(p->padding >= 0 && p->padding < m->max_mel_frames(), WB_ERR_ARG, "bad padding");
+  const int max_prompt = 1 + n_prev_tokens + 4;
+  WB_REQUIRE(row_stride >= max_prompt + p->max_depth, WB_ERR_ARG, "row_stride %d < %d", row_stride,
+             max_prompt + p->max_depth);
+  const int64_t wlen = wb_max_waveform_samples(m->max_mel_frames() - p->padding);   // transcribe.rs:32-34
+  const int64_t n_win = wb_window_extents(n, sample_rate, wlen, p->overlap_seconds, nullptr, nullptr, 0);
+  std::vector<int64_t> starts((size_t)n_win), lens((size_t)n_win);
+  wb_window_extents(n, sample_rate, wlen, p->overlap_seconds, starts.data(), lens.data(), n_win);
+  std::vector<int32_t> tokens;   // transcribe.rs:40
+  for (int64_t w = 0; w < n_win; w++) {
+    // transcribe.rs:43-50: the last n non-special tokens so far, oldest first
+    std::vector<int32_t> prev;
+    for (auto it = tokens.rbegin(); it != tokens.rend() && (int)prev.size() < n_prev_tokens; ++it)
+      if (!is_special[*it]) prev.push_back(*it);
+    std::reverse(prev.begin(), prev.end());
+    // transcribe.rs:188-199, :203
+    std::vector<int32_t> prompt;
+    if (!prev.empty()) { prompt.push_back(tok_start_of_prev); prompt.insert(prompt.end(), prev.begin(), prev.end()); }
+    for (int32_t t : {p->tok_start_of_transcript, p->tok_language, p->tok_transcribe, p->tok_no_timestamps}) prompt.push_back(t);
+    wb_session* s = nullptr;
+    int rc = session_create(m, 1, p->beam_size, p->padding, &s);
+    int32_t* row = win_tokens + (size_t)w * row_stride;
+    if (rc == WB_OK) {
+      s->sample_rate = (double)sample_rate;
+      rc = session_encode_pcm(s, pcm, n, &starts[(size_t)w], &lens[(size_t)w], false);
+      if (rc == WB_OK) rc = wb_session_set_special_mask(s, is_special);
+      if (rc == WB_OK) rc = wb_session_decode_prompt(s, p, prompt.data(), (int32_t)prompt.size(), row, row_stride, &win_lens[w]);
+      wb_session_free(s);
+    }
+    WB_TRY(rc);
+    // transcribe.rs:56-63
+    int64_t pi = 0, ci = 0;
+    if (wb_find_chunk_overlap(tokens.data(), (int64_t)tokens.size(), row, win_lens[w], p->max_n_offsets, p->min_n_overlaps,
+                              &pi, &ci)) {
+      tokens.resize((size_t)pi);
+      tokens.insert(tokens.end(), row + ci, row + win_lens[w]);
+    } else {
+      tokens.insert(tokens.end(), row, row + win_lens[w]);
+    }
+  }
+  WB_REQUIRE((int64_t)tokens.size() <= stitched_cap, WB_ERR_ARG, "stitched capacity %lld < %zu", (long long)stitched_cap,
+             tokens.size());
+  memcpy(stitched, tokens.data(), tokens.size() * sizeof(int32_t));
+  *n_stitched = (int64_t)tokens.size();
+  return WB_OK;
 }
 
 extern "C" int wb_beam_search(const wb_decode_params* p, int n_windows, int n_vocab, wb_step_fn step, void* user,

@@ -58,6 +58,10 @@ struct DevMem {
   ~DevMem() { release(); }
   int alloc(size_t n);           // returns wb_status
   int ensure(size_t n);          // grow-only
+  // grow-only, and a fresh allocation is zero-filled: for buffers a kernel may READ before it has written them under
+  // a zero weight (cached K/V rows past the current position enter a dot product with probability 0) -- whatever bit
+  // patterns hipMalloc hands back, including NaN / Inf, must not reach the arithmetic
+  int ensure_zeroed(size_t n);
   void release();
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };

@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cstdio>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 struct ihipStream_t { bool capturing = false; ihipGraph* graph = nullptr; };
@@ -290,8 +291,8 @@ static void segv_handler(int sig, siginfo_t* si, void*) {
   (void)!write(2, msg, sizeof(msg) - 1);
   if (g_cur) {
     char buf[160];
-    int n = snprintf(buf, sizeof buf, "  block (%u,%u,%u) thread %u, fault address %p\n", g_cur->tc.bidx.x, g_cur->tc.bidx.y,
-                     g_cur->tc.bidx.z, g_cur->tc.tidx.x, si->si_addr);
+    int n = snprintf(buf, sizeof buf, "  block (%u,%u,%u) thread %u, fault address %p (si_code %d)\n", g_cur->tc.bidx.x,
+                     g_cur->tc.bidx.y, g_cur->tc.bidx.z, g_cur->tc.tidx.x, si->si_addr, si->si_code);
     (void)!write(2, buf, n);
   }
   void* bt[48];
@@ -347,14 +348,50 @@ hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 hipError_t hipDeviceSynchronize() { return hipSuccess; }
 hipError_t hipGetLastError() { return hipSuccess; }
 const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : e == hipErrorOutOfMemory ? "out of memory" : "hipemu error"; }
+// HIPEMU_GUARD=1 -- an address sanitizer for the kernels: every allocation ends flush (to 16 bytes) against an
+// inaccessible page, so a read or write past its end faults at the offending instruction (HIPEMU_SEGV_TRACE=1 prints
+// the kernel's backtrace, block and thread), and fresh memory is filled with 0xFF bytes (NaN as float, -1 as int)
+// so that a read of never-written memory poisons the result instead of happening to see zeros.
+namespace {
+struct GuardAlloc { void* base; size_t len; };
+std::mutex g_alloc_mu;
+std::unordered_map<void*, GuardAlloc> g_guarded;
+bool guard_mode() {
+  static const bool on = []() { const char* e = getenv("HIPEMU_GUARD"); return e && *e && *e != '0'; }();
+  return on;
+}
+}  // namespace
 hipError_t hipMalloc(void** p, size_t n) {
   *p = nullptr;
-  if (posix_memalign(p, 256, n ? n : 256)) return hipErrorOutOfMemory;
+  if (!guard_mode()) {
+    if (posix_memalign(p, 256, n ? n : 256)) return hipErrorOutOfMemory;
+    return hipSuccess;
+  }
+  const size_t page = 4096, need = (std::max<size_t>(n, 1) + 15) & ~(size_t)15;
+  const size_t len = ((need + page - 1) / page) * page + page;
+  char* base = (char*)mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (base == MAP_FAILED) return hipErrorOutOfMemory;
+  mprotect(base + len - page, page, PROT_NONE);
+  char* user = base + len - page - need;
+  static const bool poison = []() { const char* e = getenv("HIPEMU_GUARD"); return e && *e == '1'; }();
+  if (poison) memset(user, 0xFF, need);
+  std::lock_guard<std::mutex> lk(g_alloc_mu);
+  g_guarded[user] = GuardAlloc{base, len};
+  *p = user;
   return hipSuccess;
 }
-hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipFree(void* p) {
+  if (!p) return hipSuccess;
+  if (!guard_mode()) { free(p); return hipSuccess; }
+  std::lock_guard<std::mutex> lk(g_alloc_mu);
+  auto it = g_guarded.find(p);
+  if (it == g_guarded.end()) return hipErrorInvalidValue;
+  munmap(it->second.base, it->second.len);      // use after free faults as well
+  g_guarded.erase(it);
+  return hipSuccess;
+}
 hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
-hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipHostFree(void* p) { return hipFree(p); }
 hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return hipSuccess; }
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t st) {

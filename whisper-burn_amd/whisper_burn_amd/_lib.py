@@ -76,6 +76,11 @@ SIGNATURES = {
     "wb_session_encoder_output": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_int32_p]),
     "wb_session_free": (None, [C.c_void_p]),
     "wb_session_decode": (C.c_int, [C.c_void_p, C.POINTER(WbDecodeParams), c_int32_p, C.c_int32, c_int32_p]),
+    "wb_session_decode_prompt": (C.c_int, [C.c_void_p, C.POINTER(WbDecodeParams), c_int32_p, C.c_int32, c_int32_p, C.c_int32,
+                                           c_int32_p]),
+    "wb_waveform_to_tokens_prompted": (C.c_int, [C.c_void_p, c_float_p, C.c_int64, C.c_int, C.POINTER(WbDecodeParams),
+                                                 c_uint8_p, C.c_int32, C.c_int32, c_int32_p, C.c_int32, c_int32_p,
+                                                 c_int32_p, C.c_int64, c_int64_p]),
     "wb_beam_search": (C.c_int, [C.POINTER(WbDecodeParams), C.c_int, C.c_int, C.c_void_p, C.c_void_p, c_int32_p,
                                  C.c_int32, c_int32_p]),
     "wb_waveform_to_tokens": (C.c_int, [C.c_void_p, c_float_p, C.c_int64, C.c_int, C.POINTER(WbDecodeParams),

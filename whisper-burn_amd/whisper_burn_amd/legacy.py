@@ -80,3 +80,32 @@ def legacy_greedy(whisper: Whisper, st: SpecialTokens, mel: np.ndarray, padding:
     finally:
         sess.close()
     return tokens
+
+
+def waveform_to_tokens_prompted(whisper: Whisper, st: SpecialTokens, waveform, sample_rate: int = 16000,
+                                start_of_prev: Optional[int] = None, n_prev_tokens: int = 5, beam_size: int = 5,
+                                max_depth: int = 100):
+    """waveform_to_text (transcribe.rs:23-74) with the prompt conditioning the reference wrote and then disabled
+    (:43-50, :188-199; shadowed at :201, "including the prev tokens causes whisper to hallucinate", :186): every
+    window after the first starts from [<|startofprev|>, the last five non-special tokens so far, <|startoftranscript|>,
+    language, <|transcribe|>, <|notimestamps|>].  Returns (stitched ids, per-window rows with their prompts).
+    Windows depend on their predecessors: they are decoded one at a time (no batching, no sharding)."""
+    from .model import _f32, _fp, decode_params, max_waveform_samples, window_extents
+    lib = _lib.load()
+    wav = _f32(waveform).reshape(-1)
+    p = decode_params(st, beam_size, max_depth)
+    sop = st.start_of_prev if start_of_prev is None else start_of_prev
+    wlen = max_waveform_samples(whisper.max_mel_frames() - p.padding)
+    n_win = len(window_extents(len(wav), sample_rate, wlen, p.overlap_seconds)[0])
+    stride = 1 + n_prev_tokens + 4 + max_depth + 4
+    rows = np.zeros((max(n_win, 1), stride), np.int32)
+    lens = np.zeros(max(n_win, 1), np.int32)
+    stitched = np.zeros(max(n_win, 1) * stride, np.int32)
+    n_st = C.c_int64(0)
+    mask = np.ascontiguousarray(st.is_special, dtype=np.uint8)
+    check(lib.wb_waveform_to_tokens_prompted(whisper._h, _fp(wav), len(wav), sample_rate, C.byref(p),
+                                             mask.ctypes.data_as(_lib.c_uint8_p), int(sop), n_prev_tokens,
+                                             rows.ctypes.data_as(_lib.c_int32_p), stride,
+                                             lens.ctypes.data_as(_lib.c_int32_p),
+                                             stitched.ctypes.data_as(_lib.c_int32_p), len(stitched), C.byref(n_st)))
+    return stitched[:n_st.value].tolist(), [rows[i, :lens[i]].tolist() for i in range(n_win)]

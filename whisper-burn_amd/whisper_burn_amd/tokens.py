@@ -22,6 +22,7 @@ class SpecialTokens:
     no_timestamps: int
     end_of_text: int
     is_special: np.ndarray      # uint8 [V]: 1 where tokenizer.decode([id], skip_special=True) == ""
+    start_of_prev: int = -1     # <|startofprev|> (transcribe.rs:181); only the optional prompt-conditioning mode uses it
 
     @staticmethod
     def for_vocab(n_vocab: int, language_index: int = 0) -> "SpecialTokens":
@@ -30,17 +31,20 @@ class SpecialTokens:
         if n_vocab == 51864:        # gpt2 + <|endoftext|>=50256, sot=50257, 99 langs, translate ...
             eot, sot = 50256, 50257
             lang0, transcribe, notimestamps = 50258, 50358, 50362
+            sop = 50360
         elif n_vocab == 51865:
             eot, sot = 50257, 50258
             lang0, transcribe, notimestamps = 50259, 50359, 50363
+            sop = 50361
         else:
             assert n_vocab >= 32
             eot = n_vocab - 16
             sot, lang0, transcribe, notimestamps = eot + 1, eot + 2, eot + 4, eot + 6
+            sop = eot + 5
             language_index = 0
         is_special = np.zeros(n_vocab, dtype=np.uint8)
         is_special[eot:] = 1
-        return SpecialTokens(sot, lang0 + language_index, transcribe, notimestamps, eot, is_special)
+        return SpecialTokens(sot, lang0 + language_index, transcribe, notimestamps, eot, is_special, sop)
 
 
 # ---- tokenizer integration (src/token.rs) -------------------------------------------------------------------
@@ -89,5 +93,6 @@ class TokenizerAdapter:
                 raise KeyError(f"tokenizer has no {special_token_name(kind, language)}")
             ids[kind] = int(v)
         mask = np.array([1 if self.is_special(t) else 0 for t in range(self.vocab_size())], dtype=np.uint8)
+        sop = self.special_token(special_token_name("startofprev"))
         return SpecialTokens(ids["startoftranscript"], ids["language"], ids["transcribe"], ids["notimestamps"],
-                             ids["endoftext"], mask)
+                             ids["endoftext"], mask, -1 if sop is None else int(sop))
