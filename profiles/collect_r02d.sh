@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/r02d
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 T0=$(date +%s)
-BUDGET=${BUDGET:-600}
+BUDGET=${BUDGET:-570}
 stamp() { echo "[$(( $(date +%s) - T0 )) s] $*" | tee -a "$OUT/timeline.log"; }
 left() { echo $(( BUDGET - ($(date +%s) - T0) )); }
 run() {   # run <seconds> <log> <cmd...>: skipped when less than that much time is left
