@@ -50,6 +50,15 @@ def test_unfused_decode_paths_under_the_functional_model(emu_lib, switch):
     assert p.returncode == 0 and "EMU_CHECK_OK greedy" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
+@pytest.mark.parametrize("which", ["mel", "greedy", "beam", "forward"])
+def test_sanitizer_and_reversed_schedule(emu_lib, which):
+    """HIPEMU_GUARD=1: every device allocation ends against an inaccessible page and fresh memory is 0xFF-poisoned (NaN /
+    -1), so an out-of-bounds access faults and a read of never-written memory poisons the result.  HIPEMU_ORDER=reverse:
+    blocks, waves and lanes run in descending order -- a kernel that needs a particular order is missing a barrier."""
+    p = _run(emu_lib, which, {"HIPEMU_GUARD": "1", "HIPEMU_SEGV_TRACE": "1", "HIPEMU_ORDER": "reverse"})
+    assert p.returncode == 0 and f"EMU_CHECK_OK {which}" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
 def test_the_binding_refuses_the_functional_model_build(emu_lib):
     """The product path has no CPU route: _lib.load() raises on the hipemu build unless a test opts in."""
     p = _run(emu_lib, "greedy", allow=False)

@@ -249,16 +249,22 @@ static void run_block(const std::function<void()>& body, dim3 grid, dim3 block, 
   }
   const int n_waves = (nt + 63) / 64;
   int live = nt;
+  // HIPEMU_ORDER=reverse: waves and lanes are scheduled in descending order.  A kernel whose result depends on the
+  // order in which the waves of a block (or the lanes of a wave) reach an exchange through LDS / global memory is
+  // missing a barrier; the default ascending order and the reversed one must give the same output.
+  static const bool reverse = []() { const char* e = getenv("HIPEMU_ORDER"); return e && e[0] == 'r'; }();
   while (live > 0) {
     bool progress = false;
-    for (int w = 0; w < n_waves; w++) {
+    for (int wi = 0; wi < n_waves; wi++) {
+      const int w = reverse ? n_waves - 1 - wi : wi;
       Fiber** lane = &g_fibers[w * 64];
       const int n_lanes = std::min(64, nt - w * 64);
       bool again = true;
       while (again) {
         again = false;
         bool parked = false;
-        for (int l = 0; l < n_lanes; l++) {
+        for (int li = 0; li < n_lanes; li++) {
+          const int l = reverse ? n_lanes - 1 - li : li;
           Fiber* f = lane[l];
           if (f->state == RUNNABLE) {
             g_cur = f; g_tc = &f->tc;
@@ -321,9 +327,12 @@ static double now_ms() {
 
 static void run_grid(const std::function<void()>& body, dim3 grid, dim3 block, size_t shmem) {
   if (g_dyn.size() < shmem + 16) g_dyn.resize(shmem + 16);
-  for (unsigned z = 0; z < grid.z; z++)
-    for (unsigned y = 0; y < grid.y; y++)
-      for (unsigned x = 0; x < grid.x; x++) run_block(body, grid, block, dim3(x, y, z));
+  static const bool reverse = []() { const char* e = getenv("HIPEMU_ORDER"); return e && e[0] == 'r'; }();
+  const unsigned long long nb = (unsigned long long)grid.x * grid.y * grid.z;
+  for (unsigned long long i = 0; i < nb; i++) {      // blocks too: no kernel may depend on the block order
+    const unsigned long long b = reverse ? nb - 1 - i : i;
+    run_block(body, grid, block, dim3((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((unsigned long long)grid.x * grid.y))));
+  }
 }
 
 void enqueue(hipStream_t st, std::function<void()> body, dim3 grid, dim3 block, size_t shmem, hipEvent_t e0, hipEvent_t e1) {
