@@ -87,6 +87,11 @@ void launch_dec_cross_attn(hipStream_t st, const int* state, const StepLayout& l
                            int n_chunks, const float* Pq, int KS, const float* bq, int d, const float* ckv, int ldkv,
                            int koff, const int* win_row0, const int* win_C, float scale, float* ca, int max_nb,
                            const CaFuse* fuse = nullptr);
+// batch mode, one beam per window: one block per (head, window) streams the whole cached K/V and writes the normalised
+// head outputs to att [S][d] (no chunk partials, no combine launch)
+void launch_dec_cross_attn_stream(hipStream_t st, const int* state, const StepLayout& lay, int n_windows, int n_head,
+                                  const float* Pq, int KS, const float* bq, int d, const float* ckv, int ldkv, int koff,
+                                  const int* win_row0, const int* win_C, float scale, float* att);
 // ---- per-kernel profiling (wb_profile_enable): the call site tags the NEXT launch of this thread with a kernel
 // class and its algorithmic bytes; the launcher hands the tag's start / stop events to the dispatch itself
 // (hipExtLaunchKernelGGL), so the elapsed time is that kernel's own begin -> end -- the quantity

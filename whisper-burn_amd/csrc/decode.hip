@@ -675,13 +675,16 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const int* __restri
                                                              const int* __restrict__ win_C, float scale,
                                                              int n_head, int n_chunks, float* __restrict__ ca,
                                                              CaFuse fz) {
-  __shared__ __attribute__((aligned(16))) float hs[KQ > 0 ? MAX_BEAMS : 1][KQ > 0 ? 4 * KQ : 1];   // cross_attn_ln(x) rows
+  // per-beam arrays are sized by NB, not MAX_BEAMS: the one-beam-per-window instance (greedy batch mode: 38-51 windows
+  // x heads x chunks = thousands of blocks streaming the cached K/V) then needs 36 KB instead of 55 KB of LDS and
+  // four blocks share a CU instead of two -- twice the loads in flight while a block sits in its softmax phases
+  __shared__ __attribute__((aligned(16))) float hs[KQ > 0 ? NB : 1][KQ > 0 ? 4 * KQ : 1];   // cross_attn_ln(x) rows
   __shared__ __attribute__((aligned(16))) float Kt[CA_CH][65];
-  __shared__ __attribute__((aligned(16))) float qs[MAX_BEAMS][64];
-  __shared__ float sp[2][MAX_BEAMS][CA_CH];
-  __shared__ float pb[MAX_BEAMS][CA_CH];
-  __shared__ float stat[MAX_BEAMS][2];
-  __shared__ __attribute__((aligned(16))) float ored[4][MAX_BEAMS][64];
+  __shared__ __attribute__((aligned(16))) float qs[NB][64];
+  __shared__ float sp[2][NB][CA_CH];
+  __shared__ float pb[NB][CA_CH];
+  __shared__ float stat[NB][2];
+  __shared__ __attribute__((aligned(16))) float ored[4][NB][64];
   const int c = blockIdx.x, h = blockIdx.y, w = blockIdx.z, tid = threadIdx.x;
   const int nb = st[lay.win_nb + w];
   if (nb == 0 || st[ST_N] == 0) return;            // (ST_N == 0: a chained decode whose windows have all finished)
@@ -914,6 +917,117 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const int* __restri
   }
 }
 
+
+// ---- batch-mode cross-attention, one beam per window (greedy over many windows: configs #4 / #5) -------------
+// One block per (head, window) STREAMS the window's whole cached K and V for that head (C <= 1500 keys x 64 x 2 x 4 B =
+// up to 768 KB) instead of one block per 128-key chunk + a combine launch: the four waves take the four 32-key
+// quarters of every 128-key chunk and keep private flash-softmax states (m, l, o) -- there is NO block barrier and no
+// LDS in the loop -- which are merged once at the end.  Lane = (key row rr = lane / 16, float4 column c16 = lane % 16):
+// a 16-lane DPP row reads one 256-byte head row, the 4-term partial dot products are reduced over the row with DPP,
+// so the four row groups of the wave hold the scores (and probabilities) of their own keys and the P.V product needs
+// no exchange either: each lane accumulates its 4 output dims over its row group's keys; the row groups are summed
+// once after the loop (v_permlane16/32_swap).  Three register sets rotate so that the next chunk's K and V are in
+// flight while the current one is consumed; the normalised head output goes straight to `att` (mod.rs:518-532) and
+// the chunk-combine launch disappears.
+__global__ __launch_bounds__(256) void dec_cross_attn_stream_kernel(const int* __restrict__ st, StepLayout lay,
+                                                                    const float* __restrict__ Pq, int KS,
+                                                                    const float* __restrict__ bq, int d,
+                                                                    const float* __restrict__ ckv, int ldkv, int koff,
+                                                                    const int* __restrict__ win_row0,
+                                                                    const int* __restrict__ win_C, float scale,
+                                                                    float* __restrict__ att) {
+  __shared__ float red[4][66];                       // per wave: m, l, o[64]
+  const int h = blockIdx.x, w = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nb = st[lay.win_nb + w];
+  if (nb == 0 || st[ST_N] == 0) return;
+  const int slot = st[lay.win_slots + w * MAX_BEAMS];
+  const int C = win_C[w];
+  const int rr = lane >> 4, c16 = lane & 15;
+  const float* Kb = ckv + (int64_t)win_row0[w] * ldkv + koff + h * 64 + c16 * 4;   // K pre-scaled at projection time
+  const float* Vb = Kb + d;
+  const int n_chunks = (C + CA_CH - 1) / CA_CH;
+  // keys past C re-read row C - 1 (always valid): every load is unconditional, the score is masked instead
+  auto key_of = [&](int c, int i) { return c * CA_CH + wave * 32 + 4 * i + rr; };
+  // three rotating register sets of 8 float4: while chunk c is consumed (K set -> scores, V set -> P.V), chunk c + 1's K
+  // goes into the free set at the top of the step and its V into the K set as soon as the scores are done -- 16-24 KB
+  // per wave stay in flight with ~130 VGPRs (three waves per SIMD: the grid has 2.4-3 blocks per CU, one round)
+  float4 s0[8], s1[8], s2[8];
+  auto load_k = [&](float4 (&r)[8], int c) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) r[i] = *reinterpret_cast<const float4*>(Kb + (int64_t)min(key_of(c, i), C - 1) * ldkv);
+  };
+  auto load_v = [&](float4 (&r)[8], int c) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) r[i] = *reinterpret_cast<const float4*>(Vb + (int64_t)min(key_of(c, i), C - 1) * ldkv);
+  };
+  load_k(s0, 0);
+  load_v(s1, 0);
+  // q = (x Wq + bq) * s  (mod.rs:483, :506-509): this lane's four head dims
+  float q[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    const int col = h * 64 + c16 * 4 + t;
+    q[t] = fold_partials(Pq, KS, (int64_t)lay.S * d, (int64_t)slot * d + col, bq[col]) * scale;
+  }
+  float m = -INFINITY, l = 0.f, o[4] = {0.f, 0.f, 0.f, 0.f};
+  auto step = [&](float4 (&kr)[8], float4 (&vr)[8], float4 (&fr)[8], int c) {
+    const bool more = c + 1 < n_chunks;               // (uniform)
+    if (more) load_k(fr, c + 1);
+    float sc[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const float part = (kr[i].x * q[0] + kr[i].y * q[1]) + (kr[i].z * q[2] + kr[i].w * q[3]);
+      sc[i] = row16_sum(part);                        // the 16 lanes of a row now hold their key's score
+      if (key_of(c, i) >= C) sc[i] = -INFINITY;
+      mx = fmaxf(mx, sc[i]);
+    }
+    if (more) load_v(kr, c + 1);                      // the K registers are free: the next chunk's V
+    mx = xor32_max(xor16_max(mx));                    // over the wave's 32 keys of this chunk
+    const float m_new = fmaxf(m, mx);
+    if (m_new > -INFINITY) {                          // (wave-uniform) a quarter wholly past C contributes nothing
+      const float alpha = expf(m - m_new);            // m == -inf: 0
+      float ps = 0.f, po[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const float p = expf(sc[i] - m_new);          // masked keys: exp(-inf) = 0
+        ps += p;
+        po[0] += p * vr[i].x; po[1] += p * vr[i].y; po[2] += p * vr[i].z; po[3] += p * vr[i].w;
+      }
+      ps = xor32_sum(xor16_sum(ps));                  // every lane of a row group holds the same p: sum the 4 groups
+      l = l * alpha + ps;
+#pragma unroll
+      for (int t = 0; t < 4; t++) o[t] = o[t] * alpha + po[t];
+      m = m_new;
+    }
+  };
+#pragma unroll 1
+  for (int c = 0; c < n_chunks; c += 3) {
+    step(s0, s1, s2, c);                              // K = s0, V = s1, free = s2
+    if (c + 1 < n_chunks) step(s2, s0, s1, c + 1);    // K = s2, V = s0, free = s1
+    if (c + 2 < n_chunks) step(s1, s2, s0, c + 2);    // K = s1, V = s2, free = s0
+  }
+#pragma unroll
+  for (int t = 0; t < 4; t++) o[t] = xor32_sum(xor16_sum(o[t]));   // the four row groups' partial outputs
+  if (rr == 0) {
+#pragma unroll
+    for (int t = 0; t < 4; t++) red[wave][2 + c16 * 4 + t] = o[t];
+  }
+  if (lane == 0) { red[wave][0] = m; red[wave][1] = l; }
+  __syncthreads();
+  if (tid < 64) {                                     // merge the four waves' states in a fixed order
+    const float M = fmaxf(fmaxf(red[0][0], red[1][0]), fmaxf(red[2][0], red[3][0]));
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float wgt = expf(red[j][0] - M);
+      num += wgt * red[j][2 + tid];
+      den += wgt * red[j][1];
+    }
+    att[(int64_t)slot * d + h * 64 + tid] = num / den;
+  }
+}
+
 // ---- batch mode (more than 8 live beams): prologues materialised for the split-K MFMA GEMM ------
 // out[r][k] = GELU(bias[k] + sum_s P[s][r][k])   (mod.rs:377-378)
 __global__ void dec_gelu_fold_kernel(const int* __restrict__ st, const float* __restrict__ P, int KS, int S, int K,
@@ -1118,6 +1232,13 @@ void launch_dec_cross_attn(hipStream_t st, const int* state, const StepLayout& l
   else { WB_CA_NB(0); }
 #undef WB_CA_NB
 #undef WB_CA
+}
+
+void launch_dec_cross_attn_stream(hipStream_t st, const int* state, const StepLayout& lay, int n_windows, int n_head,
+                                  const float* Pq, int KS, const float* bq, int d, const float* ckv, int ldkv, int koff,
+                                  const int* win_row0, const int* win_C, float scale, float* att) {
+  WB_KLAUNCH(dec_cross_attn_stream_kernel, dim3(n_head, n_windows), dim3(256), 0, st, state, lay, Pq, KS, bq, d, ckv,
+             ldkv, koff, win_row0, win_C, scale, att);
 }
 
 void launch_dec_topk_merge(hipStream_t st, int* state, int n_max, const float* tstats, int n_tiles, int k,

@@ -449,6 +449,11 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
       return gemm_dispatch(m, st, g, w.wt, w.k);
     };
     const float* pend = nullptr; int ks_pend = 0; const float* pbias = nullptr;
+    // one beam per window (greedy over many windows): one block per (head, window) streams the whole cached K/V and
+    // writes the normalised head outputs -- no 128-key chunk partials, no combine launch (WHISPER_HIP_CROSS_STREAM=0:
+    // the chunked kernel + combine)
+    static const bool cross_stream_enabled = []() { const char* e = getenv("WHISPER_HIP_CROSS_STREAM"); return !(e && e[0] == '0'); }();
+    const bool cross_stream = cross_stream_enabled && max_nb <= 1;
     for (int l = 0; l < NL; l++) {
       const DecBlockW& b = m->dec[l];
       launch_dec_resolve_ln(st, dst, n, xb[xi], xb[xi ^ 1], pend, ks_pend, S, pbias, d, b.ln1, m->ln_eps_inside_sqrt, h);
@@ -462,9 +467,14 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
                             m->ln_eps_inside_sqrt, h);
       xi ^= 1;
       WB_TRY(big(b.cq, s->ks_o, h, s->Pq.as<float>()));
-      launch_dec_cross_attn(st, dst, L, s->W, H, s->n_chunks, s->Pq.as<float>(), s->ks_o, b.cq.b, d, s->ckv.as<float>(),
-                            ldkv, l * 2 * d, win_row0, win_C, m->qk_scale, s->ca.as<float>(), max_nb);
-      launch_dec_attn_combine(st, dst, n, s->ca.as<float>(), H, s->n_chunks, att);
+      if (cross_stream) {
+        launch_dec_cross_attn_stream(st, dst, L, s->W, H, s->Pq.as<float>(), s->ks_o, b.cq.b, d, s->ckv.as<float>(), ldkv,
+                                     l * 2 * d, win_row0, win_C, m->qk_scale, att);
+      } else {
+        launch_dec_cross_attn(st, dst, L, s->W, H, s->n_chunks, s->Pq.as<float>(), s->ks_o, b.cq.b, d, s->ckv.as<float>(),
+                              ldkv, l * 2 * d, win_row0, win_C, m->qk_scale, s->ca.as<float>(), max_nb);
+        launch_dec_attn_combine(st, dst, n, s->ca.as<float>(), H, s->n_chunks, att);
+      }
       WB_TRY(big(b.cout, s->ks_o, att, s->Po.as<float>()));
       launch_dec_resolve_ln(st, dst, n, xb[xi], xb[xi ^ 1], s->Po.as<float>(), s->ks_o, S, b.cout.b, d, b.ln3,
                             m->ln_eps_inside_sqrt, h);

@@ -90,6 +90,19 @@ __device__ __forceinline__ float xor16_sum(float v) {
   auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+__device__ __forceinline__ float xor16_max(float v) {
+  const unsigned u = __float_as_uint(v);
+  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+// sum / max over the 16 lanes of a DPP row (lanes 16r .. 16r+15), returned in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f<DPP_QUAD_XOR1, 0xF>(0.f, v);
+  v += dpp_f<DPP_QUAD_XOR2, 0xF>(0.f, v);
+  v += dpp_f<DPP_ROW_HALF_MIRROR, 0xF>(0.f, v);
+  v += dpp_f<DPP_ROW_MIRROR, 0xF>(0.f, v);
+  return v;
+}
 __device__ __forceinline__ float xor32_max(float v) {
   const unsigned u = __float_as_uint(v);
   auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
