@@ -16,6 +16,32 @@ from oracle.model import OracleWhisper
 from whisper_burn_amd import _lib, synth
 
 
+def _shard_worker(rank, world, port, q):
+    """One rank of the N > 1 path of bench.py, with the REAL engine (under the functional model) decoding its block of
+    windows: windows sharded by shard.partition_windows, one gloo all-gather of the token rows, host stitch."""
+    import os
+    import torch.distributed as dist
+    from whisper_burn_amd import shard
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dims = synth.micro_dims(n_state=128, n_head=2, n_layer=2, n_vocab=1031)
+        eng = wb.Whisper.from_tensors(synth.synth_weights(dims, seed=4242))
+        st = wb.SpecialTokens.for_vocab(1031)
+        a = synth.synth_audio(16000 * 52, 17)                             # 5 reference windows
+        n_win = len(wb.window_extents(len(a), 16000, wb.max_waveform_samples(1490))[0])
+        row = 4 + 8 + 4
+
+        def decode_local(lo, hi):
+            return wb.waveform_to_tokens(eng, st, a, 16000, 1, 8, win_begin=lo, win_end=hi)[1]
+
+        toks, wins = shard.transcribe_sharded(decode_local, wb.stitch_windows, n_win, rank, world, row)
+        q.put((rank, n_win, toks, wins))
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
 def main(which):
     assert b"hipemu" in _lib.load().wb_version()
     dims = synth.micro_dims(n_state=128, n_head=2, n_layer=2, n_vocab=1031)
@@ -60,6 +86,23 @@ def main(which):
         ref, rw = otr.waveform_to_tokens(o2, pu.ost(st), a, 16000, 1, 6, return_windows=True)
         assert got == ref and wins == rw and len(wins) < len(ref_limit_wins), (got, ref)
         e2.close()
+    elif which == "sharded":
+        import socket
+        import torch.multiprocessing as mp
+        a = synth.synth_audio(16000 * 52, 17)
+        ref, rw = otr.waveform_to_tokens(o, pu.ost(st), a, 16000, 1, 8, return_windows=True)
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+        for p_ in procs:
+            p_.start()
+        res = [q.get(timeout=240) for _ in procs]
+        for p_ in procs:
+            p_.join(timeout=60)
+            assert p_.exitcode == 0
+        for rank, n_win, toks, wins in res:
+            assert n_win == 5 and wins == rw and toks == ref, (rank, toks, ref)
     elif which == "prompted":
         # optional mode: the prompt conditioning the reference disabled (transcribe.rs:43-50, :188-199)
         from whisper_burn_amd import legacy

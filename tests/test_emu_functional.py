@@ -59,6 +59,13 @@ def test_sanitizer_and_reversed_schedule(emu_lib, which):
     assert p.returncode == 0 and f"EMU_CHECK_OK {which}" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
+def test_two_ranks_shard_the_windows_of_the_real_engine(emu_lib):
+    """The N > 1 path end to end on CPU: two gloo ranks, each decoding its block of windows with the engine itself
+    (functional model), one all-gather of the token rows, host stitch -- equal to the oracle's single-process run."""
+    p = _run(emu_lib, "sharded")
+    assert p.returncode == 0 and "EMU_CHECK_OK sharded" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
 def test_the_binding_refuses_the_functional_model_build(emu_lib):
     """The product path has no CPU route: _lib.load() raises on the hipemu build unless a test opts in."""
     p = _run(emu_lib, "greedy", allow=False)
