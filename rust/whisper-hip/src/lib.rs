@@ -111,6 +111,11 @@ impl Whisper {
     pub fn encoder_ctx_size(&self) -> usize { self.dims.n_audio_ctx as usize }
     /// mod.rs:68-70.
     pub fn decoder_ctx_size(&self) -> usize { self.dims.n_text_ctx as usize }
+    /// Opt-in, not reference behaviour: bound the encoder POSITIONS (not the mel frames, mod.rs:236-241) by
+    /// `n_audio_ctx`, i.e. Whisper's own 30 s window of 3000 frames; `false` restores the reference's 14.9 s windows.
+    pub fn set_frame_limit(&mut self, whisper_geometry: bool) -> Result<()> {
+        check(unsafe { ffi::wb_model_set_frame_limit(self.raw, whisper_geometry as c_int) })
+    }
 
     /// mod.rs:52-54: `[B, 80, T]` -> `[B, C, d]`, `C = (T - 1) / 2 + 1`; T > n_audio_ctx is the reference's panic.
     pub fn forward_encoder(&self, mel: &Tensor) -> Result<Tensor> {

@@ -86,6 +86,20 @@ def main(which):
         ref, rw = otr.waveform_to_tokens(o2, pu.ost(st), a, 16000, 1, 6, return_windows=True)
         assert got == ref and wins == rw and len(wins) < len(ref_limit_wins), (got, ref)
         e2.close()
+    elif which.startswith("shape"):
+        # the other decode-kernel template families: d = 384 (tiny.en's fused sublayer kernels), 512 (base.en's),
+        # 768 (no fused path: per-matrix GEMVs, unfused cross-attention), one layer each, vocabulary not a tile multiple
+        d = int(which[5:])
+        dims = synth.micro_dims(n_state=d, n_head=d // 64, n_layer=1, n_vocab=2053, n_audio_ctx=400)
+        w2 = synth.synth_weights(dims, seed=31 + d)
+        e2, o2 = wb.Whisper.from_tensors(w2), OracleWhisper(w2)
+        s2 = wb.SpecialTokens.for_vocab(2053)
+        a = synth.synth_audio(16000 * 3 + 123, 77)                        # one window
+        for beam, depth in ((1, 7), (3, 4)):
+            got, wins = wb.waveform_to_tokens(e2, s2, a, 16000, beam, depth)
+            ref, rw = otr.waveform_to_tokens(o2, pu.ost(s2), a, 16000, beam, depth, return_windows=True)
+            assert wins == rw and got == ref, (d, beam, wins, rw)
+        e2.close()
     elif which == "sharded":
         import socket
         import torch.multiprocessing as mp

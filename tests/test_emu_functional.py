@@ -44,6 +44,14 @@ def test_kernel_sources_reproduce_the_oracle_under_the_functional_model(emu_lib,
     assert p.returncode == 0 and f"EMU_CHECK_OK {which}" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
+@pytest.mark.parametrize("d", [384, 768])
+def test_the_other_kernel_template_families(emu_lib, d):
+    """d = 384 (the fused sublayer kernels of tiny.en; base.en's d = 512 instantiates the same templates) and 768
+    (per-matrix GEMVs, `small`'s path); tools/emu_fuzz.py draws 512 as well."""
+    p = _run(emu_lib, f"shape{d}")
+    assert p.returncode == 0 and f"EMU_CHECK_OK shape{d}" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
 @pytest.mark.parametrize("switch", ["WHISPER_HIP_FUSE_SUB", "WHISPER_HIP_FUSE_X", "WHISPER_HIP_CHAIN", "WHISPER_HIP_GRAPH"])
 def test_unfused_decode_paths_under_the_functional_model(emu_lib, switch):
     p = _run(emu_lib, "greedy", {switch: "0"})
