@@ -94,7 +94,7 @@ def main(which):
         w2 = synth.synth_weights(dims, seed=31 + d)
         e2, o2 = wb.Whisper.from_tensors(w2), OracleWhisper(w2)
         s2 = wb.SpecialTokens.for_vocab(2053)
-        a = synth.synth_audio(16000 * 3 + 123, 77)                        # one window
+        a = synth.synth_audio((16000 * 3 if d < 768 else 16000 * 3 // 2) + 123, 77)   # one window (emulated MFMA: d = 768 gets 1.5 s)
         for beam, depth in ((1, 7), (3, 4)):
             got, wins = wb.waveform_to_tokens(e2, s2, a, 16000, beam, depth)
             ref, rw = otr.waveform_to_tokens(o2, pu.ost(s2), a, 16000, beam, depth, return_windows=True)
