@@ -280,3 +280,23 @@ def test_mel_constant_tables_match_the_oracle():
     nz = (filt != 0).sum(1)
     assert nz.min() >= 1 and nz.max() <= 16 and 380 <= (filt != 0).sum() <= 400   # 391 non-zeros, 1-14 per row
     del C
+
+
+def test_cpu_baseline_leg_of_the_bench_runs_without_a_gpu():
+    """bench.run_cpu_baseline: the oracle on one bounded window, stages timed separately, no GPU involved."""
+    import importlib.util
+    import os
+    from whisper_burn_amd import synth
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    dims = synth.micro_dims(n_state=128, n_head=2, n_layer=2, n_vocab=1031, n_audio_ctx=400)
+    w = synth.synth_weights(dims, seed=4242)
+    st = wb.SpecialTokens.for_vocab(1031)
+    audio = synth.synth_audio(16000 * 6, 3)
+    wlen = wb.max_waveform_samples(400 - 10)
+    r = bench.run_cpu_baseline(w, st, audio, 16000, wlen, 1, 5, "reference", "micro")
+    assert r["kind"] == "port" and r["value"] > 0 and r["cores"] >= 1
+    s = r["stages_s"]
+    assert abs(s["mel"] + s["encoder"] + s["decode"] - s["total"]) < 2e-3 and s["decode"] > 0
+    assert "1 window (3.9 s" in r["sample"]
