@@ -100,6 +100,8 @@ def main() -> None:
     ap.add_argument("--beam", type=int, default=1)
     ap.add_argument("--max-depth", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mel-windows", type=int, default=256,
+                    help="batched windows of the frontend-alone leg (mel-frames/s; SURVEY 8d: >= 100)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 = exact-f32 MFMA parity path (the judged configuration); bf16 = speed path")
     args = ap.parse_args()
@@ -254,7 +256,7 @@ def main() -> None:
     # ---- the frontend alone (BASELINE.json's second metric): >= 100 batched reference windows, PCM resident ----
     mel_frontend = None
     if rank == 0:
-        n_mw = 256
+        n_mw = max(1, args.mel_windows)
         shift = int(wlen) - int(params.overlap_seconds * sr)
         n_mel = shift * (n_mw - 1) + int(wlen)
         big = pcm_dev.repeat((n_mel + n_total - 1) // n_total)[:n_mel].contiguous()
@@ -272,7 +274,7 @@ def main() -> None:
         mel_frontend = {"metric": "mel-frames/s", "value": round(fps, 1), "windows": len(m_starts), "frames_per_pass": fr,
                         "ms_per_pass": round(ms / iters, 4), "algorithmic_GBps": round(960.0 * fps / 1e9, 1),
                         "frac_of_hbm_peak": round(960.0 * fps / 1e9 / HBM_PEAK_GBS, 4),
-                        "note": "mel kernel + finalize on 256 reference windows resident in HBM; 960 algorithmic "
+                        "note": f"mel kernel + finalize on {n_mw} reference windows resident in HBM; 960 algorithmic "
                                 "bytes per frame (640 B of PCM in, 320 B of log-mel out)"}
         del big, mel_out
 

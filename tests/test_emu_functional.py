@@ -74,6 +74,30 @@ def test_two_ranks_shard_the_windows_of_the_real_engine(emu_lib):
     assert p.returncode == 0 and "EMU_CHECK_OK sharded" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
+@pytest.mark.parametrize("extra", [[], ["--geometry", "whisper30", "--beam", "2"]], ids=["default", "whisper30-beam2"])
+def test_bench_main_runs_to_its_json_line(emu_lib, extra):
+    """bench.py cannot start without cuda:0, and a broken bench line cannot be repaired after a round: tools/
+    bench_dry_run.py stubs the torch.cuda calls and runs the script UNCHANGED over the functional model with a micro
+    checkpoint -- every leg executes (timed steps, profiled passes, frontend, CPU baseline, JSON assembly)."""
+    import json
+    env = dict(os.environ)
+    env["WHISPER_HIP_LIB"] = emu_lib
+    p = subprocess.run([sys.executable, os.path.join(PKG, "tools", "bench_dry_run.py"), "--steps", "1", "--warmup", "0",
+                        "--mel-windows", "2", "--seconds", "8", "--max-depth", "6"] + extra, env=env, capture_output=True,
+                       text=True, timeout=600)
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
+    assert p.returncode == 0 and len(lines) == 1, p.stdout[-1500:] + p.stderr[-3000:]
+    out = json.loads(lines[0])
+    assert out["metric"].startswith("real-time factor") and out["value"] > 0 and out["n_gpus"] == 1 and out["steps"] == 1
+    assert out["unit"] == "x real-time" and out["higher_is_better"] is True and out["scaling"] == "weak"
+    assert "model" not in out["config"] and "workload" in out["config"] and out["vs_baseline"] is None
+    assert out["roofline"]["bound"] == "hbm" and out["roofline"]["kernel"] == out["kernels"][0]["kernel"]
+    assert 0 <= out["roofline"]["frac"] and out["roofline"]["peak"] == 8000.0 and out["roofline"]["unit"] == "GB/s"
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and set(cb["stages_s"]) == {"mel", "encoder", "decode", "total"}
+    assert out["mel_frontend"]["windows"] >= 2 and out["stages"]["decode_kernels_per_token"] > 0
+
+
 def test_the_binding_refuses_the_functional_model_build(emu_lib):
     """The product path has no CPU route: _lib.load() raises on the hipemu build unless a test opts in."""
     p = _run(emu_lib, "greedy", allow=False)
