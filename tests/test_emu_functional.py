@@ -98,6 +98,27 @@ def test_bench_main_runs_to_its_json_line(emu_lib, extra):
     assert out["mel_frontend"]["windows"] >= 2 and out["stages"]["decode_kernels_per_token"] > 0
 
 
+def test_bench_main_two_ranks_over_gloo(emu_lib):
+    """The driver's N > 1 launch line (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`) with the
+    dry-run wrapper in place of bench.py: RCCL is swapped for gloo, everything else is the script's own N > 1 path (per-rank
+    window blocks, the all-gather, MAX of the rank times, rank 0 prints ONE line with n_gpus = 2 and whole-job audio)."""
+    import json
+    import socket
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["WHISPER_HIP_LIB"] = emu_lib
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(PKG, "tools", "bench_dry_run.py"), "--gpus", "2",
+                        "--steps", "1", "--warmup", "0", "--mel-windows", "2", "--seconds", "8", "--max-depth", "6"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
+    assert p.returncode == 0 and len(lines) == 1, p.stdout[-1500:] + p.stderr[-3000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["cpu_baseline"] is None      # CPU leg: N = 1 only
+    assert out["config"]["windows"] >= 2                                                        # 16 s of audio in total
+    assert abs(out["value"] - 16.0 / (out["ms_per_step"] * 1e-3)) < 0.05 * out["value"]           # whole-job audio / time
+
+
 def test_the_binding_refuses_the_functional_model_build(emu_lib):
     """The product path has no CPU route: _lib.load() raises on the hipemu build unless a test opts in."""
     p = _run(emu_lib, "greedy", allow=False)

@@ -9,6 +9,8 @@ leg, the CPU baseline and the JSON assembly.  The numbers it prints are meaningl
 that the script runs to its JSON line.  Test infrastructure only.
 
     python whisper-burn_amd/tools/bench_dry_run.py --steps 1 --warmup 0 --mel-windows 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 \
+        whisper-burn_amd/tools/bench_dry_run.py --gpus 2 --steps 1 --warmup 0 --mel-windows 2      (the N > 1 path over gloo)
 """
 import os
 import runpy
@@ -25,7 +27,7 @@ import torch  # noqa: E402
 torch.cuda.is_available = lambda: True
 torch.cuda.set_device = lambda *a, **k: None
 torch.cuda.synchronize = lambda *a, **k: None
-_to, _empty = torch.Tensor.to, torch.empty
+_to, _empty, _tensor = torch.Tensor.to, torch.empty, torch.tensor
 
 
 def _is_cuda(x):
@@ -42,8 +44,28 @@ def _empty_cpu(*a, **k):
     return _empty(*a, **k)
 
 
+def _tensor_cpu(*a, **k):
+    if _is_cuda(k.get("device")):
+        k["device"] = "cpu"
+    return _tensor(*a, **k)
+
+
 torch.Tensor.to = _to_cpu
 torch.empty = _empty_cpu
+torch.tensor = _tensor_cpu
+
+# N > 1 (launched under torch.distributed.run like the driver does): RCCL needs GPUs, gloo carries the same collectives
+import torch.distributed as _dist  # noqa: E402
+
+_init_pg = _dist.init_process_group
+
+
+def _init_gloo(backend=None, **k):
+    k.pop("device_id", None)
+    return _init_pg(backend="gloo", **k)
+
+
+_dist.init_process_group = _init_gloo
 
 from whisper_burn_amd import synth  # noqa: E402
 

@@ -351,7 +351,7 @@ void enqueue(hipStream_t st, std::function<void()> body, dim3 grid, dim3 block, 
 
 // ---- host API -------------------------------------------------------------------------------------------------------
 using hipemu::g_mu;
-hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidValue; }
+hipError_t hipSetDevice(int d) { return d >= 0 && d < 64 ? hipSuccess : hipErrorInvalidValue; }   // (every "device" is this host)
 hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 hipError_t hipDeviceSynchronize() { return hipSuccess; }
