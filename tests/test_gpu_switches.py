@@ -63,3 +63,44 @@ def test_switch_reproduces_the_oracle_tokens(switch):
     # switch against the default path run the same way (the default itself is pinned by test_gpu_workloads)
     if switch:
         assert got["tiny_beam5"] == _run({})["tiny_beam5"]
+
+
+BATCH_CHILD = r"""
+import json, sys
+sys.path[:0] = [%(root)r, %(pkg)r, %(tests)r]
+import whisper_burn_amd as wb
+from whisper_burn_amd import synth
+dims = synth.micro_dims(n_state=128, n_head=2, n_layer=2, n_vocab=1031)
+eng = wb.Whisper.from_tensors(synth.synth_weights(dims, seed=4242))
+st = wb.SpecialTokens.for_vocab(1031)
+audio = synth.synth_audio(16000 * 140, 21)            # 12 reference windows: more than 8 live rows = batch mode
+toks, wins = wb.waveform_to_tokens(eng, st, audio, 16000, 1, 10)
+print("RESULT " + json.dumps({"wins": [list(map(int, w)) for w in wins], "toks": list(map(int, toks))}))
+"""
+
+
+@pytest.mark.gpu
+def test_batch_mode_cross_attention_variants_agree_with_the_oracle():
+    """Greedy over 12 windows runs the decoder in batch mode with one beam per window: the streaming cross-attention
+    kernel (default) and the chunked kernel + combine launch (WHISPER_HIP_CROSS_STREAM=0) both reproduce the oracle."""
+    import parity_util as pu
+    from oracle import transcribe as otr
+    from oracle.model import OracleWhisper
+    from whisper_burn_amd import synth
+    import whisper_burn_amd as wb
+    code = BATCH_CHILD % {"root": ROOT, "pkg": os.path.join(ROOT, "whisper-burn_amd"), "tests": os.path.join(ROOT, "tests")}
+    res = {}
+    for v in ("1", "0"):
+        env = {k: val for k, val in os.environ.items()
+               if not k.startswith("WHISPER_HIP_") or k in ("WHISPER_HIP_LIB", "WHISPER_HIP_ALLOW_EMU")}
+        env["WHISPER_HIP_CROSS_STREAM"] = v
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[v] = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    dims = synth.micro_dims(n_state=128, n_head=2, n_layer=2, n_vocab=1031)
+    o = OracleWhisper(synth.synth_weights(dims, seed=4242))
+    st = wb.SpecialTokens.for_vocab(1031)
+    ref, rw = otr.waveform_to_tokens(o, pu.ost(st), synth.synth_audio(16000 * 140, 21), 16000, 1, 10, return_windows=True)
+    assert len(rw) == 12
+    for v in ("1", "0"):
+        assert res[v]["wins"] == rw and res[v]["toks"] == ref, v
