@@ -40,6 +40,9 @@ int DevMem::ensure_zeroed(size_t n) {
   if (n <= bytes && p) return WB_OK;
   WB_TRY(alloc(n + n / 8));
   WB_HIP(hipMemset(p, 0, bytes));
+  // the owners' streams are non-blocking (no implicit ordering with the null stream the memset runs on): wait here, once
+  // per (re)allocation, so that no later cache append can be overtaken by the fill
+  WB_HIP(hipStreamSynchronize(nullptr));
   return WB_OK;
 }
 void DevMem::release() {
