@@ -100,6 +100,34 @@ def main(which):
             ref, rw = otr.waveform_to_tokens(o2, pu.ost(s2), a, 16000, beam, depth, return_windows=True)
             assert wins == rw and got == ref, (d, beam, wins, rw)
         e2.close()
+    elif which == "bitwise":
+        # a digest of raw output bytes: the summation orders are fixed (split-K planes folded in a fixed order, no float
+        # atomics), so the digest may not depend on the order in which blocks / waves / lanes are scheduled
+        import hashlib
+        hsh = hashlib.sha256()
+        a = synth.synth_audio(16000 * 21, 19)                             # two windows
+        mel = np.concatenate([wb.prep_audio(a[None, :32000]), np.zeros((1, 80, 10), np.float32)], 2)
+        toks = np.array([[st.start_of_transcript, st.language, st.transcribe, st.no_timestamps, 11, 503, 77, 9]], np.int32)
+        hsh.update(np.ascontiguousarray(mel).tobytes())
+        hsh.update(np.ascontiguousarray(eng.forward(mel, toks)).tobytes())
+        starts, lens = wb.window_extents(len(a), 16000, wb.max_waveform_samples(1490))
+        sess = wb.Session.begin(eng, a, starts, lens, max_beams=3)
+        sess.set_special_mask(st.is_special)
+        prompt = [st.start_of_transcript, st.language, st.transcribe, st.no_timestamps]
+        for i, t in enumerate(prompt[:-1]):
+            sess.step([t, t], [-1, -1] if i == 0 else [0, 1], [0, 1], apply_special_mask=False, k=0)
+        ids, lps = sess.step([prompt[-1]] * 2, [0, 1], [0, 1], apply_special_mask=True, k=3)
+        hsh.update(np.ascontiguousarray(ids).tobytes()); hsh.update(np.ascontiguousarray(lps).tobytes())
+        # fork: three beams per window continue with their own top-3
+        nt = [int(ids[w][j]) for w in (0, 1) for j in range(3)]
+        ids2, lps2 = sess.step(nt, [0, 0, 0, 1, 1, 1], [0, 0, 0, 1, 1, 1], apply_special_mask=True, k=3)
+        hsh.update(np.ascontiguousarray(lps2).tobytes())
+        for slot in range(6):
+            hsh.update(np.ascontiguousarray(sess.last_logprobs(slot)).tobytes())
+        sess.close()
+        got, _ = wb.waveform_to_tokens(eng, st, a, 16000, 1, 8)
+        hsh.update(np.asarray(got, np.int32).tobytes())
+        print("DIGEST", hsh.hexdigest())
     elif which == "sharded":
         import socket
         import torch.multiprocessing as mp

@@ -119,6 +119,19 @@ def test_bench_main_two_ranks_over_gloo(emu_lib):
     assert abs(out["value"] - 16.0 / (out["ms_per_step"] * 1e-3)) < 0.05 * out["value"]           # whole-job audio / time
 
 
+def test_outputs_are_bitwise_independent_of_the_schedule(emu_lib):
+    """split-K partial planes are folded in a fixed order and there are no float atomics, so results are
+    bit-reproducible.  Under the functional model that claim is checkable: the SHA-256 of the raw output bytes (log-mel,
+    stateless logits, top-k log-probs of forking beams, full log-prob rows, greedy tokens) is the same whether blocks,
+    waves and lanes are scheduled in ascending or in descending order."""
+    digests = []
+    for order in ({}, {"HIPEMU_ORDER": "reverse"}):
+        p = _run(emu_lib, "bitwise", order)
+        assert p.returncode == 0 and "EMU_CHECK_OK bitwise" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+        digests.append([l for l in p.stdout.splitlines() if l.startswith("DIGEST ")][-1])
+    assert digests[0] == digests[1], digests
+
+
 def test_the_binding_refuses_the_functional_model_build(emu_lib):
     """The product path has no CPU route: _lib.load() raises on the hipemu build unless a test opts in."""
     p = _run(emu_lib, "greedy", allow=False)
