@@ -88,6 +88,19 @@ print("RESULT " + json.dumps(res))
 """
 
 
+def draw_many(rng):
+    """Batch mode: 9-16 short windows (n_audio_ctx = 400: 3.9 s windows, 0.9 s apart), greedy or beams -- more than 8 live rows,
+    i.e. split-K MFMA GEMMs, resolve-LN, the streaming (one beam) or chunked (beams) cross-attention, dec_topk_rows."""
+    d = int(rng.choice([128, 128, 384, 768]))
+    n_win = int(rng.integers(9, 17)) if d == 128 else int(rng.integers(9, 12))
+    secs = 3.9 + 0.9 * (n_win - 1) - float(rng.random()) * 0.8
+    return dict(d=d, layers=int(rng.integers(1, 3)) if d == 128 else 1, vocab=int(rng.choice([515, 1031, 2053])),
+                audio_ctx=400, text_ctx=int(rng.choice([16, 64, 448])), x2=0, ln_inside=int(rng.random() < 0.3),
+                samples=int(secs * 16000), aseed=int(rng.integers(0, 1 << 30)), wseed=int(rng.integers(0, 1 << 30)),
+                beam=int(rng.choice([1, 1, 1, 2, 3])), depth=int(rng.integers(1, 11)),
+                switches=str(rng.choice(["", "", "WHISPER_HIP_CROSS_STREAM=0", "WHISPER_HIP_CHAIN=0", "WHISPER_HIP_GRAPH=0"])))
+
+
 def draw(rng):
     d = int(rng.choice([128, 128, 384, 512, 768]))
     audio_ctx = int(rng.choice([400, 1500])) if d == 128 else 400     # (emulated MFMA: keep the encoder affordable)
@@ -111,6 +124,7 @@ def main():
     ap.add_argument("--minutes", type=float, default=10)
     ap.add_argument("--guard", action="store_true")
     ap.add_argument("--reverse", action="store_true")
+    ap.add_argument("--many-windows", action="store_true", help="batch-mode cases: 9-16 windows per clip")
     ap.add_argument("--log", default=None)
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
@@ -121,7 +135,7 @@ def main():
     log = open(args.log, "a") if args.log else None
     n = 0
     while time.time() < t_end:
-        cfg = draw(rng)
+        cfg = draw_many(rng) if args.many_windows else draw(rng)
         env = {k: v for k, v in os.environ.items() if not k.startswith("WHISPER_HIP_")}
         env.update(WHISPER_HIP_LIB=lib, WHISPER_HIP_ALLOW_EMU="1")
         if cfg["switches"]:
