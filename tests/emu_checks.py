@@ -60,6 +60,19 @@ def main(which):
         ref, rw = otr.waveform_to_tokens(o, pu.ost(st), a, 16000, 1, 10, return_windows=True)
         assert got == ref and wins == rw, (got, ref)
         assert len(set(got[4:])) >= 4                                   # not a degenerate sequence
+    elif which in ("chain_eot", "chain_eot_batch"):
+        # device-chained greedy decode whose windows end on <|endoftext|> at DIFFERENT steps: rows that have ended are
+        # marked dead in the step state (their attention blocks exit, a finished window streams no cached K/V, its
+        # token is frozen), the last finisher blanks ST_N while sibling blocks may not have started, and the host's
+        # flag wait ends through its "every window finished" branch.  4 windows: the fused small-batch kernels;
+        # 13 windows: batch mode (streaming cross-attention; WHISPER_HIP_CROSS_STREAM=0: chunked + combine).
+        n_s, seed = (16000 * 40, 23) if which == "chain_eot" else (16000 * 150, 29)
+        a = synth.synth_audio(n_s, seed)
+        got, wins = wb.waveform_to_tokens(eng, st, a, 16000, 1, 30)
+        ref, rw = otr.waveform_to_tokens(o, pu.ost(st), a, 16000, 1, 30, return_windows=True)
+        gen = [len(r) - 4 for r in rw]
+        assert wins == rw and got == ref, (wins, rw)
+        assert len(set(gen)) >= 3 and all(r[-1] == st.end_of_text for r in rw) and max(gen) < 30, gen
     elif which == "beam":
         a = synth.synth_audio(16000 * 2, 9)
         got, _ = wb.waveform_to_tokens(eng, st, a, 16000, 3, 6)

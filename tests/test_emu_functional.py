@@ -44,6 +44,15 @@ def test_kernel_sources_reproduce_the_oracle_under_the_functional_model(emu_lib,
     assert p.returncode == 0 and f"EMU_CHECK_OK {which}" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
+@pytest.mark.parametrize("which,env", [("chain_eot", {}), ("chain_eot", {"WHISPER_HIP_POLL": "0"}),
+                                       ("chain_eot_batch", {}), ("chain_eot_batch", {"WHISPER_HIP_CROSS_STREAM": "0"})])
+def test_chained_greedy_windows_ending_at_different_steps(emu_lib, which, env):
+    """Dead rows of the device-chained greedy loop (a window that ended on <|endoftext|> while others go on), the
+    last-finisher blanking of ST_N and the host's early exit, small-batch and batch mode."""
+    p = _run(emu_lib, which, env)
+    assert p.returncode == 0 and f"EMU_CHECK_OK {which}" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
 @pytest.mark.parametrize("d", [384, 768])
 def test_the_other_kernel_template_families(emu_lib, d):
     """d = 384 (the fused sublayer kernels of tiny.en; base.en's d = 512 instantiates the same templates) and 768

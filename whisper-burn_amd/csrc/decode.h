@@ -6,6 +6,7 @@
 
 #include <algorithm>
 
+#include "kernels.h"
 #include "wb_internal.h"
 
 namespace wb {
@@ -27,14 +28,16 @@ enum { GC_STEP = 0, GC_NDONE = 1, GC_ALLDONE = 2, GC_HDR = 4 };   // [1]: window
 struct StepLayout {
   int S = 0, W = 0;                                  // slot capacity, windows
   int tok = 0, parent = 0, len = 0, win = 0;         // offsets of int[S] arrays
+  int dead = 0;                                      // int[S]: 1 = this row's window already ended (chained greedy decode):
+                                                     // its attention blocks exit at once and stream no cached K/V
   int win_nb = 0, win_slots = 0;                     // int[W], int[W][MAX_BEAMS]
   int total = 0;
 };
 inline StepLayout make_step_layout(int S, int W) {
   StepLayout l;
   l.S = S; l.W = W;
-  l.tok = ST_HDR; l.parent = l.tok + S; l.len = l.parent + S; l.win = l.len + S;
-  l.win_nb = l.win + S; l.win_slots = l.win_nb + W; l.total = l.win_slots + W * MAX_BEAMS;
+  l.tok = ST_HDR; l.parent = l.tok + S; l.len = l.parent + S; l.win = l.len + S; l.dead = l.win + S;
+  l.win_nb = l.dead + S; l.win_slots = l.win_nb + W; l.total = l.win_slots + W * MAX_BEAMS;
   return l;
 }
 
@@ -92,24 +95,6 @@ void launch_dec_cross_attn(hipStream_t st, const int* state, const StepLayout& l
 void launch_dec_cross_attn_stream(hipStream_t st, const int* state, const StepLayout& lay, int n_windows, int n_head,
                                   const float* Pq, int KS, const float* bq, int d, const float* ckv, int ldkv, int koff,
                                   const int* win_row0, const int* win_C, float scale, float* att);
-// ---- per-kernel profiling (wb_profile_enable): the call site tags the NEXT launch of this thread with a kernel
-// class and its algorithmic bytes; the launcher hands the tag's start / stop events to the dispatch itself
-// (hipExtLaunchKernelGGL), so the elapsed time is that kernel's own begin -> end -- the quantity
-// `rocprofv3 --kernel-trace` reports.  With profiling off a tag costs one predictable branch.
-enum KernelClass {
-  KC_PREPARE = 0, KC_ATTN_FUSED, KC_CROSS_ATTN, KC_GEMV_COUT, KC_MLP_FUSED, KC_LOGITS, KC_TOPK_MERGE,
-  KC_GEMV_LN_QKV, KC_SELF_ATTN, KC_GEMV_OUT, KC_GEMV_LN_CQ, KC_GEMV_LN_MLP1, KC_GEMV_MLP2, KC_BATCH, KC_CROSS_FUSED, KC_COUNT
-};
-void prof_tag(int cls, double algo_bytes);
-bool prof_take_events(hipEvent_t* start, hipEvent_t* stop);
-#define WB_KLAUNCH(kernel, grid, block, shmem, stream, ...)                                        \
-  do {                                                                                             \
-    hipEvent_t _pa, _pb;                                                                           \
-    if (wb::prof_take_events(&_pa, &_pb))                                                          \
-      hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, _pa, _pb, 0, __VA_ARGS__);         \
-    else                                                                                           \
-      hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                         \
-  } while (0)
 // what the merge kernel needs to prepare the NEXT chained step (x == nullptr: it does not)
 struct NextPrep {
   float* x = nullptr;        // residual-stream rows [S][d] the next step starts from
@@ -128,7 +113,7 @@ void launch_dec_gelu_fold(hipStream_t st, const int* state, int n_max, const flo
                           const float* bias, float* out);
 void launch_dec_attn_combine(hipStream_t st, const int* state, int n_max, const float* ca, int n_head, int n_chunks,
                              float* out);
-void launch_dec_topk_rows(hipStream_t st, const int* state, int n_max, const float* logits, int V, const float* mask,
+void launch_dec_topk_rows(hipStream_t st, int* state, int n_max, const float* logits, int V, const float* mask,
                           int use_mask, int k, int32_t* out_id, float* out_lp, float* row_stats, const StepLayout& lay,
                           int* gctl, int* gtok, int Lmax, int eot);
 void launch_dec_logprob_row(hipStream_t st, const float* x, int KS, int64_t plane, int V, const float* mask,

@@ -88,7 +88,8 @@ __global__ void dec_prepare_kernel(const int* __restrict__ st_host, int* __restr
         else if (e >= lay.parent && e < lay.parent + n) v = e - lay.parent;
         else if (e >= lay.len && e < lay.len + n) v = len;
         else if (e >= lay.win && e < lay.win + n) v = e - lay.win;
-        else if (e >= lay.win_nb && e < lay.win_nb + n) v = 1;
+        else if (e >= lay.dead && e < lay.dead + n) v = gctl[GC_HDR + lay.S + (e - lay.dead)];
+        else if (e >= lay.win_nb && e < lay.win_nb + n) v = gctl[GC_HDR + lay.S + (e - lay.win_nb)] ? 0 : 1;   // a finished window streams no K/V
         else if (e >= lay.win_slots && (e - lay.win_slots) % MAX_BEAMS == 0 && (e - lay.win_slots) / MAX_BEAMS < n)
           v = (e - lay.win_slots) / MAX_BEAMS;
         st_dev[e] = v;
@@ -398,8 +399,10 @@ __global__ __launch_bounds__(256, (MR >= 8 && DPL >= 16) ? 1 : 2) void dec_gemv_
 // top-1 and the next step's embedding gather.
 __device__ __forceinline__ int chained_update(int* st, const StepLayout& lay, int* gctl, int* gtok, int Lmax,
                                               int eot, int r, int gi, int len, int finished, int step) {
-  gctl[GC_HDR + r] = gi;
   if (!finished) {
+    // (a finished row keeps its last token: its attention blocks no longer run, so its later "argmax" is computed
+    // from stale planes and must never become an embedding index)
+    gctl[GC_HDR + r] = gi;
     gtok[r * Lmax + len] = gi;
     gctl[GC_HDR + 2 * lay.S + r] = len + 1;
     if (gi == eot) {
@@ -420,8 +423,12 @@ __device__ __forceinline__ void chained_publish(int* hflags, int r, int finished
 // ---- merge the per-tile statistics of one beam's logits row: log_softmax + top-k ------------------
 // Device-chained greedy decode (gctl != nullptr) with `nx.x` set: the block of row r also PREPARES row r of the
 // next step (token + position embedding, position table, step state), which saves the prepare launch.
-// Cross-block hazards: every block only reads and writes its own row's state; ST_N never changes in a
-// chain; ST_STEP is read and written by block 0 only.
+// Cross-block hazards: every block only reads and writes its own row's state; ST_STEP is read and written by block 0
+// only.  ST_N is written by ONE block at most once per chain -- blanked to 0 by the block whose row is the LAST window
+// to finish (GC_NDONE == W) -- while sibling blocks of the same launch may still be reading it at kernel entry.  That is
+// benign by this invariant: a block that reads 0 instead of n belongs to a row that had ALREADY finished in an earlier
+// step (the last finisher itself read n), so the only thing it skips is a chained_update that would have been a no-op
+// and a host-flag publish the host does not wait for (wait_flags ends through its "every window finished" branch).
 __global__ __launch_bounds__(256) void dec_topk_merge_kernel(int* __restrict__ st, const float* __restrict__ tstats,
                                                              int n_tiles, int k, int32_t* __restrict__ out_id,
                                                              float* __restrict__ out_lp, float* __restrict__ row_stats,
@@ -434,6 +441,7 @@ __global__ __launch_bounds__(256) void dec_topk_merge_kernel(int* __restrict__ s
   const int n_live = st[ST_N], len_now = st[lay.len + r];      // requested together with the tile records below
   const int step_now = st[ST_STEP];
   const int fin_now = gctl ? gctl[GC_HDR + lay.S + r] : 0;
+  const int st_tok_now = st[lay.tok + r];
   const float* ts = tstats + (int64_t)r * n_tiles * TS_STRIDE;
   // Ordinary vocabularies give <= 512 tiles: each thread pulls the whole record of its (at most) two tiles -- max,
   // sum-exp and the k candidates -- in ONE batch of loads, so the row costs one global round trip instead of three
@@ -543,16 +551,18 @@ __global__ __launch_bounds__(256) void dec_topk_merge_kernel(int* __restrict__ s
     // next step of the chain: position len_now (0-based) holds token `first`
     __syncthreads();                       // chained_update (thread 0) has read this row's state
     const int step = len_now - 1, nstep = step + 1;
+    const int tok_next_w = fin_now ? st_tok_now : first;
     if (tid == 0) {
-      st[lay.tok + r] = first;
+      st[lay.tok + r] = tok_next_w;
       st[lay.len + r] = len_now + 1;
+      st[lay.dead + r] = (fin_now || first == eot) ? 1 : 0;          // = chained_update's `finished` for this row
       if (r == 0) st[ST_STEP] = nstep;
     }
     int* tab_new = nx.tabs + (size_t)(nstep & 1) * lay.S * Lmax;
     const int* tab_old = nx.tabs + (size_t)((nstep & 1) ^ 1) * lay.S * Lmax;
     for (int p = tid; p < len_now; p += 256) tab_new[r * Lmax + p] = tab_old[r * Lmax + p];
     if (tid == 0) tab_new[r * Lmax + len_now] = nstep * lay.S + r;
-    const float4* e = reinterpret_cast<const float4*>(nx.E + (int64_t)first * nx.d);
+    const float4* e = reinterpret_cast<const float4*>(nx.E + (int64_t)tok_next_w * nx.d);
     const float4* pp = reinterpret_cast<const float4*>(nx.pos + (int64_t)len_now * nx.d);
     float4* o = reinterpret_cast<float4*>(nx.x + (int64_t)r * nx.d);
     for (int c = tid; c < (nx.d >> 2); c += 256) {
@@ -576,7 +586,7 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const int* __restric
   __shared__ float red[8];
   __shared__ float ored[4][64];
   const int i = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (i >= st[ST_N]) return;
+  if (i >= st[ST_N] || st[lay.dead + i]) return;   // (dead: a chained row whose window has ended)
   const int len = st[lay.len + i];
   const int* tb = tabs + (size_t)(st[ST_STEP] & 1) * lay.S * Lmax + i * Lmax;
   for (int p = tid; p < len; p += 256) tbs[p] = tb[p];
@@ -1050,7 +1060,7 @@ __global__ void dec_attn_combine_kernel(const int* __restrict__ st, const float*
 }
 
 // mask + log_softmax + top-k of one beam's full logits row (batch mode; transcribe.rs:271-304)
-__global__ __launch_bounds__(1024) void dec_topk_rows_kernel(const int* __restrict__ st, const float* __restrict__ logits,
+__global__ __launch_bounds__(1024) void dec_topk_rows_kernel(int* __restrict__ st, const float* __restrict__ logits,
                                                               int V, const float* __restrict__ mask, int use_mask,
                                                               int k, int32_t* __restrict__ out_id,
                                                               float* __restrict__ out_lp, float* __restrict__ row_stats,
@@ -1114,7 +1124,7 @@ __global__ __launch_bounds__(1024) void dec_topk_rows_kernel(const int* __restri
       out_id[r * TOPK_MAX + round] = gi;
       out_lp[r * TOPK_MAX + round] = (gv - M) - lse;
       if (gctl && round == 0)
-        chained_update(const_cast<int*>(st), lay, gctl, gtok, Lmax, eot, r, gi, st[lay.len + r], gctl[GC_HDR + lay.S + r], st[ST_STEP]);
+        chained_update(st, lay, gctl, gtok, Lmax, eot, r, gi, st[lay.len + r], gctl[GC_HDR + lay.S + r], st[ST_STEP]);
     }
     if (ti[0] == gi) {
 #pragma unroll
@@ -1263,7 +1273,7 @@ void launch_dec_attn_combine(hipStream_t st, const int* state, int n_max, const 
   WB_KLAUNCH(dec_attn_combine_kernel, dim3((n_head * 64 + 255) / 256, n_max), dim3(256), 0, st, state, ca, n_head,
                      n_chunks, out);
 }
-void launch_dec_topk_rows(hipStream_t st, const int* state, int n_max, const float* logits, int V, const float* mask,
+void launch_dec_topk_rows(hipStream_t st, int* state, int n_max, const float* logits, int V, const float* mask,
                           int use_mask, int k, int32_t* out_id, float* out_lp, float* row_stats, const StepLayout& lay,
                           int* gctl, int* gtok, int Lmax, int eot) {
   WB_KLAUNCH(dec_topk_rows_kernel, dim3(n_max), dim3(1024), 0, st, state, logits, V, mask, use_mask, k, out_id,

@@ -409,6 +409,7 @@ __global__ __launch_bounds__(512) void dec_attn_fused_kernel(AttnFusedArgs a) {
   if (h >= a.n_head) return;
   // the row's state words first: the position table, and through it the cached K / V addresses, hang on them
   const int n_rows = a.st[ST_N], len = a.st[a.lay.len + r], step_par = a.st[ST_STEP] & 1;
+  const int dead = a.st[a.lay.dead + r];           // chained greedy decode: this row's window has already ended
   // ---- then, in this order (loads return in order: the fold must not queue behind the weights): the fold
   // operands of row r, LayerNorm parameters (wave 0 normalises), bias, then two QKV weight rounds.
   // No global STORE happens before the last phase: a pending store turns every __syncthreads into vmcnt(0).
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(512) void dec_attn_fused_kernel(AttnFusedArgs a) {
     }
     load_round(wr[0], 0);
     if (NIT > 1) load_round(wr[1], 1);
-    if (r >= n_rows) return;                       // (block-uniform; the first wait of the kernel)
+    if (r >= n_rows || dead) return;               // (block-uniform; the first wait of the kernel)
     if (a.KSp > 0) {
 #pragma unroll
       for (int j = 0; j < FP; j++) accp += (j < a.KSp) ? t[j] : 0.f;
@@ -666,6 +667,7 @@ __global__ __launch_bounds__(512) void dec_cross_fused_kernel(CrossFusedArgs a) 
   const int h = blockIdx.x, r = blockIdx.y;
   if (h >= a.n_head) return;
   const int n_live = a.st[ST_N], w_row = a.st[a.lay.win + r];
+  const int dead = a.st[a.lay.dead + r];           // chained greedy decode: this row's window has already ended
   // the window geometry of the first 8 windows rides with the state words -- as VECTOR loads (lane i holds window i; a
   // scalar load here would stall the next kernel-argument wait, lgkmcnt being one counter): the K stream can then start
   // one round trip after kernel entry instead of two (row -> window -> geometry)
@@ -698,7 +700,7 @@ __global__ __launch_bounds__(512) void dec_cross_fused_kernel(CrossFusedArgs a) 
 #pragma unroll
       for (int i = 0; i < NWQ; i++) wqr[i] = *reinterpret_cast<const float4*>(wp + (int64_t)(32 * i) * d);
     }
-    if (r >= n_live) return;                       // (block-uniform; the first wait of the kernel)
+    if (r >= n_live || dead) return;               // (block-uniform; the first wait of the kernel)
     if (a.KSp > 0) {
 #pragma unroll
       for (int j = 0; j < FP; j++) accp += (j < a.KSp) ? t[j] : 0.f;

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
 template <int BM, int BN, int WGM, int WGN, int AMODE, int BK = 16, int PF = 1>
 void launch_cfg(hipStream_t st, const GemmArgs& a) {
   dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.ksplit > 1 ? a.ksplit : 1);
-  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WGM, WGN, AMODE, BK, PF>), grid, dim3(NT), 0, st, a);
+  WB_KLAUNCH((gemm_f32_kernel<BM, BN, WGM, WGN, AMODE, BK, PF>), grid, dim3(NT), 0, st, a);
 }
 
 #ifdef WB_GEMM_PROBE

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs g, const u16* __
 template <int BM, int BN, int WGM, int WGN>
 void launch_cfg(hipStream_t st, const GemmArgs& a, const u16* Wt, int ldwt) {
   dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.ksplit > 1 ? a.ksplit : 1);
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN>), grid, dim3(NT), 0, st, a, Wt, ldwt);
+  WB_KLAUNCH((gemm_bf16_kernel<BM, BN, WGM, WGN>), grid, dim3(NT), 0, st, a, Wt, ldwt);
 }
 
 }  // namespace

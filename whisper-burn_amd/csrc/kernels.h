@@ -1,9 +1,34 @@
 // Host-callable launchers of the gfx950 kernels (defined in the .hip files).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 namespace wb {
+
+// ---- per-kernel profiling (wb_profile_enable): the call site tags the NEXT launch of this thread with a kernel
+// class and its algorithmic bytes; the launcher hands the tag's start / stop events to the dispatch itself
+// (hipExtLaunchKernelGGL), so the elapsed time is that kernel's own begin -> end -- the quantity
+// `rocprofv3 --kernel-trace` reports.  With profiling off a tag costs one predictable branch.
+enum KernelClass {
+  KC_PREPARE = 0, KC_ATTN_FUSED, KC_CROSS_ATTN, KC_GEMV_COUT, KC_MLP_FUSED, KC_LOGITS, KC_TOPK_MERGE,
+  KC_GEMV_LN_QKV, KC_SELF_ATTN, KC_GEMV_OUT, KC_GEMV_LN_CQ, KC_GEMV_LN_MLP1, KC_GEMV_MLP2, KC_CROSS_FUSED,
+  // batch mode (more than 8 live rows): one class per kernel of the per-layer chain
+  KC_B_RESOLVE_LN, KC_B_GEMM, KC_B_SELF_ATTN, KC_B_CROSS_STREAM, KC_B_CROSS_CHUNK, KC_B_COMBINE, KC_B_GELU_FOLD,
+  KC_B_LOGITS_GEMM, KC_B_TOPK_ROWS, KC_PERSIST,
+  KC_COUNT
+};
+void prof_tag(int cls, double algo_bytes);
+bool prof_take_events(hipEvent_t* start, hipEvent_t* stop);
+#define WB_KLAUNCH(kernel, grid, block, shmem, stream, ...)                                        \
+  do {                                                                                             \
+    hipEvent_t _pa, _pb;                                                                           \
+    if (wb::prof_take_events(&_pa, &_pb))                                                          \
+      hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, _pa, _pb, 0, __VA_ARGS__);         \
+    else                                                                                           \
+      hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                         \
+  } while (0)
+
 
 // ---- mel frontend (mel.hip) ---------------------------------------------------------
 constexpr int MEL_N_FFT = 400, MEL_HOP = 160, MEL_N_MELS = 80, MEL_N_BINS = 201, MEL_MAX_TAPS = 16;

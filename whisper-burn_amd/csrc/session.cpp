@@ -28,8 +28,11 @@ static const char* const g_kernel_names[KC_COUNT] = {
     "dec_prepare", "dec_attn_fused (LN + QKV + self-attention + out-proj)", "dec_cross_attn (LN + Wq + cross-attention)",
     "dec_gemv cross-attn out-proj", "dec_mlp_fused (LN + lin1 + GELU + lin2)", "dec_gemv logits (LN + E^T + tile stats)",
     "dec_topk_merge", "dec_gemv LN + QKV", "dec_self_attn", "dec_gemv self-attn out-proj", "dec_gemv LN + Wq",
-    "dec_gemv LN + lin1", "dec_gemv GELU + lin2", "batch-mode decode kernels",
-    "dec_cross_fused (LN + Wq + cross-attention + out-proj)"};
+    "dec_gemv LN + lin1", "dec_gemv GELU + lin2", "dec_cross_fused (LN + Wq + cross-attention + out-proj)",
+    "batch: dec_resolve_ln (fold + LayerNorm)", "batch: split-K MFMA GEMM (decoder weight stream)",
+    "batch: dec_self_attn (paged self-KV)", "batch: dec_cross_attn_stream (cached K/V stream)",
+    "batch: dec_cross_attn chunked (cached K/V, beams)", "batch: dec_attn_combine", "batch: dec_gelu_fold",
+    "batch: logits MFMA GEMM (E^T stream)", "batch: dec_topk_rows", "dec_persist (flag-chained decode steps)"};
 struct PendingLaunch { hipEvent_t a, b; int cls; double bytes; };
 static std::mutex g_prof_mu;
 static std::vector<PendingLaunch> g_pending;
@@ -45,6 +48,11 @@ void prof_tag(int cls, double algo_bytes) {
     g_pending.push_back(PendingLaunch{a, b, cls, algo_bytes});
   }
   tl_ev_a = a; tl_ev_b = b;
+}
+void prof_adjust_bytes(int cls, double delta) {
+  if (!profile().on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_kstats[cls].bytes += delta;
 }
 bool prof_take_events(hipEvent_t* start, hipEvent_t* stop) {
   if (!tl_ev_a) return false;
@@ -413,7 +421,7 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
   const double wsz = m->compute_dtype == WB_BF16 ? 2.0 : 4.0, dd = (double)d * d;
   double ckv_bytes = 0;
   for (int c : s->C) ckv_bytes += 8.0 * c * d;                    // K and V rows of one layer, f32
-  const double self_kv_bytes = 8.0 * (double)n * (s->step + 1) * d;
+  const double self_kv_bytes = 8.0 * (double)n * (s->step + s->prof_step_off + 1) * d;
 
   int* gctl = chained ? s->gctl.as<int>() : nullptr;
   // chained small-batch steps: the previous step's merge kernel already prepared this one (the chain's
@@ -446,7 +454,13 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
       GemmArgs g;
       g.A = A; g.lda = w.k; g.B = w.w; g.ldb = w.n; g.C = P; g.ldc = w.n; g.M = n; g.N = w.n; g.K = w.k;
       g.ksplit = ks; g.c_split_stride = (int64_t)S * w.n;
+      prof_tag(KC_B_GEMM, wsz * (double)w.k * w.n + 4.0 * n * ((double)w.k + (double)ks * w.n));
       return gemm_dispatch(m, st, g, w.wt, w.k);
+    };
+    auto resolve = [&](const float* pend, int ks_pend, const float* pbias, const LayerNormW& ln) {
+      prof_tag(KC_B_RESOLVE_LN, 4.0 * n * d * (ks_pend + 3));
+      launch_dec_resolve_ln(st, dst, n, xb[xi], xb[xi ^ 1], pend, ks_pend, S, pbias, d, ln, m->ln_eps_inside_sqrt, h);
+      xi ^= 1;
     };
     const float* pend = nullptr; int ks_pend = 0; const float* pbias = nullptr;
     // one beam per window (greedy over many windows): one block per (head, window) streams the whole cached K/V and
@@ -456,47 +470,53 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
     const bool cross_stream = cross_stream_enabled && max_nb <= 1;
     for (int l = 0; l < NL; l++) {
       const DecBlockW& b = m->dec[l];
-      launch_dec_resolve_ln(st, dst, n, xb[xi], xb[xi ^ 1], pend, ks_pend, S, pbias, d, b.ln1, m->ln_eps_inside_sqrt, h);
-      xi ^= 1;
+      resolve(pend, ks_pend, pbias, b.ln1);
       WB_TRY(big(b.qkv, s->ks_qkv, h, s->Pqkv.as<float>()));
+      prof_tag(KC_B_SELF_ATTN, self_kv_bytes + 4.0 * n * 3 * d * s->ks_qkv);
+      s->prof_cls_self = KC_B_SELF_ATTN;
       launch_dec_self_attn(st, dst, L, n, H, s->Pqkv.as<float>(), s->ks_qkv, b.qkv.b, d,
                            s->kc.as<float>() + (size_t)l * pool * d, s->vc.as<float>() + (size_t)l * pool * d, tabs,
                            s->Lmax, m->qk_scale, att);
       WB_TRY(big(b.out, s->ks_o, att, s->Po.as<float>()));
-      launch_dec_resolve_ln(st, dst, n, xb[xi], xb[xi ^ 1], s->Po.as<float>(), s->ks_o, S, b.out.b, d, b.ln2,
-                            m->ln_eps_inside_sqrt, h);
-      xi ^= 1;
+      resolve(s->Po.as<float>(), s->ks_o, b.out.b, b.ln2);
       WB_TRY(big(b.cq, s->ks_o, h, s->Pq.as<float>()));
       if (cross_stream) {
+        prof_tag(KC_B_CROSS_STREAM, ckv_bytes + 4.0 * n * d * (s->ks_o + 1));
+        s->prof_cls_cross = KC_B_CROSS_STREAM;
         launch_dec_cross_attn_stream(st, dst, L, s->W, H, s->Pq.as<float>(), s->ks_o, b.cq.b, d, s->ckv.as<float>(), ldkv,
                                      l * 2 * d, win_row0, win_C, m->qk_scale, att);
       } else {
+        prof_tag(KC_B_CROSS_CHUNK, ckv_bytes + 4.0 * n * d * s->ks_o);
+        s->prof_cls_cross = KC_B_CROSS_CHUNK;
         launch_dec_cross_attn(st, dst, L, s->W, H, s->n_chunks, s->Pq.as<float>(), s->ks_o, b.cq.b, d, s->ckv.as<float>(),
                               ldkv, l * 2 * d, win_row0, win_C, m->qk_scale, s->ca.as<float>(), max_nb);
+        prof_tag(KC_B_COMBINE, 4.0 * n * H * s->n_chunks * CA_STRIDE);
         launch_dec_attn_combine(st, dst, n, s->ca.as<float>(), H, s->n_chunks, att);
       }
       WB_TRY(big(b.cout, s->ks_o, att, s->Po.as<float>()));
-      launch_dec_resolve_ln(st, dst, n, xb[xi], xb[xi ^ 1], s->Po.as<float>(), s->ks_o, S, b.cout.b, d, b.ln3,
-                            m->ln_eps_inside_sqrt, h);
-      xi ^= 1;
+      resolve(s->Po.as<float>(), s->ks_o, b.cout.b, b.ln3);
       WB_TRY(big(b.mlp1, s->ks_1, h, s->P1.as<float>()));
+      prof_tag(KC_B_GELU_FOLD, 4.0 * n * 4 * d * (s->ks_1 + 1));
       launch_dec_gelu_fold(st, dst, n, s->P1.as<float>(), s->ks_1, S, 4 * d, b.mlp1.b, hm);
       WB_TRY(big(b.mlp2, s->ks_2, hm, s->P2.as<float>()));
       pend = s->P2.as<float>(); ks_pend = s->ks_2; pbias = b.mlp2.b;
     }
     if (k > 0) {
-      launch_dec_resolve_ln(st, dst, n, xb[xi], xb[xi ^ 1], pend, ks_pend, S, pbias, d, m->ln_dec, m->ln_eps_inside_sqrt, h);
+      resolve(pend, ks_pend, pbias, m->ln_dec);
       ScopedTimer tm_logits(st, 6);
       GemmArgs g;
       g.A = h; g.lda = d; g.B = m->tok_emb_t; g.ldb = m->vocab_ld; g.C = s->logits.as<float>(); g.ldc = V;
       g.M = n; g.N = V; g.K = d;
+      prof_tag(KC_B_LOGITS_GEMM, wsz * (double)V * d + 4.0 * n * ((double)d + V));
       WB_TRY(gemm_dispatch(m, st, g, m->tok_emb_bf, d));
       tm_logits.stop();
-      launch_dec_topk_rows(st, dst, n, s->logits.as<float>(), V, s->mask.as<float>(), use_mask, k, out_id_dev,
+      prof_tag(KC_B_TOPK_ROWS, 4.0 * (double)n * V);
+      launch_dec_topk_rows(st, s->state.as<int>(), n, s->logits.as<float>(), V, s->mask.as<float>(), use_mask, k, out_id_dev,
                            out_lp_dev, s->row_stats.as<float>(), L, gctl, s->gtok.as<int>(), s->Lmax, eot);
       if (timed && tm_logits.on) {
         WB_HIP(hipStreamSynchronize(st));
         tm_logits.collect();
+        prof_collect();
         profile().ms[7] += 1;
       }
     }
@@ -536,6 +556,7 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
       fa.Kc = s->kc.as<float>() + (size_t)l * pool * d; fa.Vc = s->vc.as<float>() + (size_t)l * pool * d;
       fa.tabs = tabs; fa.Lmax = s->Lmax; fa.Wo = b.out.w; fa.P = s->Pa.as<float>();
       prof_tag(KC_ATTN_FUSED, 4.0 * dd * 4 + self_kv_bytes);
+      s->prof_cls_self = KC_ATTN_FUSED;
       launch_dec_attn_fused(st, fa, n);
       xi ^= 1;
       att_planes = s->Pa.as<float>(); att_ks = H;
@@ -543,6 +564,7 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
       prof_tag(KC_GEMV_LN_QKV, wsz * dd * 3);
       ln_gemv(gemv(b.qkv, s->ks_qkv, s->ksl_qkv, PRO_PLAIN, nullptr, d, s->Pqkv.as<float>()), pend_a, ks_a, pb_a, b.ln1, false);
       prof_tag(KC_SELF_ATTN, self_kv_bytes);
+      s->prof_cls_self = KC_SELF_ATTN;
       launch_dec_self_attn(st, dst, L, n, H, s->Pqkv.as<float>(), s->ks_qkv, b.qkv.b, d,
                            s->kc.as<float>() + (size_t)l * pool * d, s->vc.as<float>() + (size_t)l * pool * d, tabs,
                            s->Lmax, m->qk_scale, att);
@@ -559,6 +581,7 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
       ca.ckv = s->ckv.as<float>(); ca.ldkv = ldkv; ca.koff = l * 2 * d; ca.win_row0 = win_row0; ca.win_C = win_C;
       ca.Wo = b.cout.w; ca.P = s->Pc.as<float>();
       prof_tag(KC_CROSS_FUSED, ckv_bytes + 4.0 * dd * 2);
+      s->prof_cls_cross = KC_CROSS_FUSED;
       launch_dec_cross_fused(st, ca, n);
       xi ^= 1;
     } else if (fuse_q) {
@@ -569,6 +592,7 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
       fz.Wq = b.cq.w;
       if (fuse_co) { fz.Wo = b.cout.w; fz.rec = s->carec.as<float>(); }
       prof_tag(KC_CROSS_ATTN, ckv_bytes + 4.0 * dd * (fuse_co ? 2 : 1));
+      s->prof_cls_cross = KC_CROSS_ATTN;
       launch_dec_cross_attn(st, dst, L, s->W, H, s->n_chunks, nullptr, 0, b.cq.b, d, s->ckv.as<float>(), ldkv,
                             l * 2 * d, win_row0, win_C, m->qk_scale, s->ca.as<float>(), max_nb, &fz);
       xi ^= 1;
@@ -577,6 +601,7 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
       ln_gemv(gemv(b.cq, s->ks_o, s->ksl_o, PRO_PLAIN, nullptr, d, s->Pq.as<float>()), att_planes, att_ks, b.out.b, b.ln2,
               false);
       prof_tag(KC_CROSS_ATTN, ckv_bytes);
+      s->prof_cls_cross = KC_CROSS_ATTN;
       launch_dec_cross_attn(st, dst, L, s->W, H, s->n_chunks, s->Pq.as<float>(), s->ks_o, b.cq.b, d,
                             s->ckv.as<float>(), ldkv, l * 2 * d, win_row0, win_C, m->qk_scale, s->ca.as<float>(), max_nb);
     }
@@ -643,7 +668,10 @@ static int launch_step(wb_session* s, int n_launch, int k, int use_mask, bool fu
   wb_model* m = s->m;
   hipStream_t st = s->st;
   if (!use_graph) {
-    for (int i = 0; i < reps; i++) WB_TRY(enqueue_step(s, n_launch, k, use_mask, fuse_ln, max_nb, true, chained, eot));
+    for (int i = 0; i < reps; i++) {
+      WB_TRY(enqueue_step(s, n_launch, k, use_mask, fuse_ln, max_nb, true, chained, eot));
+      if (chained) s->prof_step_off++;
+    }
     return WB_OK;
   }
   // graphs bake in buffer addresses and launch geometry: drop them if anything moved since capture
@@ -846,6 +874,20 @@ int session_greedy_chain(wb_session* s, int first_token, int eot, int max_depth,
     for (int p = prompt_len; p < len; p++) out_tokens[(size_t)w * row_stride + p] = toks[(size_t)w * s->Lmax + p];
     out_lens[w] = len;
   }
+  if (profile().on && s->prof_cls_cross >= 0 && s->prof_cls_self >= 0) {
+    // The tags counted every launched row's cached K/V.  A row whose window had already ended is marked dead in the
+    // step state: its attention blocks exit at their first wait and stream nothing -- take those bytes back, so that
+    // the reported algorithmic bytes are the NECESSARY ones.
+    const int dm = m->dims.n_text_state, NL = m->dims.n_text_layer;
+    double dead_ckv = 0, dead_self = 0;
+    for (int w = 0; w < W; w++) {
+      const int live = std::max(0, std::min(out_lens[w] - prompt_len, depth));   // steps in which row w was live
+      for (int t = live; t < depth; t++) { dead_ckv += 8.0 * s->C[w] * dm; dead_self += 8.0 * (s->step + t + 1) * dm; }
+    }
+    prof_adjust_bytes(s->prof_cls_cross, -(double)NL * dead_ckv);
+    prof_adjust_bytes(s->prof_cls_self, -(double)NL * dead_self);
+  }
+  s->prof_step_off = 0;
   s->step += depth;
   s->prev_len.assign(W, s->step);
   s->last_had_logits = 0;

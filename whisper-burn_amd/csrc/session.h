@@ -36,6 +36,9 @@ struct wb_session {
   int prev_n = 0, step = 0;
   bool has_mask = false, decode_ready = false;
   int last_use_mask = 0, last_had_logits = 0;
+  // profiling only: which kernel classes carried the per-row cached K/V bytes of the last enqueued step, and how many
+  // chained steps were enqueued since s->step was last advanced (the chained loop advances it once, at its end)
+  int prof_cls_cross = -1, prof_cls_self = -1, prof_step_off = 0;
   std::unordered_map<uint64_t, hipGraphExec_t> graphs;   // captured decode steps, keyed by launch shape
   uint64_t buf_sig = 0;                                  // signature of the buffers the graphs were captured with
   void clear_graphs();
@@ -51,6 +54,7 @@ struct Profile {
 Profile& profile();
 // per-kernel-class accumulators of the tagged launches (decode.h: prof_tag / WB_KLAUNCH)
 struct KernelStat { int64_t calls = 0; double ms = 0, bytes = 0; };
+void prof_adjust_bytes(int cls, double delta);   // correct a class's algorithmic bytes after the fact (dead rows)
 void prof_collect();          // after the stream was synchronised: fold the pending tagged launches into the stats
 // Timed region helper: records two events on `st` and adds the elapsed ms to slot `i` (when profiling is on).
 struct ScopedTimer {
