@@ -179,7 +179,12 @@ pub fn waveform_to_text<T: Tokenizer>(whisper: &Whisper, bpe: &T, lang: T::Lang,
     p.tok_transcribe = id(SpecialToken::Transcribe)?;
     p.tok_no_timestamps = id(SpecialToken::NoTimeStamps)?;
     p.tok_end_of_text = id(SpecialToken::EndofText)?;
-    // transcribe.rs:243-251 builds this mask per window (51 864 decodes each time); it is hoisted here
+    // transcribe.rs:243-251 builds this mask per window (51 864 decodes each time); it is hoisted here.  The reference adds
+    // a [vocab_size] mask to [.., n_vocab] logits and panics on a tokenizer / checkpoint mismatch: same contract
+    if bpe.vocab_size() != whisper.dims.n_vocab as usize {
+        return Err(format!("tokenizer vocabulary ({}) and model vocabulary ({}) differ", bpe.vocab_size(),
+                           whisper.dims.n_vocab).into());
+    }
     let is_special: Vec<u8> = (0..whisper.dims.n_vocab as usize).map(|t| bpe.is_special(t) as u8).collect();
     let wlen = max_waveform_samples(whisper.encoder_ctx_size() - p.padding as usize) as i64; // transcribe.rs:32-34
     let n_win = unsafe {

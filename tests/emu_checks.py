@@ -73,6 +73,41 @@ def main(which):
         gen = [len(r) - 4 for r in rw]
         assert wins == rw and got == ref, (wins, rw)
         assert len(set(gen)) >= 3 and all(r[-1] == st.end_of_text for r in rw) and max(gen) < 30, gen
+    elif which == "pool":
+        # a session that outlives its model: model A is freed, model B (same architecture, other weights) is loaded --
+        # its handle may reuse A's heap address -- then A's leftover session is released and B decodes.  The session
+        # pool is keyed by a never-reused model id, so A's session (captured graphs over A's freed weights) must not be
+        # handed to B.
+        a = synth.synth_audio(16000 * 3, 7)
+        starts, lens = wb.window_extents(len(a), 16000, wb.max_waveform_samples(1490))
+        for trial in range(4):
+            ea = wb.Whisper.from_tensors(w)
+            sa = wb.Session.begin(ea, a, starts, lens, max_beams=1)
+            sa.set_special_mask(st.is_special)
+            sa.decode(wb.decode_params(st, 1, 6))             # captures the decode graphs over A's buffers
+            ea.close()                                        # model first ...
+            w2 = synth.synth_weights(dims, seed=777 + trial)
+            eb, ob = wb.Whisper.from_tensors(w2), OracleWhisper(w2)
+            sa.close()                                        # ... then its session
+            got, _ = wb.waveform_to_tokens(eb, st, a, 16000, 1, 6)
+            assert got == otr.waveform_to_tokens(ob, pu.ost(st), a, 16000, 1, 6), trial
+            eb.close()
+    elif which == "bigpad":
+        # padding above 1536 frames with short windows (allowed below max_mel_frames = 3000 with the opt-in geometry):
+        # the mel grid is wider than the per-window (max, min) table, whose padding-only tiles must not be written
+        e2, o2 = wb.Whisper.from_tensors(w), OracleWhisper(w, frame_limit_x2=True)
+        e2.set_frame_limit(True)
+        pad = 1700
+        a = synth.synth_audio(16000 * 5, 43)
+        starts, lens = np.array([0, 30000], np.int64), np.array([24000, 50000], np.int64)
+        sess = wb.Session.begin(e2, a, starts, lens, max_beams=1, padding=pad)
+        sess.set_special_mask(st.is_special)
+        rows = sess.decode(wb.decode_params(st, 1, 6, padding=pad))
+        for wi in range(2):
+            mel = omel.prep_audio(torch.from_numpy(a[starts[wi]:starts[wi] + lens[wi]])[None])
+            ref = otr.mels_to_tokens(o2, pu.ost(st), mel, pad, 1, 6)
+            assert rows[wi] == ref, (wi, rows[wi], ref)
+        sess.close(); e2.close()
     elif which == "beam":
         a = synth.synth_audio(16000 * 2, 9)
         got, _ = wb.waveform_to_tokens(eng, st, a, 16000, 3, 6)

@@ -38,7 +38,7 @@ def _run(emu_lib, which, extra_env=None, allow=True):
                           capture_output=True, text=True, timeout=300)
 
 
-@pytest.mark.parametrize("which", ["mel", "greedy", "beam", "forward", "geometry", "prompted"])
+@pytest.mark.parametrize("which", ["mel", "greedy", "beam", "forward", "geometry", "prompted", "pool", "bigpad"])
 def test_kernel_sources_reproduce_the_oracle_under_the_functional_model(emu_lib, which):
     p = _run(emu_lib, which)
     assert p.returncode == 0 and f"EMU_CHECK_OK {which}" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]

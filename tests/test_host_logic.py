@@ -300,3 +300,17 @@ def test_cpu_baseline_leg_of_the_bench_runs_without_a_gpu():
     s = r["stages_s"]
     assert abs(s["mel"] + s["encoder"] + s["decode"] - s["total"]) < 2e-3 and s["decode"] > 0
     assert "1 window (3.9 s" in r["sample"]
+
+
+def test_special_mask_length_is_checked_before_it_reaches_c():
+    """A tokenizer whose vocabulary is smaller than the model's would make the C side read past the mask buffer
+    (it reads n_vocab bytes); the reference panics on that shape mismatch (transcribe.rs:243-275)."""
+    import types
+
+    from whisper_burn_amd import model as wm
+    fake = types.SimpleNamespace(dims={"n_vocab": 100})
+    assert wm.special_mask_bytes(fake, np.zeros(100, np.uint8)).shape == (100,)
+    for n in (99, 101, 0):
+        with pytest.raises(wm.WbError) as ei:
+            wm.special_mask_bytes(fake, np.zeros(n, np.uint8))
+        assert ei.value.status == wm.WB_ERR_SHAPE

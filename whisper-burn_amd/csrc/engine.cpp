@@ -78,6 +78,7 @@ int run_encoder(wb_model* m, hipStream_t st, Workspace& ws, const MelBatch& mb, 
   const bool same_geom = ws.enc_T == mb.T && ws.enc_win_stride == mb.win_stride && ws.enc_row_stride == mb.row_stride &&
                          ws.enc_d == d && ws.desc1.p && ws.desc2.p && ws.auxidx.p && ws.segs.p;
   if (!same_geom) {
+  ws.enc_T.clear(); ws.enc_d = -1;    // the key names the device contents: void it BEFORE they change, set it after the sync
   std::vector<RowDesc> d1(rows1), d2(rows2);
   std::vector<int32_t> aidx(rows2);
   std::vector<AttnSeg> segs(nw);

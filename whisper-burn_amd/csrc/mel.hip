@@ -118,8 +118,9 @@ __global__ __launch_bounds__(MEL_THREADS, 4) void mel_spectrogram_kernel(
   const int tid = threadIdx.x;
   const int zend = min(w.n_emit + pad, pad_limit);            // frames [n_emit, zend) := 0  (transcribe.rs:171-177)
   if (f0 >= w.n_frames) {
-    // past the last frame: at most the zero padding frames fall into this tile
-    if (tid == 0) { gmax[((int64_t)blockIdx.y * bmax_stride + blockIdx.x) * 2] = -INFINITY; gmax[((int64_t)blockIdx.y * bmax_stride + blockIdx.x) * 2 + 1] = INFINITY; }
+    // past the last frame: at most the zero padding frames fall into this tile.  No (max, min) pair is written: the
+    // fix-up pass only reads the tiles that hold real frames (blk < ceil(n_frames / FPB)), and with a large padding the
+    // grid may be wider than the per-window stride of `gmax` (a pair written here could land in the next window's slots).
     float* oz = out + (int64_t)blockIdx.y * win_stride;
     for (int e = tid; e < MEL_N_MELS * FPB; e += MEL_THREADS) {
       const int m = e / FPB, f = f0 + (e - m * FPB);
@@ -389,7 +390,7 @@ __global__ void fill_f32_kernel(float* p, int64_t n, float v) {
 
 }  // namespace
 
-int mel_bmax_stride(int max_frames) { return (max_frames + FPB - 1) / FPB + 48; }   // (+48: tiles that hold padding frames only)
+int mel_bmax_stride(int max_frames) { return (max_frames + FPB - 1) / FPB; }   // one (max, min) pair per tile with real frames
 
 void launch_mel_spectrogram(hipStream_t st, const float* pcm, const MelWindow* wins_dev, int n_windows,
                             int max_frames, const MelTables* tabs_dev, float* out, int64_t win_stride,

@@ -85,13 +85,15 @@ ScopedTimer::~ScopedTimer() {
 // g_pool has an entry for exactly the models that are alive: a session released after its model was freed is
 // destroyed instead of being parked under a dangling key, and a pooled session never outlives its model.
 static std::mutex g_pool_mu;
-static std::unordered_map<wb_model*, std::vector<wb_session*>> g_pool;
+static std::unordered_map<uint64_t, std::vector<wb_session*>> g_pool;   // by wb_model::uid (never reused), not by address
+static uint64_t g_next_model_uid = 1;
 constexpr size_t POOL_MAX_SESSIONS = 8;
 constexpr size_t POOL_MAX_BYTES = (size_t)4 << 30;   // per model: big batches (large-v2 x 64 windows ~ 20 GB) are not parked
 
 void session_pool_register(wb_model* m) {
   std::lock_guard<std::mutex> lk(g_pool_mu);
-  g_pool[m];
+  m->uid = g_next_model_uid++;
+  g_pool[m->uid];
 }
 
 // wb_model_free: pooled sessions of that model die with it
@@ -99,7 +101,7 @@ void session_pool_purge(wb_model* m) {
   std::vector<wb_session*> dead;
   {
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    auto it = g_pool.find(m);
+    auto it = g_pool.find(m->uid);
     if (it != g_pool.end()) { dead.swap(it->second); g_pool.erase(it); }
   }
   for (wb_session* s : dead) delete s;
@@ -125,13 +127,14 @@ int session_create(wb_model* m, int n_windows, int max_beams, int padding, wb_se
   wb_session* s = nullptr;
   {
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    auto it = g_pool.find(m);
+    auto it = g_pool.find(m->uid);
     WB_REQUIRE(it != g_pool.end(), WB_ERR_ARG, "session: the model handle is not alive");
     if (!it->second.empty()) { s = it->second.back(); it->second.pop_back(); }
   }
   if (!s) {
     s = new wb_session();
     s->m = m;
+    s->model_uid = m->uid;
     s->device = m->device;
     hipError_t e = hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking);
     if (e != hipSuccess) { delete s; set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); return WB_ERR_HIP; }
@@ -180,6 +183,7 @@ static int session_finish_encode(wb_session* s, const MelBatch& mb) {
   for (int w = 0; w < s->W; w++) { meta[w] = s->row0[w]; meta[s->W + w] = s->C[w]; }
   WB_TRY(s->win_meta.ensure(meta.size() * 4));
   if (meta != s->meta_host || s->meta_dev_ptr != s->win_meta.p) {   // (same geometry as last time: already on the device)
+    s->meta_host.clear(); s->meta_dev_ptr = nullptr;                 // void the cache key before the contents change
     WB_HIP(hipMemcpyAsync(s->win_meta.p, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, s->st));
     WB_HIP(hipStreamSynchronize(s->st));
     s->meta_host = meta; s->meta_dev_ptr = s->win_meta.p;
@@ -222,6 +226,7 @@ int session_encode_pcm(wb_session* s, const float* pcm, int64_t n_pcm, const int
   const bool same_wins = s->wins_host.size() == wins.size() && s->wins_dev_ptr == s->wins.p &&
                          memcmp(s->wins_host.data(), wins.data(), wins.size() * sizeof(MelWindow)) == 0;
   if (!same_wins) {
+    s->wins_host.clear(); s->wins_dev_ptr = nullptr;                  // void the cache key before the contents change
     WB_HIP(hipMemcpyAsync(s->wins.p, wins.data(), wins.size() * sizeof(MelWindow), hipMemcpyHostToDevice, s->st));
     WB_HIP(hipStreamSynchronize(s->st));   // `wins` is a stack vector
     s->wins_host = wins; s->wins_dev_ptr = s->wins.p;
@@ -366,7 +371,8 @@ void wb_session_free(wb_session* s) {
   if (!s) return;
   {
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    auto it = g_pool.find(s->m);     // absent: the model was freed first -- s->m dangles and must not be touched
+    auto it = g_pool.find(s->model_uid);   // absent: the model was freed first -- s->m dangles and must not be touched
+                                            // (a NEW model at the same address has another uid: no false match)
     if (it != g_pool.end()) {
       size_t parked = 0;
       for (const wb_session* q : it->second) parked += session_device_bytes(q);
@@ -683,6 +689,7 @@ static int launch_step(wb_session* s, int n_launch, int k, int use_mask, bool fu
     mix((uint64_t)(uintptr_t)b->p);
   mix((uint64_t)(uintptr_t)s->host_block_dev);
   for (int v : {s->S, s->W, s->Lmax, s->n_chunks, s->max_beams, m->ln_eps_inside_sqrt, eot}) mix((uint64_t)(int64_t)v);
+  mix(m->uid);
   if (sig != s->buf_sig) { s->clear_graphs(); s->buf_sig = sig; }
   // (reps > 1: device-chained steps read their position from the control block, so one graph can hold
   // several consecutive steps and the host launches once per run)

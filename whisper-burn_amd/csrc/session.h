@@ -7,6 +7,7 @@
 
 struct wb_session {
   wb_model* m = nullptr;
+  uint64_t model_uid = 0;       // m->uid at creation: what the pool is keyed by (m may dangle once its model is freed)
   int device = 0;               // m->device, kept so that a session can be destroyed after its model
   hipStream_t st = nullptr;
   hipStream_t st2 = nullptr;       // reads the chained decode's finished flags behind ev_seg while `st` runs ahead

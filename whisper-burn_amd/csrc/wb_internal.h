@@ -115,6 +115,9 @@ struct Workspace {
 }  // namespace wb
 
 struct wb_model {
+  // process-unique, never reused (build_model): the session pool and the captured decode graphs are keyed by it, not by
+  // the handle's address -- glibc hands a freed model's address to the next model of the same size
+  uint64_t uid = 0;
   wb_dims dims{};
   int device = 0;
   int compute_dtype = WB_F32;

@@ -13,7 +13,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
-from .model import Session, Whisper, check
+from .model import Session, Whisper, check, special_mask_bytes
 from .tokens import SpecialTokens
 
 
@@ -102,7 +102,7 @@ def waveform_to_tokens_prompted(whisper: Whisper, st: SpecialTokens, waveform, s
     lens = np.zeros(max(n_win, 1), np.int32)
     stitched = np.zeros(max(n_win, 1) * stride, np.int32)
     n_st = C.c_int64(0)
-    mask = np.ascontiguousarray(st.is_special, dtype=np.uint8)
+    mask = special_mask_bytes(whisper, st.is_special)
     check(lib.wb_waveform_to_tokens_prompted(whisper._h, _fp(wav), len(wav), sample_rate, C.byref(p),
                                              mask.ctypes.data_as(_lib.c_uint8_p), int(sop), n_prev_tokens,
                                              rows.ctypes.data_as(_lib.c_int32_p), stride,

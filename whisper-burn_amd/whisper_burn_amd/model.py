@@ -39,6 +39,17 @@ def _ip(a: np.ndarray):
     return a.ctypes.data_as(_lib.c_int32_p)
 
 
+def special_mask_bytes(whisper: "Whisper", is_special) -> np.ndarray:
+    """uint8 [n_vocab] for the C side, which reads exactly n_vocab bytes.  The reference adds a [vocab_size] mask to
+    [.., n_vocab] logits (transcribe.rs:243-275) and panics when the tokenizer's vocabulary and the model's differ; a
+    shorter buffer here would be an out-of-bounds host read."""
+    m = np.ascontiguousarray(is_special, dtype=np.uint8).reshape(-1)
+    if m.shape[0] != whisper.dims["n_vocab"]:
+        raise WbError(WB_ERR_SHAPE, f"special-token mask has {m.shape[0]} entries but the model's vocabulary has "
+                                    f"{whisper.dims['n_vocab']} (tokenizer / checkpoint mismatch)")
+    return m
+
+
 def max_waveform_samples(n_frame_max: int) -> int:
     """audio.rs:12-17."""
     return int(_lib.load().wb_max_waveform_samples(int(n_frame_max)))
@@ -319,7 +330,7 @@ def waveform_to_tokens(whisper: Whisper, st: SpecialTokens, waveform, sample_rat
     cap = max(n_local, 1) * stride
     stitched = np.zeros(cap, dtype=np.int32)
     n_st = C.c_int64(0)
-    mask = np.ascontiguousarray(st.is_special, dtype=np.uint8)
+    mask = special_mask_bytes(whisper, st.is_special)
     if device_ptr is None:
         check(lib.wb_waveform_to_tokens(whisper._h, _fp(wav), n_samples, sample_rate, C.byref(p),
                                         mask.ctypes.data_as(_lib.c_uint8_p), win_begin, win_end, _ip(win_tokens),
@@ -375,7 +386,7 @@ class Session:
         return Session(whisper, h, len(mels))
 
     def set_special_mask(self, is_special) -> None:
-        m = np.ascontiguousarray(is_special, dtype=np.uint8)
+        m = special_mask_bytes(self._w, is_special)
         check(_lib.load().wb_session_set_special_mask(self._h, m.ctypes.data_as(_lib.c_uint8_p)))
 
     def step(self, new_tokens, parent, window, apply_special_mask: bool = False, k: int = 5):
