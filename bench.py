@@ -29,10 +29,12 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s
 MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # dense peaks, same guide
 
 
-def e2e_roofline_ms(dims, lens, n_steps, dtype, clip=1490):
+def e2e_roofline_ms(dims, lens, n_steps, dtype, clip=1490, gen_lens=None, prompt_steps=3):
     """Roofline time of one bench step from the algorithmic work of every stage: mel = 960 B
     per frame over HBM, encoder + cross-K/V projection = dense FLOPs over the MFMA peak of the path's dtype,
-    decode = weights + cached cross-K/V streamed once per step over HBM."""
+    decode = weights + cached cross-K/V streamed once per step over HBM.  `gen_lens` (tokens each window generated):
+    only the NECESSARY bytes are counted -- a window's cached K/V for the steps in which it is still live, and no step
+    after the last window has ended (the engine marks finished rows dead and stops)."""
     d, L, V = dims["n_text_state"], dims["n_text_layer"], dims["n_vocab"]
     s = 2.0 if dtype == "bf16" else 4.0
     frames = [int(n) // 160 for n in lens]
@@ -43,17 +45,30 @@ def e2e_roofline_ms(dims, lens, n_steps, dtype, clip=1490):
                     for t, c in zip(T, C))
     ckv_flops = sum(L * 4 * c * d * d for c in C)
     enc_ms = (enc_flops + ckv_flops) / (MFMA_PEAK_TFLOPS[dtype] * 1e12) * 1e3
-    step_bytes = s * (V * d + L * 14 * d * d) + 4.0 * L * 2 * d * sum(C)     # cached K/V stay f32
-    dec_ms = n_steps * step_bytes / (HBM_PEAK_GBS * 1e9) * 1e3
+    w_bytes = s * (V * d + L * 14 * d * d)                                    # decoder weights + E^T, once per step
+    if gen_lens is None:
+        dec_bytes = n_steps * (w_bytes + 4.0 * L * 2 * d * sum(C))           # cached K/V stay f32
+    else:
+        live_steps = [prompt_steps + int(g) for g in gen_lens]               # prompt prefill + one step per token
+        dec_bytes = max(live_steps, default=0) * w_bytes + sum(4.0 * L * 2 * d * c * n for c, n in zip(C, live_steps))
+    dec_ms = dec_bytes / (HBM_PEAK_GBS * 1e9) * 1e3
     return {"mel": mel_ms, "encoder_and_cross_kv": enc_ms, "decode": dec_ms, "total": mel_ms + enc_ms + dec_ms,
-            "_work": {"encoder_flops": float(enc_flops + ckv_flops), "decode_bytes": float(n_steps * step_bytes)}}
+            "_work": {"encoder_flops": float(enc_flops + ckv_flops), "decode_bytes": float(dec_bytes)}}
 
 
-def run_cpu_baseline(weights, st, audio, sr, wlen, beam, depth, geometry, model_name):
+CPU_BASELINE_DEPTH = 32     # decode depth of the CPU leg's bounded sample (the reference re-runs the whole prefix per token:
+                            # its cost per token GROWS with the depth, so a shallower sample flatters the CPU figure)
+
+
+def run_cpu_baseline(weights, st, audio, sr, wlen, beam, depth, geometry, model_name, reps=3):
     """The `cpu_baseline` leg: the oracle (kind "port": the PyTorch-CPU fp32 restatement of the reference algorithm as
-    written -- dense-DFT mel, no KV cache, full-prefix decoder re-run per step) on a BOUNDED sample of the workload, ONE
-    window with the GPU run's decode settings, on the host cores PyTorch uses; the mel and encoder stages are timed on
-    their own as well, the decode time is the rest.  Runs without a GPU (tests call it on a micro model)."""
+    written -- dense-DFT mel, no KV cache, full-prefix decoder re-run per step) on a BOUNDED sample of the workload: ONE
+    window, decode depth min(depth, CPU_BASELINE_DEPTH), on the host cores PyTorch uses.  BASELINE.md section 3: one
+    warm-up run, then `reps` (>= 3) timed runs, the MEDIAN is reported (every run is listed); the mel and encoder stages
+    are timed on their own as well, the decode time is the rest.  Runs without a GPU (tests call it on a
+    micro model)."""
+    import statistics
+
     import torch
     from oracle import mel as omel
     from oracle import transcribe as otr
@@ -63,23 +78,33 @@ def run_cpu_baseline(weights, st, audio, sr, wlen, beam, depth, geometry, model_
                             st.end_of_text, st.is_special.astype(bool))
     n_cpu = min(len(audio), int(wlen))                               # bounded sample: ONE window
     clip = audio[:n_cpu]
-    t0 = time.perf_counter()
-    otr.waveform_to_tokens(ow, ost, clip, sr, beam, depth)            # the baseline figure: the whole path, as it comes
-    cpu_dt = time.perf_counter() - t0
-    t0 = time.perf_counter()                                          # ... then the two front stages on their own
-    mel = omel.prep_audio(torch.from_numpy(np.ascontiguousarray(clip))[None], float(sr))
-    t_mel = time.perf_counter() - t0
-    keep = min(mel.shape[2], ow.encoder_ctx_size() - 10)
-    melp = torch.cat([mel[:, :, :keep], torch.zeros(1, mel.shape[1], 10)], 2)
-    t0 = time.perf_counter()
-    ow.forward_encoder(melp)
-    t_enc = time.perf_counter() - t0
+    cpu_depth = min(int(depth), CPU_BASELINE_DEPTH)
+    otr.waveform_to_tokens(ow, ost, clip, sr, beam, min(cpu_depth, 4))   # warm-up: thread pool, allocator, code paths
+    runs = []
+    for _ in range(max(1, reps)):
+        t0 = time.perf_counter()
+        otr.waveform_to_tokens(ow, ost, clip, sr, beam, cpu_depth)        # the baseline figure: the whole path, as it comes
+        runs.append(time.perf_counter() - t0)
+    cpu_dt = statistics.median(runs)
+    t_mels, t_encs = [], []
+    for _ in range(max(1, reps)):                                        # ... then the two front stages on their own
+        t0 = time.perf_counter()
+        mel = omel.prep_audio(torch.from_numpy(np.ascontiguousarray(clip))[None], float(sr))
+        t_mels.append(time.perf_counter() - t0)
+        keep = min(mel.shape[2], ow.encoder_ctx_size() - 10)
+        melp = torch.cat([mel[:, :, :keep], torch.zeros(1, mel.shape[1], 10)], 2)
+        t0 = time.perf_counter()
+        ow.forward_encoder(melp)
+        t_encs.append(time.perf_counter() - t0)
+    t_mel, t_enc = statistics.median(t_mels), statistics.median(t_encs)
     t_mel, t_enc = min(t_mel, cpu_dt), min(t_enc, max(cpu_dt - min(t_mel, cpu_dt), 0.0))
     return {"value": round((n_cpu / sr) / cpu_dt, 3), "unit": "x real-time", "cores": torch.get_num_threads(),
             "kind": "port",
             "sample": f"1 window ({n_cpu / sr:.1f} s, {geometry} geometry), {model_name}, beam {beam}, "
-                      f"depth {depth}, PyTorch-CPU fp32 restatement of the reference algorithm as "
-                      f"written (dense-DFT mel, no KV cache); {cpu_dt:.1f} s wall",
+                      f"depth {cpu_depth}" + (f" (GPU run: {depth})" if cpu_depth != depth else "") +
+                      f", PyTorch-CPU fp32 restatement of the reference algorithm as "
+                      f"written (dense-DFT mel, no KV cache); 1 warm-up + {len(runs)} runs, median {cpu_dt:.2f} s wall",
+            "runs_s": [round(r, 3) for r in runs],
             "stages_s": {"mel": round(t_mel, 3), "encoder": round(t_enc, 3),
                          "decode": round(cpu_dt - t_mel - t_enc, 3), "total": round(cpu_dt, 3)},
             "host_cpus": os.cpu_count()}
@@ -102,6 +127,12 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mel-windows", type=int, default=256,
                     help="batched windows of the frontend-alone leg (mel-frames/s; SURVEY 8d: >= 100)")
+    ap.add_argument("--large-v2-leg", default="auto", choices=["auto", "on", "off"],
+                    help="extra timed leg: large-v2, --large-v2-seconds of audio per GPU (BASELINE.json's 8-GPU headline is "
+                         "large-v2; the driver's command line cannot select a model).  auto = only when --gpus > 1; "
+                         "`value` stays the tiny.en figure in every case")
+    ap.add_argument("--large-v2-seconds", type=float, default=450.0,
+                    help="audio per GPU of the large-v2 leg (450 s = 38 windows = one GPU's share of the 8-GPU hour)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 = exact-f32 MFMA parity path (the judged configuration); bf16 = speed path")
     args = ap.parse_args()
@@ -206,7 +237,9 @@ def main() -> None:
         # corrected per MI355X_MICROARCH.md (profiles/summarize_pmc.py), keyed by kernel class; only used when the
         # file was collected on this workload (it records the command line)
         pmc = {}
-        pmc_json = os.path.join(ROOT, "profiles", "r02_c_pmc_traffic_tiny_en_30s.json")
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_traffic_tiny_en_30s.json")))
+        pmc_json = cands[-1] if cands else os.path.join(ROOT, "profiles", "none.json")     # the newest round's passes
         if args.model in ("tiny.en", "tiny_en") and args.dtype == "f32" and args.beam == 1 and args.seconds == 30.0 \
                 and args.geometry == "reference" and os.path.exists(pmc_json):
             pmc = json.load(open(pmc_json))
@@ -284,11 +317,62 @@ def main() -> None:
         cpu_baseline = run_cpu_baseline(weights, st, audio, sr, int(wlen), args.beam, args.max_depth, args.geometry,
                                         args.model)
 
+    # ---- large-v2 leg (BASELINE.json's multi-GPU headline config): every rank decodes --large-v2-seconds of audio ----
+    large_v2 = None
+    if args.large_v2_leg == "on" or (args.large_v2_leg == "auto" and world > 1):
+        eng.close()
+        del pcm_dev
+        lw = synth.synth_preset("large-v2")
+        leng = wb.Whisper.from_tensors(lw, device=local_rank,
+                                       compute_dtype=wb.WB_BF16 if args.dtype == "bf16" else wb.WB_F32)
+        del lw
+        lst = wb.SpecialTokens.for_vocab(leng.dims["n_vocab"])
+        lparams = wb.decode_params(lst, beam_size=1, max_depth=args.max_depth)
+        ln_total = int(round(args.large_v2_seconds * sr)) * world
+        laudio = synth.synth_audio(ln_total, synth.BENCH_AUDIO_SEED + 5)
+        lpcm = torch.from_numpy(laudio).to(dev)
+        lstarts, llens = wb.window_extents(ln_total, sr, wlen, lparams.overlap_seconds)
+        ln_win = len(lstarts)
+
+        def ldecode(lo_, hi_):
+            return wb.waveform_to_tokens(leng, lst, None, sr, params=lparams, win_begin=lo_, win_end=hi_,
+                                         device_ptr=lpcm.data_ptr(), n_samples=ln_total)[1]
+
+        def lstep():
+            return shard.transcribe_sharded(ldecode, wb.stitch_windows, ln_win, rank, world, row_stride,
+                                            device=dev if world > 1 else None)
+
+        l_steps, l_warm = 3, 1
+        for _ in range(l_warm):
+            lstep()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(l_steps):
+            ltok, lrows = lstep()
+        barrier()
+        ldt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([ldt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ldt = float(t.item())
+        if rank == 0:
+            large_v2 = {"metric": "real-time factor (audio-sec/wall-sec)",
+                        "value": round(args.large_v2_seconds * world * l_steps / ldt, 2), "unit": "x real-time",
+                        "n_gpus": world, "steps": l_steps, "warmup": l_warm, "ms_per_step": round(ldt / l_steps * 1e3, 2),
+                        "dtype": args.dtype,
+                        "config": {"workload": f"large-v2, {args.large_v2_seconds:g} s of 16 kHz audio per GPU per step, "
+                                               f"reference windowing ({ln_win} windows), greedy, max_depth {args.max_depth}",
+                                   "windows": ln_win, "tokens_out": len(ltok),
+                                   "generated_tokens_per_window_mean": round(float(np.mean([len(r) - 4 for r in lrows])), 1)},
+                        "target": ">= 50x real-time on 8 GPUs (BASELINE.json north_star)"}
+        leng.close()
+
     if rank == 0:
         audio_s = args.seconds * world * args.steps
         lo, hi = shard.partition_windows(n_win, rank, world)
+        gen_lens = [max(0, len(r) - 4) for r in per_window[lo:hi]] if args.beam == 1 else None
         rl = e2e_roofline_ms(eng.dims, lens[lo:hi], 3 + args.max_depth, args.dtype,
-                             eng.max_mel_frames() - params.padding)                      # per rank (weak scaling)
+                             eng.max_mel_frames() - params.padding, gen_lens=gen_lens)   # per rank (weak scaling)
         work = rl.pop("_work")
         if stages:
             # achieved rates of the two big stages from their algorithmic work: encoder + cross-K/V from the profiled
@@ -303,9 +387,11 @@ def main() -> None:
         rl_rtf = args.seconds / (rl["total"] * 1e-3)
         e2e = {"roofline_rtf": round(rl_rtf, 1), "frac": round((rtf / world) / rl_rtf, 4),
                "roofline_ms_per_step": {k: round(v, 4) for k, v in rl.items()},
+               "generated_tokens_per_window": gen_lens,
                "note": "per-GPU roofline of the same step: algorithmic bytes over 8 TB/s (mel, decode) and FLOPs over "
-                       "the dense MFMA peak of the path's dtype (encoder, cross-K/V); decode is launch-latency-bound "
-                       "at this size (stages.decode_kernels_per_token dependent launches per token)"}
+                       "the dense MFMA peak of the path's dtype (encoder, cross-K/V); decode bytes are the NECESSARY ones "
+                       "(weights once per step while any window is live, a window's cached K/V only while it is live); "
+                       "decode is latency-bound at this size (stages.decode_kernels_per_token dependent launches per token)"}
         out = {
             "metric": "real-time factor (audio-sec/wall-sec)",
             "value": round(audio_s / dt, 2),
@@ -335,6 +421,7 @@ def main() -> None:
             "e2e_roofline": e2e,
             "mel_frontend": mel_frontend,
             "stages": stages,
+            "large_v2": large_v2,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -83,7 +83,8 @@ def test_two_ranks_shard_the_windows_of_the_real_engine(emu_lib):
     assert p.returncode == 0 and "EMU_CHECK_OK sharded" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
-@pytest.mark.parametrize("extra", [[], ["--geometry", "whisper30", "--beam", "2"]], ids=["default", "whisper30-beam2"])
+@pytest.mark.parametrize("extra", [["--large-v2-leg", "on", "--large-v2-seconds", "4"], ["--geometry", "whisper30", "--beam", "2"]],
+                         ids=["default+large-v2-leg", "whisper30-beam2"])
 def test_bench_main_runs_to_its_json_line(emu_lib, extra):
     """bench.py cannot start without cuda:0, and a broken bench line cannot be repaired after a round: tools/
     bench_dry_run.py stubs the torch.cuda calls and runs the script UNCHANGED over the functional model with a micro
@@ -105,6 +106,13 @@ def test_bench_main_runs_to_its_json_line(emu_lib, extra):
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and set(cb["stages_s"]) == {"mel", "encoder", "decode", "total"}
     assert out["mel_frontend"]["windows"] >= 2 and out["stages"]["decode_kernels_per_token"] > 0
+    assert len(cb["runs_s"]) == 3
+    if "--large-v2-leg" in extra:
+        lv = out["large_v2"]
+        assert lv["n_gpus"] == 1 and lv["value"] > 0 and lv["steps"] == 3 and "large-v2" in lv["config"]["workload"]
+        assert out["e2e_roofline"]["generated_tokens_per_window"] is not None
+    else:
+        assert out["large_v2"] is None
 
 
 def test_bench_main_two_ranks_over_gloo(emu_lib):
@@ -118,14 +126,18 @@ def test_bench_main_two_ranks_over_gloo(emu_lib):
     env["WHISPER_HIP_LIB"] = emu_lib
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", str(port), os.path.join(PKG, "tools", "bench_dry_run.py"), "--gpus", "2",
-                        "--steps", "1", "--warmup", "0", "--mel-windows", "2", "--seconds", "8", "--max-depth", "4"],
-                       env=env, capture_output=True, text=True, timeout=600)
+                        "--steps", "1", "--warmup", "0", "--mel-windows", "2", "--seconds", "8", "--max-depth", "4",
+                        "--large-v2-seconds", "8"],
+                       env=env, capture_output=True, text=True, timeout=900)
     lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
     assert p.returncode == 0 and len(lines) == 1, p.stdout[-1500:] + p.stderr[-3000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["cpu_baseline"] is None      # CPU leg: N = 1 only
     assert out["config"]["windows"] >= 2                                                        # 16 s of audio in total: one window per rank
     assert abs(out["value"] - 16.0 / (out["ms_per_step"] * 1e-3)) < 0.05 * out["value"]           # whole-job audio / time
+    lv = out["large_v2"]                                  # N > 1: the large-v2 leg runs by default (the 8-GPU headline config)
+    assert lv["n_gpus"] == 2 and lv["config"]["windows"] >= 2
+    assert abs(lv["value"] - 16.0 / (lv["ms_per_step"] * 1e-3)) < 0.05 * lv["value"]
 
 
 def test_outputs_are_bitwise_independent_of_the_schedule(emu_lib):

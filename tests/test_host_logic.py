@@ -299,7 +299,8 @@ def test_cpu_baseline_leg_of_the_bench_runs_without_a_gpu():
     assert r["kind"] == "port" and r["value"] > 0 and r["cores"] >= 1
     s = r["stages_s"]
     assert abs(s["mel"] + s["encoder"] + s["decode"] - s["total"]) < 2e-3 and s["decode"] > 0
-    assert "1 window (3.9 s" in r["sample"]
+    assert "1 window (3.9 s" in r["sample"] and "1 warm-up + 3 runs, median" in r["sample"]
+    assert len(r["runs_s"]) == 3 and min(r["runs_s"]) <= s["total"] <= max(r["runs_s"])
 
 
 def test_special_mask_length_is_checked_before_it_reaches_c():
