@@ -16,826 +16,28 @@
 #include <hip/hip_runtime.h>
 
 #include "decode.h"
+#include "decode_fused_bodies.h"
 #include "wave_ops.h"
 
 namespace wb {
 namespace {
 
-// developer probe: tools/decode_probe.cpp builds this file with -DWB_STAMPS and prints the phase timeline of block 0
-#ifdef WB_STAMPS
-#define WB_STAMP_DECL __shared__ unsigned long long stamp_buf[16]
-#define WB_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) stamp_buf[i] = wall_clock64(); } while (0)
-#define WB_STAMP_FLUSH(a, n) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && (a).stamps) for (int _i = 0; _i < (n); _i++) (a).stamps[_i] = stamp_buf[_i]; } while (0)
-#else
-#define WB_STAMP_DECL
-#define WB_STAMP(i) do {} while (0)
-#define WB_STAMP_FLUSH(a, n) do {} while (0)
-#endif
+using namespace fused;
 
-constexpr int FD_MAX = 512;      // largest n_state of the fused path (test models 128, tiny.en 384, base.en 512)
-constexpr int FA_MAXPOS = 448;   // n_text_ctx
-
-__device__ __forceinline__ float gelu_erf_f(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
-}
-
-// One wave folds row `row`: v = x_in + (pbias + sum_s pend[s]) (s ascending, mod.rs:346-348), optionally writes
-// the folded stream, then LayerNorm (Burn nn::LayerNorm: biased variance, two passes) into out[0..d).
-// Every load is unconditional (columns past d alias column `lane`; planes past KSp alias the last plane).
-template <int DPL>
-__device__ __forceinline__ void fold_ln_row(const float* __restrict__ x_in, const float* __restrict__ pend, int KSp,
-                                            int64_t plane, const float* __restrict__ pbias, float* __restrict__ x_out,
-                                            const float* __restrict__ g, const float* __restrict__ b, float eps,
-                                            int eps_inside, int d, int row, int lane, float* __restrict__ out) {
-  int co[DPL];
-#pragma unroll
-  for (int i = 0; i < DPL; i++) co[i] = lane + (64 * i < d ? 64 * i : 0);
-  float gv[DPL], bv[DPL], v[DPL];
-  const float* xr = x_in + (int64_t)row * d;
-#pragma unroll
-  for (int i = 0; i < DPL; i++) { gv[i] = g[co[i]]; bv[i] = b[co[i]]; v[i] = xr[co[i]]; }
-  if (KSp > 0) {
-    float acc[DPL];
-#pragma unroll
-    for (int i = 0; i < DPL; i++) acc[i] = pbias[co[i]];
-    const float* pp = pend + (int64_t)row * d;
-    constexpr int CH = DPL <= 6 ? 8 : 4;
-    for (int sp = 0; sp < KSp; sp += CH) {
-      float t[CH][DPL];
-#pragma unroll
-      for (int j = 0; j < CH; j++) {
-        const float* pj = pp + (int64_t)min(sp + j, KSp - 1) * plane;
-#pragma unroll
-        for (int i = 0; i < DPL; i++) t[j][i] = pj[co[i]];
-      }
-#pragma unroll
-      for (int j = 0; j < CH; j++) {
-        const bool live = sp + j < KSp;
-#pragma unroll
-        for (int i = 0; i < DPL; i++) acc[i] += live ? t[j][i] : 0.f;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < DPL; i++) v[i] = v[i] + acc[i];
-  }
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < DPL; i++) {
-    if (64 * i < d) { s += v[i]; if (x_out) x_out[(int64_t)row * d + co[i]] = v[i]; }
-  }
-  const float mean = wave_sum(s) / (float)d;
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < DPL; i++) {
-    if (64 * i < d) { const float t = v[i] - mean; q += t * t; }
-  }
-  const float var = wave_sum(q) / (float)d;
-  const float denom = eps_inside ? sqrtf(var + eps) : (sqrtf(var) + eps);
-#pragma unroll
-  for (int i = 0; i < DPL; i++) {
-    const int c = lane + 64 * i;
-    if (c < d) out[c] = (v[i] - mean) / denom * gv[i] + bv[i];
-  }
-}
-
-// Cooperative fold of the residual stream: xs[r][c] = x_in[r][c] + pbias[c] + sum_s pend[s][r][c] for every
-// r < MR, c < d, all loads of a thread issued together (one memory round trip instead of one per plane chunk).
-// Rows >= n_rows read valid memory (the buffers carry MR rows of slack) and are never used.
-template <int NT, int MR, int EPT, int PCH>
-__device__ __forceinline__ void fold_rows(const float* __restrict__ x_in, const float* __restrict__ pend, int KSp,
-                                          int64_t plane, const float* __restrict__ pbias, int d, int tid,
-                                          float (&v)[EPT]) {
-  int off[EPT], col[EPT];
-#pragma unroll
-  for (int i = 0; i < EPT; i++) {
-    int e = tid + NT * i;
-    if (e >= MR * d) e = tid;                      // past the tile: alias an in-range element, result unused
-    off[i] = e; col[i] = e % d;
-  }
-#pragma unroll
-  for (int i = 0; i < EPT; i++) v[i] = x_in[off[i]];
-  if (KSp > 0) {
-    float acc[EPT];
-#pragma unroll
-    for (int i = 0; i < EPT; i++) acc[i] = pbias[col[i]];
-    for (int sp = 0; sp < KSp; sp += PCH) {
-      float t[PCH][EPT];
-#pragma unroll
-      for (int j = 0; j < PCH; j++) {
-        const float* pj = pend + (int64_t)min(sp + j, KSp - 1) * plane;
-#pragma unroll
-        for (int i = 0; i < EPT; i++) t[j][i] = pj[off[i]];
-      }
-#pragma unroll
-      for (int j = 0; j < PCH; j++) {
-        const bool live = sp + j < KSp;
-#pragma unroll
-        for (int i = 0; i < EPT; i++) acc[i] += live ? t[j][i] : 0.f;     // s ascending: fixed order
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < EPT; i++) v[i] = v[i] + acc[i];                   // x + (bias + partials)  (mod.rs:346-348)
-  }
-}
-
-// LayerNorm of row r held in LDS (in place), one wave: Burn nn::LayerNorm, biased variance, two passes.
-template <int DPL>
-__device__ __forceinline__ void ln_row_lds(float* __restrict__ row, int d, int lane, const float (&gv)[DPL],
-                                           const float (&bv)[DPL], float eps, int eps_inside) {
-  float v[DPL];
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < DPL; i++) { v[i] = row[lane + 64 * i]; s += v[i]; }
-  const float mean = wave_sum(s) / (float)d;
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < DPL; i++) { const float t = v[i] - mean; q += t * t; }
-  const float var = wave_sum(q) / (float)d;
-  const float denom = eps_inside ? sqrtf(var + eps) : (sqrtf(var) + eps);
-#pragma unroll
-  for (int i = 0; i < DPL; i++) row[lane + 64 * i] = (v[i] - mean) / denom * gv[i] + bv[i];
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// MLP.  block = 512 threads, grid = 4 d / 64.  Every global load of the block (fold operands, the W1 slice, the
-// W2 slice) is requested before the first use of any of them: one memory round trip on the critical path.
-// Phase 1: 16 lanes x float4 cover the 64 slice columns of one W1 row; thread (rg = tid / 16, c4) owns rows
-// rg, rg + 32, ... (d / 32 of them).  Phase 2: thread (cf = tid % (d / 4), jg = tid / (d / 4)) owns a float4 of
-// output columns and 64 / G rows of the W2 slice.
+// one launch per sublayer: grid = the roles of that sublayer, the step state comes from a.st
 template <int MR, int DPL, bool REC>
 __global__ __launch_bounds__(512) void dec_mlp_fused_kernel(MlpFusedArgs a) {
-  constexpr int HS = 64, NT = 512;
-  constexpr int d = 64 * DPL;
-  constexpr int CF = d / 4;
-  constexpr int G = CF <= 32 ? 8 : 4;              // phase-2 row groups (d = 128: 8 x 8 rows, 384 / 512: 4 x 16 rows)
-  constexpr int RPG = HS / G;
-  constexpr int EPT = (MR * d + NT - 1) / NT;
-  constexpr int PCH = EPT <= 3 ? 8 : EPT <= 6 ? 6 : 3;
-  __shared__ __attribute__((aligned(16))) float hs[MR][d];              // x + pending, then LN of it
-  __shared__ __attribute__((aligned(16))) float red[8][MR][HS];         // per-wave partial hidden sums
-  __shared__ __attribute__((aligned(16))) float hid[MR][HS];            // GELU(hidden slice)
-  __shared__ __attribute__((aligned(16))) float obuf[(G - 1) * MR * d]; // phase-2 partials of row groups >= 1
-  __shared__ float mlb[REC ? MR : 1][48][2];                            // record mode: (m, l) of every (head, chunk)
-  __shared__ float coef[REC ? MR : 1][48];                              // ... and its flash-combine weight
-  WB_STAMP_DECL;
-  WB_STAMP(0);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int j0 = blockIdx.x * HS;
-  const int rg = tid >> 4, c4 = (tid & 15) * 4;
-  // Requested up front, in the order of use (loads return in order): fold operands, LayerNorm parameters, bias, the W1
-  // slice, the W2 slice.  No global STORE before the last phase (a pending store makes every __syncthreads a vmcnt(0)).
-  float xv_fold[EPT];
-  constexpr int NW1 = d / 32;
-  float4 w1[NW1];
-  const int cf = tid % CF, jg = tid / CF;
-  const bool p2 = jg < G;
-  const int jb = (p2 ? jg : 0) * RPG;
-  float4 w2[RPG];
-  float gv[DPL], bv[DPL];
-  float b1v;
-  {
-    int off[EPT], col[EPT];
-#pragma unroll
-    for (int i = 0; i < EPT; i++) {
-      int e = tid + NT * i;
-      if (e >= MR * d) e = tid;
-      off[i] = e; col[i] = e % d;
-    }
-    float acc0[EPT];
-    constexpr bool rec = REC;                        // pend = cross-attention chunk records {m, l, P[d]}
-    const int64_t plane = rec ? (int64_t)a.S * (d + 2) : (int64_t)a.S * d;
-    int poff[EPT];                                   // element offset inside a plane / record plane
-#pragma unroll
-    for (int i = 0; i < EPT; i++) poff[i] = rec ? (off[i] / d) * (d + 2) + 2 + col[i] : off[i];
-    constexpr int PCHR = EPT <= 3 ? 18 : EPT <= 4 ? 16 : EPT <= 6 ? 12 : 8;
-    constexpr int PC = REC ? PCHR : PCH;
-    float t[PC][EPT];
-    const int npl = a.KSp;
-    const int ch = rec ? PCHR : PCH;                 // planes per round
-#pragma unroll
-    for (int i = 0; i < EPT; i++) { xv_fold[i] = a.x_in[off[i]]; acc0[i] = npl > 0 ? a.pbias[col[i]] : 0.f; }
-    float mlv0 = -1.0e30f, mlv1 = 0.f;
-    if (rec && tid < MR * npl) {                     // (m, l) of record (row tid / npl, plane tid % npl)
-      const float* rp = a.pend + (int64_t)(tid % npl) * plane + (int64_t)(tid / npl) * (d + 2);
-      mlv0 = rp[0]; mlv1 = rp[1];
-    }
-    if (npl > 0) {
-#pragma unroll
-      for (int j = 0; j < PC; j++)
-        if (j < ch) {
-#pragma unroll
-          for (int i = 0; i < EPT; i++) t[j][i] = a.pend[(int64_t)min(j, npl - 1) * plane + poff[i]];
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < DPL; i++) { gv[i] = a.ln_g[lane + 64 * i]; bv[i] = a.ln_b[lane + 64 * i]; }
-    b1v = a.b1[j0 + (tid & 63)];
-    {
-      const float* wp = a.W1 + (int64_t)rg * a.ld1 + j0 + c4;
-#pragma unroll
-      for (int i = 0; i < NW1; i++) w1[i] = *reinterpret_cast<const float4*>(wp + (int64_t)(32 * i) * a.ld1);
-    }
-    {
-      const float* wp = a.W2 + (int64_t)(j0 + jb) * d + cf * 4;
-#pragma unroll
-      for (int i = 0; i < RPG; i++) w2[i] = *reinterpret_cast<const float4*>(wp + (int64_t)i * d);
-    }
-    if constexpr (REC) {
-      // flash-combine weights: coef[r][h][c] = exp(m_hc - M_h) / sum_c' exp(m_hc' - M_h) l_hc'  (mod.rs:529 softmax,
-      // split over key chunks by dec_cross_attn_kernel)
-      if (tid < MR * npl) { mlb[tid / npl][tid % npl][0] = mlv0; mlb[tid / npl][tid % npl][1] = mlv1; }
-      __syncthreads();
-      if (tid < MR * a.n_head) {
-        const int r = tid / a.n_head, hh = tid % a.n_head;
-        float M = -1.0e30f;
-        for (int c = 0; c < a.n_chunks; c++) M = fmaxf(M, mlb[r][hh * a.n_chunks + c][0]);
-        float den = 0.f;
-        for (int c = 0; c < a.n_chunks; c++) den += expf(mlb[r][hh * a.n_chunks + c][0] - M) * mlb[r][hh * a.n_chunks + c][1];
-        for (int c = 0; c < a.n_chunks; c++)
-          coef[r][hh * a.n_chunks + c] = den > 0.f ? expf(mlb[r][hh * a.n_chunks + c][0] - M) / den : 0.f;
-      }
-      __syncthreads();
-    }
-    if (npl > 0) {
-      int rowi[EPT];
-#pragma unroll
-      for (int i = 0; i < EPT; i++) rowi[i] = off[i] / d;
-      for (int sp = 0; sp < npl; sp += ch) {
-        if (sp > 0) {
-#pragma unroll
-          for (int j = 0; j < PC; j++)
-            if (j < ch) {
-#pragma unroll
-              for (int i = 0; i < EPT; i++) t[j][i] = a.pend[(int64_t)min(sp + j, npl - 1) * plane + poff[i]];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < PC; j++)
-          if (j < ch) {
-#pragma unroll
-            for (int i = 0; i < EPT; i++) {
-              const bool live = sp + j < npl;
-              float wgt = 1.f;
-              if constexpr (REC) wgt = coef[rowi[i]][min(sp + j, npl - 1)];
-              acc0[i] += live ? wgt * t[j][i] : 0.f;                                        // plane order fixed
-            }
-          }
-      }
-#pragma unroll
-      for (int i = 0; i < EPT; i++) xv_fold[i] += acc0[i];                               // x + (bias + partials)  (mod.rs:346-348)
-    }
-#pragma unroll
-    for (int i = 0; i < EPT; i++) {
-      const int e = tid + NT * i;
-      if (e < MR * d) (&hs[0][0])[e] = xv_fold[i];
-    }
-  }
-  const int n_rows = a.st[ST_N];
-  if (n_rows == 0) return;                         // chained decode, every window finished (block-uniform)
-  WB_STAMP(1);
-  __syncthreads();
-  if (wave < MR) ln_row_lds<DPL>(hs[wave], d, lane, gv, bv, a.ln_eps, a.ln_inside);
-  __syncthreads();
-  WB_STAMP(2);
-  float acc[MR][4];
-#pragma unroll
-  for (int r = 0; r < MR; r++) { acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.f; }
-#pragma unroll
-  for (int i = 0; i < NW1; i++) {
-    const int k = rg + 32 * i;
-#pragma unroll
-    for (int r = 0; r < MR; r++) {
-      const float xv = hs[r][k];
-      acc[r][0] += xv * w1[i].x; acc[r][1] += xv * w1[i].y; acc[r][2] += xv * w1[i].z; acc[r][3] += xv * w1[i].w;
-    }
-  }
-  // lanes l, l ^ 16, l ^ 32, l ^ 48 hold the same columns for different rows: fold them, then the eight waves
-#pragma unroll
-  for (int r = 0; r < MR; r++)
-#pragma unroll
-    for (int c = 0; c < 4; c++) { acc[r][c] = xor16_sum(acc[r][c]); acc[r][c] = xor32_sum(acc[r][c]); }
-  if (lane < 16) {
-#pragma unroll
-    for (int r = 0; r < MR; r++)
-      *reinterpret_cast<float4*>(&red[wave][r][c4]) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
-  }
-  __syncthreads();
-  if (tid < MR * HS) {
-    const int r = tid >> 6, c = tid & 63;
-    float v = 0.f;
-#pragma unroll
-    for (int w8 = 0; w8 < 8; w8++) v += red[w8][r][c];                  // wave order fixed
-    hid[r][c] = gelu_erf_f(v + b1v);                                    // mod.rs:377-378
-  }
-  __syncthreads();
-  WB_STAMP(3);
-  float o[MR][4];
-#pragma unroll
-  for (int r = 0; r < MR; r++) { o[r][0] = o[r][1] = o[r][2] = o[r][3] = 0.f; }
-#pragma unroll
-  for (int i = 0; i < RPG; i++) {
-#pragma unroll
-    for (int r = 0; r < MR; r++) {
-      const float hv = hid[r][jb + i];
-      o[r][0] += hv * w2[i].x; o[r][1] += hv * w2[i].y; o[r][2] += hv * w2[i].z; o[r][3] += hv * w2[i].w;
-    }
-  }
-  if (p2 && jg > 0) {
-#pragma unroll
-    for (int r = 0; r < MR; r++)
-      *reinterpret_cast<float4*>(&obuf[((jg - 1) * MR + r) * d + cf * 4]) = make_float4(o[r][0], o[r][1], o[r][2], o[r][3]);
-  }
-  __syncthreads();
-  if (jg == 0) {
-#pragma unroll
-    for (int g2 = 1; g2 < G; g2++) {               // group order fixed: deterministic sums
-#pragma unroll
-      for (int r = 0; r < MR; r++) {
-        const float4 t = *reinterpret_cast<const float4*>(&obuf[((g2 - 1) * MR + r) * d + cf * 4]);
-        o[r][0] += t.x; o[r][1] += t.y; o[r][2] += t.z; o[r][3] += t.w;
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < MR; r++)
-      if (r < n_rows)
-        *reinterpret_cast<float4*>(&a.P[((int64_t)blockIdx.x * a.S + r) * d + cf * 4]) =
-            make_float4(o[r][0], o[r][1], o[r][2], o[r][3]);
-  }
-  if (blockIdx.x == 0) {                           // the folded residual stream, off the critical path
-#pragma unroll
-    for (int i = 0; i < EPT; i++) {
-      const int e = tid + NT * i;
-      if (e < n_rows * d) a.x_out[e] = xv_fold[i];
-    }
-  }
-  WB_STAMP(4);
-  WB_STAMP_FLUSH(a, 5);
+  dec_mlp_body<MR, DPL, REC, false>(a, blockIdx.x, PsStep());
 }
-
-// ---------------------------------------------------------------------------------------------------------
-// Self-attention block.  block = 512 threads (8 waves), grid = (n_head, rows): block (h, r) owns head h of beam r.
-// (One block per head for ALL beams keeps 4-8 accumulator sets per thread next to two weight rounds and spills;
-// per-beam blocks re-read the head's weight slices through L2 -- HBM still sees them once.)
-// QKV: wave w owns K-rows [w d / 8, (w + 1) d / 8); lane (seg = lane / 16 in {q, k, v, idle}, c4) reads a float4 of
-// the head's 64 columns of that segment; rounds of 16 rows, two rounds in flight.  Requested up front: the fold
-// operands + two weight rounds, then (as soon as the position table is known) the cached K / V rows of the first 128
-// positions in the coalesced row layout -- they land under the QKV FMAs; when the weight registers free up: the
-// out-projection slice.  The attention phases and the out-projection do not wait on memory.
+// grid = (8, rows): workgroups go round-robin over the 8 XCDs by linear id, so x = head puts every beam's block of
+// one head on the SAME XCD -- the head's weight slices cross the fabric once and are shared through that L2
 template <int DPL>
 __global__ __launch_bounds__(512) void dec_attn_fused_kernel(AttnFusedArgs a) {
-  constexpr int NT = 512;
-  constexpr int d = 64 * DPL;
-  constexpr int KW = d / 8;                        // K rows per wave (16, 48, 64)
-  constexpr int RK = DPL >= 6 ? 8 : 16;            // K rows per weight round (sized so that two rounds + the cached K/V tile stay in registers)
-  constexpr int NIT = KW / RK;
-  constexpr int CF = d / 4;
-  constexpr int G = CF <= 32 ? 8 : 4;              // out-projection row groups (d = 128: 8 x 8 rows, 384 / 512: 4 x 16)
-  constexpr int RPG = 64 / G;
-  constexpr int RED = (8 * 192 > (G - 1) * d) ? 8 * 192 : (G - 1) * d;
-  constexpr int PT = 128, PSL = PT * 16 / NT;      // cached positions per tile, float4 slots per thread per tile (4)
-  __shared__ __attribute__((aligned(16))) float hs[d];
-  __shared__ __attribute__((aligned(16))) float red[RED];              // QKV partials, later the out-projection partials
-  __shared__ __attribute__((aligned(16))) float qkv[192];              // q * s, k * s, v of the new token (head h)
-  __shared__ int tbs[FA_MAXPOS];
-  __shared__ float sc[FA_MAXPOS];
-  __shared__ __attribute__((aligned(16))) float part[32][64];
-  __shared__ __attribute__((aligned(16))) float att[64];
-  WB_STAMP_DECL;
-  WB_STAMP(0);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // grid = (8, rows): workgroups go round-robin over the 8 XCDs by linear id, so x = head puts every beam's block of
-  // one head on the SAME XCD -- the head's weight slices cross the fabric once and are shared through that L2
-  const int h = blockIdx.x, r = blockIdx.y;
-  if (h >= a.n_head) return;
-  // the row's state words first: the position table, and through it the cached K / V addresses, hang on them
-  const int n_rows = a.st[ST_N], len = a.st[a.lay.len + r], step_par = a.st[ST_STEP] & 1;
-  const int dead = a.st[a.lay.dead + r];           // chained greedy decode: this row's window has already ended
-  // ---- then, in this order (loads return in order: the fold must not queue behind the weights): the fold
-  // operands of row r, LayerNorm parameters (wave 0 normalises), bias, then two QKV weight rounds.
-  // No global STORE happens before the last phase: a pending store turns every __syncthreads into vmcnt(0).
-  const int seg = lane >> 4, c4 = (lane & 15) * 4;
-  const bool seg_ok = seg < 3;
-  const float* wq = a.Wqkv + (int64_t)(wave * KW) * a.ldqkv + (seg_ok ? seg : 0) * d + h * 64 + c4;
-  float4 wr[2][RK];
-  auto load_round = [&](float4 (&w)[RK], int it) {
-#pragma unroll
-    for (int j = 0; j < RK; j++) w[j] = *reinterpret_cast<const float4*>(wq + (int64_t)(RK * it + j) * a.ldqkv);
-  };
-  float xfold;                                     // this thread's element of x + pending (kept for the final x_out store)
-  float gv[DPL], bv[DPL];                          // LayerNorm parameters (wave 0 normalises)
-  {
-    // x + (bias + partial planes), s ascending (mod.rs:346-348): one element per thread, all planes in flight together
-    const int c = tid < d ? tid : 0;
-    const float* pp = a.pend + (int64_t)r * d + c;
-    const int64_t plane = (int64_t)a.S * d;
-    float v = a.x_in[(int64_t)r * d + c];
-    constexpr int FP = 32;                          // planes per round: 4 d / 64 <= 32 MLP planes in ONE round trip
-    float t[FP];
-    float accp = 0.f;
-    if (a.KSp > 0) {
-      accp = a.pbias[c];
-#pragma unroll
-      for (int j = 0; j < FP; j++) t[j] = pp[(int64_t)min(j, a.KSp - 1) * plane];
-    }
-    if (wave == 0) {
-#pragma unroll
-      for (int i = 0; i < DPL; i++) { gv[i] = a.ln_g[lane + 64 * i]; bv[i] = a.ln_b[lane + 64 * i]; }
-    }
-    load_round(wr[0], 0);
-    if (NIT > 1) load_round(wr[1], 1);
-    if (r >= n_rows || dead) return;               // (block-uniform; the first wait of the kernel)
-    if (a.KSp > 0) {
-#pragma unroll
-      for (int j = 0; j < FP; j++) accp += (j < a.KSp) ? t[j] : 0.f;
-      for (int sp = FP; sp < a.KSp; sp += FP) {
-#pragma unroll
-        for (int j = 0; j < FP; j++) t[j] = pp[(int64_t)min(sp + j, a.KSp - 1) * plane];
-#pragma unroll
-        for (int j = 0; j < FP; j++) accp += (sp + j < a.KSp) ? t[j] : 0.f;
-      }
-      v += accp;
-    }
-    xfold = v;
-    if (tid < d) hs[tid] = v;
-  }
-  const float qbias = tid < 192 ? a.bqkv[(tid >> 6) * d + h * 64 + (tid & 63)] : 0.f;   // key part is zero (mod.rs:402-404)
-  // ---- the cached K / V rows of the first 128 positions, the coalesced way (16 lanes x 16 B = one 256-byte head row;
-  // thread (rg, pq4) holds quad pq4 of positions rg + 32 i): requested HERE, behind the first two weight rounds, so
-  // that they arrive under the QKV FMAs instead of costing two dependent round trips after them.  Positions past the
-  // live range re-read slot 0 of the row (always valid; masked where consumed).
-  const int npast = len - 1;                       // cached positions; the new token attends to itself from LDS
-  const int rg = tid >> 4, pq4 = (tid & 15) * 4;
-  const int* tb = a.tabs + (size_t)step_par * a.lay.S * a.Lmax + r * a.Lmax;
-  int slot[PSL];
-#pragma unroll
-  for (int i = 0; i < PSL; i++) slot[i] = tb[rg + 32 * i < npast ? rg + 32 * i : 0];
-  const int slot_new = tb[npast];
-  if (npast > PT)                                  // only the tail tiles of long sequences walk the table through LDS
-    for (int p = tid; p < npast; p += NT) tbs[p] = tb[p];
-  float4 kc[PSL], vc[PSL];
-#pragma unroll
-  for (int i = 0; i < PSL; i++) kc[i] = *reinterpret_cast<const float4*>(a.Kc + (int64_t)slot[i] * d + h * 64 + pq4);
-#pragma unroll
-  for (int i = 0; i < PSL; i++) vc[i] = *reinterpret_cast<const float4*>(a.Vc + (int64_t)slot[i] * d + h * 64 + pq4);
-  WB_STAMP(1);
-  __syncthreads();
-  if (wave == 0) ln_row_lds<DPL>(hs, d, lane, gv, bv, a.ln_eps, a.ln_inside);
-  __syncthreads();
-  WB_STAMP(2);
-  // ---- QKV for head h (rolled on purpose: unrolled, every round's loads are hoisted to the top and spill)
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-  for (int it = 0; it < NIT; it += 2) {
-#pragma unroll
-    for (int b = 0; b < 2; b++) {
-      if (it + b < NIT) {
-        const int kb = wave * KW + RK * (it + b);
-#pragma unroll
-        for (int j = 0; j < RK; j++) {
-          const float xv = hs[kb + j];
-          acc[0] += xv * wr[b][j].x; acc[1] += xv * wr[b][j].y; acc[2] += xv * wr[b][j].z; acc[3] += xv * wr[b][j].w;
-        }
-        if (it + b + 2 < NIT) load_round(wr[b], it + b + 2);
-      }
-    }
-  }
-  WB_STAMP(3);
-  __syncthreads();   // (also pins the loads below behind the FMAs: the weight registers are free now)
-  // ---- requested now: the Wo slice (consumed last)
-  const int cf = tid % CF, jg = tid / CF;
-  const bool p5 = jg < G;
-  const int jb = (p5 ? jg : 0) * RPG;
-  float4 wo[RPG];
-  {
-    const float* wp = a.Wo + (int64_t)(h * 64 + jb) * d + cf * 4;
-#pragma unroll
-    for (int i = 0; i < RPG; i++) wo[i] = *reinterpret_cast<const float4*>(wp + (int64_t)i * d);
-  }
-  if (seg_ok) *reinterpret_cast<float4*>(&red[wave * 192 + seg * 64 + c4]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-  __syncthreads();
-  if (tid < 192) {
-    float v = 0.f;
-#pragma unroll
-    for (int w8 = 0; w8 < 8; w8++) v += red[w8 * 192 + tid];            // wave order fixed
-    v += qbias;
-    if (tid < 128) v *= a.scale;                                        // q * s, k * s  (mod.rs:506-514)
-    qkv[tid] = v;
-  }
-  __syncthreads();
-  WB_STAMP(4);
-  // ---- scores: 4-term partial dots summed over the 16 lanes of a position's row (DPP); tail tiles (sequences longer
-  // than 128 cached positions) reload through the LDS copy of the table
-  {
-    const float4 q4 = *reinterpret_cast<const float4*>(&qkv[pq4]);
-    auto row_dot = [&](const float4& k4) {
-      float s = q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
-      s += dpp_f<DPP_QUAD_XOR1, 0xF>(0.f, s);
-      s += dpp_f<DPP_QUAD_XOR2, 0xF>(0.f, s);
-      s += dpp_f<DPP_ROW_HALF_MIRROR, 0xF>(0.f, s);
-      s += dpp_f<DPP_ROW_MIRROR, 0xF>(0.f, s);
-      return s;
-    };
-#pragma unroll
-    for (int i = 0; i < PSL; i++) {
-      const int p = rg + 32 * i;
-      const float s = row_dot(kc[i]);
-      if ((tid & 15) == 0 && p < npast) sc[p] = s;
-    }
-    for (int t0 = PT; t0 < npast; t0 += PT) {
-      float4 kt[PSL];
-#pragma unroll
-      for (int i = 0; i < PSL; i++) {
-        const int p = min(t0 + rg + 32 * i, npast - 1);
-        kt[i] = *reinterpret_cast<const float4*>(a.Kc + (int64_t)tbs[p] * d + h * 64 + pq4);
-      }
-#pragma unroll
-      for (int i = 0; i < PSL; i++) {
-        const int p = t0 + rg + 32 * i;
-        const float s = row_dot(kt[i]);
-        if ((tid & 15) == 0 && p < npast) sc[p] = s;
-      }
-    }
-    if (wave == 7) {                                                    // the new token's own key (k * s from LDS)
-      const float s = wave_sum(qkv[lane] * qkv[64 + lane]);
-      if (lane == 0) sc[npast] = s;
-    }
-  }
-  __syncthreads();
-  WB_STAMP(5);
-  // softmax statistics, redundantly per wave (no extra barrier): m, l over all positions
-  float m = -INFINITY;
-  for (int p = lane; p < len; p += 64) m = fmaxf(m, sc[p]);
-  m = wave_max(m);
-  float l = 0.f;
-  for (int p = lane; p < len; p += 64) l += expf(sc[p] - m);
-  l = wave_sum(l);
-  {
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int i = 0; i < PSL; i++) {
-      const int p = rg + 32 * i;
-      const float pk = p < npast ? expf(sc[p] - m) : 0.f;
-      o.x += pk * vc[i].x; o.y += pk * vc[i].y; o.z += pk * vc[i].z; o.w += pk * vc[i].w;
-    }
-    for (int t0 = PT; t0 < npast; t0 += PT) {
-      float4 vt[PSL];
-#pragma unroll
-      for (int i = 0; i < PSL; i++) {
-        const int p = min(t0 + rg + 32 * i, npast - 1);
-        vt[i] = *reinterpret_cast<const float4*>(a.Vc + (int64_t)tbs[p] * d + h * 64 + pq4);
-      }
-#pragma unroll
-      for (int i = 0; i < PSL; i++) {
-        const int p = t0 + rg + 32 * i;
-        const float pk = p < npast ? expf(sc[p] - m) : 0.f;
-        o.x += pk * vt[i].x; o.y += pk * vt[i].y; o.z += pk * vt[i].z; o.w += pk * vt[i].w;
-      }
-    }
-    *reinterpret_cast<float4*>(&part[rg][pq4]) = o;
-  }
-  __syncthreads();
-  if (tid < 64) {
-    float v = 0.f;
-#pragma unroll
-    for (int g2 = 0; g2 < 32; g2++) v += part[g2][tid];                 // row-group order fixed
-    v += expf(sc[npast] - m) * qkv[128 + tid];                          // the new token's own value
-    att[tid] = v / l;
-  }
-  __syncthreads();
-  WB_STAMP(6);
-  // ---- plane h, row r = att Wo[head h rows, :]
-  float ov[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < RPG; i++) {
-    const float av = att[jb + i];
-    ov[0] += av * wo[i].x; ov[1] += av * wo[i].y; ov[2] += av * wo[i].z; ov[3] += av * wo[i].w;
-  }
-  if (p5 && jg > 0)                                 // (the QKV partials in `red` are dead)
-    *reinterpret_cast<float4*>(&red[(jg - 1) * d + cf * 4]) = make_float4(ov[0], ov[1], ov[2], ov[3]);
-  __syncthreads();
-  if (jg == 0) {
-#pragma unroll
-    for (int g2 = 1; g2 < G; g2++) {
-      const float4 t = *reinterpret_cast<const float4*>(&red[(g2 - 1) * d + cf * 4]);
-      ov[0] += t.x; ov[1] += t.y; ov[2] += t.z; ov[3] += t.w;
-    }
-    *reinterpret_cast<float4*>(&a.P[((int64_t)h * a.S + r) * d + cf * 4]) = make_float4(ov[0], ov[1], ov[2], ov[3]);
-  }
-  // ---- the stores that are not on anybody's critical path: k * s, v of the new token into the cache, the folded stream
-  if (tid >= 64 && tid < 192) {
-    float* dst = (tid < 128 ? a.Kc : a.Vc) + (int64_t)slot_new * d + h * 64 + (tid & 63);
-    *dst = qkv[tid];
-  }
-  if (h == 0 && tid < d) a.x_out[(int64_t)r * d + tid] = xfold;
-  WB_STAMP(7);
-  WB_STAMP_FLUSH(a, 8);
+  dec_attn_body<DPL, false>(a, blockIdx.x, blockIdx.y, PsStep());
 }
-
-// ---------------------------------------------------------------------------------------------------------
-// Cross-attention block.  block = 512 threads, grid = (8, rows): block (h, r) owns head h of beam r (x = head keeps a
-// head's blocks on one XCD: the Wq / Wo slices and, for beams of the same window, the cached K/V cross the fabric once).
-//   LN(x + pending) -> q = . Wq[:, head h] + bq, * s -> scores against ALL of the window's cached K (C <= 768 keys)
-//   -> softmax -> . V -> . Wo[head h rows, :] -> plane h of [H][S][d]                              (mod.rs:482-490)
-// One launch instead of cross-attention (per 128-key chunk) + chunk combine + out-projection GEMV.
-//
-// A block streams ~0.6 MB (K and V of its head: 2 x C x 256 B, the Wq and Wo slices: 2 x d x 256 B) through ONE CU, so
-// the kernel is organised around bytes in flight.  K/V rows are read the coalesced way (16 lanes x 16 B = one 256-byte
-// head row, 32 rows per wave-instruction round) into a register ring that holds the WHOLE K of the head (6 tiles x 128
-// keys, 24 float4 per thread); every K register is refilled with the V row of the same key as soon as its score is
-// done, so the V stream is in flight under the softmax statistics.  Scores are 4-term partial dots reduced over the
-// 16 lanes of a row by DPP (no LDS transpose); the output is a float4 of partial sums per thread, reduced over the 32
-// row groups in a fixed order.  The Wq slice arrives under the fold + LayerNorm, the Wo slice under the scores.
 template <int DPL>
 __global__ __launch_bounds__(512) void dec_cross_fused_kernel(CrossFusedArgs a) {
-  constexpr int NT = 512;
-  constexpr int d = 64 * DPL;
-  constexpr int NWQ = d / 32;                      // Wq rows per thread
-  constexpr int CF = d / 4;
-  constexpr int G = CF <= 32 ? 8 : 4;
-  constexpr int RPG = 64 / G;
-  constexpr int KT = 128, NTILE = CROSS_FUSED_MAX_C / KT, SL = KT * 16 / NT;   // 6 tiles x 4 float4 slots per thread
-  static_assert(CROSS_FUSED_MAX_C % KT == 0 && SL * NT == KT * 16, "tile geometry");
-  __shared__ __attribute__((aligned(16))) float hs[d];
-  __shared__ __attribute__((aligned(16))) float red[8][64];
-  __shared__ __attribute__((aligned(16))) float qv[64];
-  __shared__ float sc[CROSS_FUSED_MAX_C];
-  __shared__ float pbuf[CROSS_FUSED_MAX_C];
-  __shared__ __attribute__((aligned(16))) float part[32][64];
-  __shared__ __attribute__((aligned(16))) float att[64];
-  __shared__ __attribute__((aligned(16))) float obuf[(G - 1) * d];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int h = blockIdx.x, r = blockIdx.y;
-  if (h >= a.n_head) return;
-  const int n_live = a.st[ST_N], w_row = a.st[a.lay.win + r];
-  const int dead = a.st[a.lay.dead + r];           // chained greedy decode: this row's window has already ended
-  // the window geometry of the first 8 windows rides with the state words -- as VECTOR loads (lane i holds window i; a
-  // scalar load here would stall the next kernel-argument wait, lgkmcnt being one counter): the K stream can then start
-  // one round trip after kernel entry instead of two (row -> window -> geometry)
-  const int wi8 = min(lane & 7, a.lay.W - 1);
-  const int vC8 = a.win_C[wi8], vR8 = a.win_row0[wi8];
-  // ---- requested first (in order of use): fold operands, LayerNorm parameters, bias, the Wq slice
-  float xfold;
-  float gv[DPL], bv[DPL];
-  const int rg = tid >> 4, c4 = (tid & 15) * 4;
-  float4 wqr[NWQ];
-  {
-    const int c = tid < d ? tid : 0;
-    const float* pp = a.pend + (int64_t)r * d + c;
-    const int64_t plane = (int64_t)a.S * d;
-    float v = a.x_in[(int64_t)r * d + c];
-    constexpr int FP = 16;
-    float t[FP];
-    float accp = 0.f;
-    if (a.KSp > 0) {
-      accp = a.pbias[c];
-#pragma unroll
-      for (int j = 0; j < FP; j++) t[j] = pp[(int64_t)min(j, a.KSp - 1) * plane];
-    }
-    if (wave == 0) {
-#pragma unroll
-      for (int i = 0; i < DPL; i++) { gv[i] = a.ln_g[lane + 64 * i]; bv[i] = a.ln_b[lane + 64 * i]; }
-    }
-    {
-      const float* wp = a.Wq + (int64_t)rg * d + h * 64 + c4;
-#pragma unroll
-      for (int i = 0; i < NWQ; i++) wqr[i] = *reinterpret_cast<const float4*>(wp + (int64_t)(32 * i) * d);
-    }
-    if (r >= n_live || dead) return;               // (block-uniform; the first wait of the kernel)
-    if (a.KSp > 0) {
-#pragma unroll
-      for (int j = 0; j < FP; j++) accp += (j < a.KSp) ? t[j] : 0.f;
-      for (int sp = FP; sp < a.KSp; sp += FP) {
-#pragma unroll
-        for (int j = 0; j < FP; j++) t[j] = pp[(int64_t)min(sp + j, a.KSp - 1) * plane];
-#pragma unroll
-        for (int j = 0; j < FP; j++) accp += (sp + j < a.KSp) ? t[j] : 0.f;
-      }
-      v += accp;                                   // x + (bias + partials), s ascending  (mod.rs:346-348)
-    }
-    xfold = v;
-    if (tid < d) hs[tid] = v;
-  }
-  const float qbias = tid < 64 ? a.bq[h * 64 + tid] : 0.f;
-  // ---- the head's cached K, all of it, into the register ring (key = tile * 128 + rg + 32 * slot; quad c4)
-  int C_w, row0_w;
-  {
-    const int ws = __builtin_amdgcn_readfirstlane(w_row);
-    if (ws < 8) { C_w = __builtin_amdgcn_readlane(vC8, ws); row0_w = __builtin_amdgcn_readlane(vR8, ws); }
-    else { C_w = a.win_C[ws]; row0_w = a.win_row0[ws]; }
-  }
-  const int C = min(C_w, CROSS_FUSED_MAX_C);
-  // uniform base + 32-bit per-lane offsets; keys past C re-read row C - 1 (their scores are never stored and their
-  // probabilities are zero), so every load is unconditional: no predicate sits between two requests
-  const float* Kh = a.ckv + (int64_t)row0_w * a.ldkv + a.koff + h * 64;                  // K pre-scaled at projection time
-  const float* Vh = Kh + d;
-  float4 kv[NTILE][SL];
-#pragma unroll
-  for (int t = 0; t < NTILE; t++)
-#pragma unroll
-    for (int i = 0; i < SL; i++) {
-      const int key = min(t * KT + rg + 32 * i, C - 1);
-      kv[t][i] = *reinterpret_cast<const float4*>(Kh + (key * a.ldkv + c4));
-    }
-  __syncthreads();
-  if (wave == 0) ln_row_lds<DPL>(hs, d, lane, gv, bv, a.ln_eps, a.ln_inside);
-  __syncthreads();
-  // ---- q = (cross_attn_ln(x) Wq + bq) * s for head h  (mod.rs:483, :506-509)
-  {
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < NWQ; i++) {
-      const float xv = hs[rg + 32 * i];
-      acc[0] += xv * wqr[i].x; acc[1] += xv * wqr[i].y; acc[2] += xv * wqr[i].z; acc[3] += xv * wqr[i].w;
-    }
-#pragma unroll
-    for (int c = 0; c < 4; c++) { acc[c] = xor16_sum(acc[c]); acc[c] = xor32_sum(acc[c]); }
-    if (lane < 16) *reinterpret_cast<float4*>(&red[wave][c4]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-  }
-  __syncthreads();   // (also keeps the loads below behind the Wq registers' last use)
-  // ---- requested now: the Wo slice (consumed last)
-  const int cf = tid % CF, jg = tid / CF;
-  const bool p5 = jg < G;
-  const int jb = (p5 ? jg : 0) * RPG;
-  float4 wo[RPG];
-  {
-    const float* wp = a.Wo + (int64_t)(h * 64 + jb) * d + cf * 4;
-#pragma unroll
-    for (int i = 0; i < RPG; i++) wo[i] = *reinterpret_cast<const float4*>(wp + (int64_t)i * d);
-  }
-  if (tid < 64) {
-    float v = 0.f;
-#pragma unroll
-    for (int w8 = 0; w8 < 8; w8++) v += red[w8][tid];                   // wave order fixed
-    qv[tid] = (v + qbias) * a.scale;
-  }
-  __syncthreads();
-  // ---- scores: partial dot over this thread's quad, summed over the 16 lanes of the key row; the register then
-  // takes the V row of the same key
-  {
-    const float4 q4 = *reinterpret_cast<const float4*>(&qv[c4]);
-#pragma unroll
-    for (int t = 0; t < NTILE; t++)
-#pragma unroll
-      for (int i = 0; i < SL; i++) {
-        const int key = t * KT + rg + 32 * i;
-        float s = q4.x * kv[t][i].x + q4.y * kv[t][i].y + q4.z * kv[t][i].z + q4.w * kv[t][i].w;
-        s += dpp_f<DPP_QUAD_XOR1, 0xF>(0.f, s);
-        s += dpp_f<DPP_QUAD_XOR2, 0xF>(0.f, s);
-        s += dpp_f<DPP_ROW_HALF_MIRROR, 0xF>(0.f, s);
-        s += dpp_f<DPP_ROW_MIRROR, 0xF>(0.f, s);
-        if ((tid & 15) == 0 && key < C) sc[key] = s;
-        kv[t][i] = *reinterpret_cast<const float4*>(Vh + (min(key, C - 1) * a.ldkv + c4));
-      }
-  }
-  __syncthreads();
-  // softmax statistics, redundantly per wave (no extra barrier); then the probabilities, two keys per thread
-  float m = -INFINITY;
-  for (int j = lane; j < C; j += 64) m = fmaxf(m, sc[j]);
-  m = wave_max(m);
-  float l = 0.f;
-  for (int j = lane; j < C; j += 64) l += expf(sc[j] - m);
-  l = wave_sum(l);
-  for (int j = tid; j < C; j += NT) pbuf[j] = expf(sc[j] - m);
-  __syncthreads();
-  // ---- o[c4 .. c4 + 3] partial over this thread's keys (tile, slot ascending), then over the 32 row groups
-  {
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int t = 0; t < NTILE; t++)
-#pragma unroll
-      for (int i = 0; i < SL; i++) {
-        const int key = t * KT + rg + 32 * i;
-        const float pk = key < C ? pbuf[key] : 0.f;
-        o.x += pk * kv[t][i].x; o.y += pk * kv[t][i].y; o.z += pk * kv[t][i].z; o.w += pk * kv[t][i].w;
-      }
-    *reinterpret_cast<float4*>(&part[rg][c4]) = o;
-  }
-  __syncthreads();
-  if (tid < 64) {
-    float v = 0.f;
-#pragma unroll
-    for (int g2 = 0; g2 < 32; g2++) v += part[g2][tid];                 // row-group order fixed
-    att[tid] = v / l;
-  }
-  __syncthreads();
-  // ---- plane h, row r = att Wo[head h rows, :]
-  float ov[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < RPG; i++) {
-    const float av = att[jb + i];
-    ov[0] += av * wo[i].x; ov[1] += av * wo[i].y; ov[2] += av * wo[i].z; ov[3] += av * wo[i].w;
-  }
-  if (p5 && jg > 0) *reinterpret_cast<float4*>(&obuf[(jg - 1) * d + cf * 4]) = make_float4(ov[0], ov[1], ov[2], ov[3]);
-  __syncthreads();
-  if (jg == 0) {
-#pragma unroll
-    for (int g2 = 1; g2 < G; g2++) {
-      const float4 t = *reinterpret_cast<const float4*>(&obuf[(g2 - 1) * d + cf * 4]);
-      ov[0] += t.x; ov[1] += t.y; ov[2] += t.z; ov[3] += t.w;
-    }
-    *reinterpret_cast<float4*>(&a.P[((int64_t)h * a.S + r) * d + cf * 4]) = make_float4(ov[0], ov[1], ov[2], ov[3]);
-  }
-  if (h == 0 && tid < d) a.x_out[(int64_t)r * d + tid] = xfold;      // the folded stream, off the critical path
+  dec_cross_body<DPL, false>(a, blockIdx.x, blockIdx.y, PsStep());
 }
 
 }  // namespace

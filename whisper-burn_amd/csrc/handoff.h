@@ -1,0 +1,120 @@
+// Cross-workgroup hand-offs INSIDE one launch (the persistent decode kernel, decode_persist.hip).
+//
+// gfx950 has 8 XCDs with private, mutually non-coherent L2s, and a CU's vector L1 is never refreshed by another CU's
+// stores.  The protocol used here is the write-through form of MI355X_MICROARCH.md "Workgroup dispatch, XCD placement &
+// inter-workgroup visibility" / cdna_hip_programming.md section 6, Guideline 16 (R1), in its COUNTER form:
+//
+//   producer   payload with `sc1` (write-through, agent-scope) stores  ->  EVERY storing wave `s_waitcnt vmcnt(0)`  ->
+//              __syncthreads()  ->  ONE lane: relaxed agent-scope atomic add on the consumers' arrival counter
+//   consumer   ONE lane polls that ONE word with relaxed agent-scope loads (+ s_sleep)  ->  __syncthreads()  ->
+//              payload with `sc1` loads (they bypass the L1; "sc1 loads may replace the acquire only when the producer
+//              stored sc1")
+//
+// Counters are monotonic within a launch (target = (epoch + 1) x arrivals per epoch) and zeroed by the host before
+// every launch.  Every spin is bounded: on give-up the error word is set and every block leaves the kernel.
+// Results never depend on dispatch order, timing or block -> XCD placement.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wb {
+
+// (the functional model tools/hipemu predefines these two hooks; everything else in this file is plain HIP)
+#ifndef WB_DRAIN_VMEM
+#define WB_DRAIN_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")   // inline asm: invisible to the waitcnt pass
+#endif
+#ifndef WB_LAUNCH_COOP
+#define WB_LAUNCH_COOP(kernel, grid, block, shmem, stream, arg) \
+  [&]() { void* _args[] = {(void*)&(arg)}; return hipLaunchCooperativeKernel((const void*)(kernel), grid, block, _args, shmem, stream); }()
+#endif
+
+typedef unsigned hx_u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- sc1 (agent-scope, L1-bypassing / write-through) accesses -----------------------------------------------------
+template <bool SC1>
+__device__ __forceinline__ float ld_f(const float* p) {
+  if constexpr (SC1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool SC1>
+__device__ __forceinline__ int ld_i(const int* p) {
+  if constexpr (SC1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool SC1>
+__device__ __forceinline__ void st_f(float* p, float v) {
+  if constexpr (SC1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+__device__ __forceinline__ void st_i_sc1(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// 16-byte accesses go through a raw buffer resource (aux = 16 selects sc1 on gfx950); `base` must be 16-byte aligned
+// and the byte offset < 4 GiB
+struct Buf16 {
+  __amdgpu_buffer_rsrc_t r;
+  __device__ __forceinline__ explicit Buf16(const void* base)
+      : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000)) {}
+};
+template <bool SC1>
+__device__ __forceinline__ float4 ld_f4(const float* base, const Buf16& b, uint32_t elem_off) {
+  if constexpr (SC1) {
+    const hx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b.r, elem_off * 4u, 0, 16);
+    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+  } else {
+    return *reinterpret_cast<const float4*>(base + elem_off);
+  }
+}
+template <bool SC1>
+__device__ __forceinline__ void st_f4(float* base, const Buf16& b, uint32_t elem_off, float4 v) {
+  if constexpr (SC1) {
+    hx_u32x4 u;
+    u[0] = __float_as_uint(v.x); u[1] = __float_as_uint(v.y); u[2] = __float_as_uint(v.z); u[3] = __float_as_uint(v.w);
+    __builtin_amdgcn_raw_buffer_store_b128(u, b.r, elem_off * 4u, 0, 16);
+  } else {
+    *reinterpret_cast<float4*>(base + elem_off) = v;
+  }
+}
+
+// ---- arrival counters ---------------------------------------------------------------------------------------------
+constexpr unsigned HX_SPIN_LIMIT = 40u * 1000u * 1000u;     // polls before a wait gives up (~ seconds): a bug, not a wait
+
+// Control words of one persistent launch (device memory, zeroed / initialised by the host before the launch)
+enum { HX_STOP = 0,        // first chain step that must NOT run (INT_MAX while the decode goes on)
+       HX_ERR = 1,         // != 0: a wait gave up (value = 1 + index of the counter) -- every block leaves
+       HX_NDONE = 2,       // rows finished so far
+       HX_HDR = 8 };       // counters start here
+
+// Publish: call with ALL threads of the block after the role's last payload store.
+__device__ __forceinline__ void hx_arrive(unsigned* ctr) {
+  WB_DRAIN_VMEM();                     // every storing wave: its write-through stores have left the CU
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Wait until *ctr >= target.  Returns false when the decode was stopped at or before `step` (every window has ended)
+// or a wait anywhere gave up: the caller leaves the kernel without arriving anywhere.  Call with ALL threads.
+__device__ __forceinline__ bool hx_wait(const unsigned* ctr, unsigned target, const int* ctl, int step, int ctr_index,
+                                        int* lds_flag) {
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    unsigned spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (__hip_atomic_load(ctl + HX_STOP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= step ||
+          __hip_atomic_load(ctl + HX_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
+      if (++spins > HX_SPIN_LIMIT) {
+        __hip_atomic_store(const_cast<int*>(ctl) + HX_ERR, 1 + ctr_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (ok && __hip_atomic_load(ctl + HX_STOP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= step) ok = 0;
+    *lds_flag = ok;
+  }
+  __syncthreads();
+  const int ok = *lds_flag;
+  __syncthreads();                     // (the flag word is reused by the next wait)
+  return ok != 0;
+}
+
+}  // namespace wb

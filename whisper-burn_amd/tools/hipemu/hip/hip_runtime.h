@@ -7,8 +7,11 @@
 // they reach a block barrier (__syncthreads) or a wave-collective operation (DPP, v_readlane, v_permlane*_swap,
 // MFMA, ...), where the 64 lanes of the wave exchange operands exactly as the instruction does (lane / row /
 // bank semantics of the ISA; the MFMA register layouts of the CDNA matrix cores).  __shared__ variables are
-// statics (one block runs at a time).  Device memory is host memory; streams are synchronous; stream capture
-// records closures that hipGraphLaunch replays.
+// thread-local statics: an ordinary launch runs all its blocks on the calling thread, one at a time; a CO-RESIDENT
+// launch (hipemu::launch_coop, the model of a cooperative / persistent grid whose blocks wait for one another on
+// device-scope counters) gives every block its own OS thread -- hence its own LDS -- and passes a baton between
+// them, so exactly one block runs at any time and a block that spins (s_sleep) hands the baton on.
+// Device memory is host memory; streams are synchronous; stream capture records closures that hipGraphLaunch replays.
 //
 // What it does NOT model: timing, caches, memory ordering between blocks, LDS capacity, register pressure.
 // Code that relies on the lock-step of a wave WITHOUT a collective or a barrier (wave-local LDS exchange) must
@@ -32,7 +35,7 @@
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
-#define __shared__ static
+#define __shared__ static thread_local
 #define __align__(n) __attribute__((aligned(n)))
 #define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(hipemu::dyn_shared());
 #define __HIP_MEMORY_SCOPE_SYSTEM 5
@@ -43,6 +46,10 @@
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
 #define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
 #define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), (order))
+// hooks of the engine's cross-block hand-off helpers (csrc/wave_ops.h defines the gfx950 forms unless these exist)
+#define WB_DRAIN_VMEM() __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#define WB_LAUNCH_COOP(kernel, grid, block, shmem, stream, arg) \
+  (hipemu::launch_coop(kernel, dim3(grid), dim3(block), (size_t)(shmem), stream, arg), hipSuccess)
 
 struct dim3 {
   unsigned x, y, z;
@@ -116,24 +123,38 @@ hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t);
 hipError_t hipGraphDestroy(hipGraph_t);
 hipError_t hipGraphExecDestroy(hipGraphExec_t);
 hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int);
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 16 };
+hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t attr, int device);   // CU count: HIPEMU_CUS (default 256)
+// resident blocks per CU of a kernel: the model has no registers or LDS budget -- HIPEMU_BLOCKS_PER_CU (default 1)
+hipError_t hipemu_occupancy(int* blocks_per_cu);
+#define hipOccupancyMaxActiveBlocksPerMultiprocessor(out, kernel, block, shmem) hipemu_occupancy(out)
 
 // ---- execution model ----------------------------------------------------------------------------------------
 namespace hipemu {
 struct Fiber;
 struct ThreadCtx { dim3 tidx, bidx, bdim, gdim; };
-extern ThreadCtx* g_tc;   // the running fiber's coordinates
+extern thread_local ThreadCtx* g_tc;   // the running fiber's coordinates
 void* dyn_shared();
 void syncthreads();
 enum Op { OP_WAVE_BARRIER = 1, OP_READFIRSTLANE, OP_READLANE, OP_DPP, OP_PERMLANE32_SWAP, OP_PERMLANE16_SWAP,
           OP_MFMA_F32_32X32X2, OP_MFMA_BF16_32X32X16, OP_SHFL, OP_SHFL_XOR, OP_BALLOT };
 // hands the calling lane's operands to the wave and returns when the collective has been executed
 void wave_op(int op, const void* in0, const void* in1, const void* in2, void* out, int i0, int i1, int i2, int i3);
-void enqueue(hipStream_t st, std::function<void()> body, dim3 grid, dim3 block, size_t shmem, hipEvent_t e0, hipEvent_t e1);
+void enqueue(hipStream_t st, std::function<void()> body, dim3 grid, dim3 block, size_t shmem, hipEvent_t e0, hipEvent_t e1,
+             bool coresident = false);
+// a spinning thread gives way: inside a co-resident launch the block's baton moves on once no thread of the block
+// can run; in an ordinary launch (blocks run to completion one after another) a spin can never be satisfied -> abort
+void spin_yield();
 
 template <class... P, class... A>
 void launch(void (*k)(P...), dim3 g, dim3 b, size_t sh, hipStream_t st, hipEvent_t e0, hipEvent_t e1, A&&... a) {
   std::tuple<std::decay_t<P>...> args(std::forward<A>(a)...);
   enqueue(st, [k, args]() { std::apply(k, args); }, g, b, sh, e0, e1);
+}
+template <class... P, class... A>
+void launch_coop(void (*k)(P...), dim3 g, dim3 b, size_t sh, hipStream_t st, A&&... a) {
+  std::tuple<std::decay_t<P>...> args(std::forward<A>(a)...);
+  enqueue(st, [k, args]() { std::apply(k, args); }, g, b, sh, nullptr, nullptr, true);
 }
 }  // namespace hipemu
 
@@ -185,6 +206,22 @@ template <class T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *
 template <class T> static inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <class T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 template <class T> static inline T atomicCAS(T* p, T c, T v) { T o = *p; if (o == c) *p = v; return o; }
+
+// ---- buffer resources (raw 16-byte loads / stores with cache-policy bits: plain memory here) ---------------------
+struct hipemu_rsrc { char* base; };
+typedef hipemu_rsrc __amdgpu_buffer_rsrc_t;
+typedef unsigned hipemu_u32x4 __attribute__((ext_vector_type(4)));
+static inline hipemu_rsrc hipemu_make_buffer_rsrc(const void* p, int, int, int) { return hipemu_rsrc{(char*)p}; }
+static inline hipemu_u32x4 hipemu_raw_buffer_load_b128(hipemu_rsrc r, unsigned voff, unsigned soff, int) {
+  hipemu_u32x4 v; memcpy(&v, r.base + voff + soff, 16); return v;
+}
+static inline void hipemu_raw_buffer_store_b128(hipemu_u32x4 v, hipemu_rsrc r, unsigned voff, unsigned soff, int) {
+  memcpy(r.base + voff + soff, &v, 16);
+}
+#define __builtin_amdgcn_make_buffer_rsrc(p, stride, n, flags) hipemu_make_buffer_rsrc((const void*)(p), stride, n, flags)
+#define __builtin_amdgcn_raw_buffer_load_b128 hipemu_raw_buffer_load_b128
+#define __builtin_amdgcn_raw_buffer_store_b128 hipemu_raw_buffer_store_b128
+#define __builtin_amdgcn_s_sleep(n) hipemu::spin_yield()
 
 // ---- wave collectives (the builtins of the gfx950 target, by their ISA semantics) ------------------------------
 typedef unsigned hipemu_u32x2 __attribute__((ext_vector_type(2)));

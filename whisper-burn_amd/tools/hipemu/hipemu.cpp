@@ -2,6 +2,8 @@
 // See hip/hip_runtime.h for what is modelled and what is not.  TEST INFRASTRUCTURE -- never part of the product.
 #include <hip/hip_runtime.h>
 #include <execinfo.h>
+#include <pthread.h>
+#include <semaphore.h>
 #include <signal.h>
 #include <sys/mman.h>
 #include <unistd.h>
@@ -19,7 +21,7 @@ struct ihipGraphExec { std::vector<std::function<void()>> nodes; };
 
 namespace hipemu {
 
-enum { RUNNABLE = 0, AT_BARRIER = 1, AT_WAVE = 2, DONE = 3 };
+enum { RUNNABLE = 0, AT_BARRIER = 1, AT_WAVE = 2, DONE = 3, AT_SPIN = 4 };
 constexpr size_t STACK_BYTES = 256 << 10;
 
 // A fiber switch is the callee-saved register file and the stack pointer (glibc's swapcontext makes a signal-mask
@@ -65,14 +67,35 @@ struct Fiber {
   int imm[4] = {0, 0, 0, 0};
 };
 
-ThreadCtx* g_tc = nullptr;
-static Fiber* g_cur = nullptr;
-static Ctx g_sched;
-static std::vector<Fiber*> g_fibers;
-static const std::function<void()>* g_body = nullptr;
-static std::vector<char> g_dyn;
+// Scheduler state is per OS thread: an ordinary launch runs on the caller's thread, a co-resident launch runs every
+// block on a thread of its own (so that the thread-local __shared__ statics are per block).
+thread_local ThreadCtx* g_tc = nullptr;
+static thread_local Fiber* g_cur = nullptr;
+static thread_local Ctx g_sched;
+static thread_local std::vector<Fiber*> g_fibers;
+static thread_local const std::function<void()>* g_body = nullptr;
+static thread_local std::vector<char> g_dyn;
 static std::recursive_mutex g_mu;
 static ihipStream_t g_null_stream;
+
+// ---- co-resident launches: one thread per block, a baton (per-block semaphores) serialises them ----------------
+struct CoopGrid {
+  int n = 0;
+  std::vector<sem_t> sem;
+  std::vector<char> live;
+  bool reverse = false;
+  unsigned long long yields = 0, yield_limit = 0;
+};
+static CoopGrid* g_coop = nullptr;                 // the co-resident launch in flight (launches are serialised by g_mu)
+static thread_local int g_coop_me = -1;            // this thread's block number in it
+
+static int coop_next(CoopGrid* g, int me) {        // next live block in the round-robin order, -1 if none but `me`
+  for (int i = 1; i <= g->n; i++) {
+    const int b = g->reverse ? ((me - i) % g->n + g->n) % g->n : (me + i) % g->n;
+    if (b != me && g->live[b]) return b;
+  }
+  return -1;
+}
 
 void* dyn_shared() { return g_dyn.data(); }
 
@@ -92,6 +115,11 @@ void wave_op(int op, const void* in0, const void* in1, const void* in2, void* ou
   yield_to_scheduler();
 }
 
+void spin_yield() {
+  g_cur->state = AT_SPIN;
+  yield_to_scheduler();
+}
+
 static void trampoline() {
   (*g_body)();
   g_cur->state = DONE;
@@ -102,6 +130,17 @@ static void trampoline() {
 static void die(const char* msg) {
   fprintf(stderr, "hipemu: %s\n", msg);
   abort();
+}
+
+// the running block cannot go on until another block acts: hand the baton to the next live block and wait for it
+static void coop_yield() {
+  CoopGrid* g = g_coop;
+  if (!g || g_coop_me < 0) die("a thread spins (s_sleep) in an ORDINARY launch: its blocks run one after another, so nothing can satisfy the wait -- launch co-resident");
+  const int nx = coop_next(g, g_coop_me);
+  if (nx < 0) die("co-resident launch: the last live block spins on a condition nobody can satisfy (deadlock)");
+  if (++g->yields > g->yield_limit) die("co-resident launch: yield budget exhausted (HIPEMU_YIELD_LIMIT) -- deadlock or livelock");
+  sem_post(&g->sem[nx]);
+  sem_wait(&g->sem[g_coop_me]);
 }
 
 // ---- the collectives ------------------------------------------------------------------------------------------
@@ -278,6 +317,15 @@ static void run_block(const std::function<void()>& body, dim3 grid, dim3 block, 
         if (parked) { run_collective(lane, n_lanes); again = true; progress = true; }
       }
     }
+    // no wave can run: threads that spin on another block's progress give way first (a block barrier must not open
+    // while a thread of the block is still on its way to it)
+    bool spin = false;
+    for (int t = 0; t < nt; t++) spin |= g_fibers[t]->state == AT_SPIN;
+    if (spin) {
+      coop_yield();
+      for (int t = 0; t < nt; t++) if (g_fibers[t]->state == AT_SPIN) g_fibers[t]->state = RUNNABLE;
+      continue;
+    }
     // every wave is now at the block barrier or finished
     bool any = false;
     for (int t = 0; t < nt; t++) any |= g_fibers[t]->state == AT_BARRIER;
@@ -335,12 +383,56 @@ static void run_grid(const std::function<void()>& body, dim3 grid, dim3 block, s
   }
 }
 
-void enqueue(hipStream_t st, std::function<void()> body, dim3 grid, dim3 block, size_t shmem, hipEvent_t e0, hipEvent_t e1) {
+// co-resident launch: every block on a thread of its own (own thread-local LDS, own fibers); the baton starts at block 0
+struct CoopArg { const std::function<void()>* body; dim3 grid, block; size_t shmem; int b; CoopGrid* g; };
+static void* coop_thread(void* p) {
+  CoopArg* a = (CoopArg*)p;
+  CoopGrid* g = a->g;
+  g_coop_me = a->b;
+  sem_wait(&g->sem[a->b]);                          // my first turn
+  if (g_dyn.size() < a->shmem + 16) g_dyn.resize(a->shmem + 16);
+  const unsigned long long b = (unsigned long long)a->b;
+  run_block(*a->body, a->grid, a->block, dim3((unsigned)(b % a->grid.x), (unsigned)((b / a->grid.x) % a->grid.y),
+                                              (unsigned)(b / ((unsigned long long)a->grid.x * a->grid.y))));
+  for (Fiber* f : g_fibers) { munmap(f->stack, STACK_BYTES); delete f; }
+  g_fibers.clear();
+  g->live[a->b] = 0;
+  const int nx = coop_next(g, a->b);
+  if (nx >= 0) sem_post(&g->sem[nx]);               // the baton moves on; the last block to finish just leaves
+  return nullptr;
+}
+static void run_grid_coop(const std::function<void()>& body, dim3 grid, dim3 block, size_t shmem) {
+  const unsigned long long nb = (unsigned long long)grid.x * grid.y * grid.z;
+  if (nb > 4096) die("co-resident launch with more than 4096 blocks");
+  CoopGrid g;
+  g.n = (int)nb; g.sem.resize(nb); g.live.assign(nb, 1);
+  { const char* e = getenv("HIPEMU_ORDER"); g.reverse = e && e[0] == 'r'; }
+  { const char* e = getenv("HIPEMU_YIELD_LIMIT"); g.yield_limit = e ? strtoull(e, nullptr, 10) : 200000000ull; }
+  for (auto& s : g.sem) sem_init(&s, 0, 0);
+  std::vector<CoopArg> args(nb);
+  std::vector<pthread_t> th(nb);
+  pthread_attr_t at; pthread_attr_init(&at); pthread_attr_setstacksize(&at, 1 << 20);
+  g_coop = &g;
+  for (unsigned long long b = 0; b < nb; b++) {
+    args[b] = CoopArg{&body, grid, block, shmem, (int)b, &g};
+    if (pthread_create(&th[b], &at, coop_thread, &args[b])) die("pthread_create failed");
+  }
+  pthread_attr_destroy(&at);
+  sem_post(&g.sem[g.reverse ? nb - 1 : 0]);
+  for (unsigned long long b = 0; b < nb; b++) pthread_join(th[b], nullptr);
+  g_coop = nullptr;
+  for (auto& s : g.sem) sem_destroy(&s);
+}
+
+void enqueue(hipStream_t st, std::function<void()> body, dim3 grid, dim3 block, size_t shmem, hipEvent_t e0, hipEvent_t e1,
+             bool coresident) {
   std::lock_guard<std::recursive_mutex> lk(g_mu);
   install_segv_trace();
   if (!st) st = &g_null_stream;
   if (block.x * block.y * block.z == 0 || grid.x * grid.y * grid.z == 0) return;
-  auto node = [body, grid, block, shmem]() { run_grid(body, grid, block, shmem); };
+  auto node = [body, grid, block, shmem, coresident]() {
+    if (coresident) run_grid_coop(body, grid, block, shmem); else run_grid(body, grid, block, shmem);
+  };
   if (st->capturing) { st->graph->nodes.push_back(node); return; }
   if (e0) e0->t_ms = now_ms();
   node();
@@ -461,3 +553,14 @@ hipError_t hipGraphLaunch(hipGraphExec_t ge, hipStream_t) {
 hipError_t hipGraphDestroy(hipGraph_t g) { delete g; return hipSuccess; }
 hipError_t hipGraphExecDestroy(hipGraphExec_t g) { delete g; return hipSuccess; }
 hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t attr, int) {
+  if (attr != hipDeviceAttributeMultiprocessorCount) return hipErrorInvalidValue;
+  const char* e = getenv("HIPEMU_CUS");
+  *v = e ? atoi(e) : 256;
+  return hipSuccess;
+}
+hipError_t hipemu_occupancy(int* blocks_per_cu) {
+  const char* e = getenv("HIPEMU_BLOCKS_PER_CU");
+  *blocks_per_cu = e ? atoi(e) : 1;
+  return hipSuccess;
+}
