@@ -155,6 +155,39 @@ struct CrossFusedArgs {
   float* P = nullptr;                                                             // out: planes [n_head][S][d] (out bias NOT added)
   unsigned long long* stamps = nullptr;
 };
+// ---- persistent flag-chained greedy decode (decode_persist.hip) --------------------------------------------------
+// ONE co-resident grid runs every sublayer of every step of the device-chained greedy loop: a block executes the
+// roles i = blockIdx.x, + gridDim.x, ... of a per-step role list in dependency order (self-attention block (head, row),
+// cross-attention block (head, row), MLP block (64 hidden units), logits tile (128 vocabulary columns), merge (row)),
+// streams each role's weights BEFORE it waits for the arrival counter of the role's producers, and publishes its output
+// planes with write-through stores (handoff.h).  No kernel boundary, no grid barrier, fixed summation orders.
+struct PsLayerArgs { AttnFusedArgs attn; CrossFusedArgs cross; MlpFusedArgs mlp; };
+enum { PSR_ATTN = 0, PSR_CROSS = 1, PSR_MLP = 2, PSR_LOGITS = 3, PSR_MERGE = 4 };
+struct PsRole { int kind, layer, a, b; };     // a: head / hidden slice / tile, b: row
+struct PersistArgs {
+  const PsLayerArgs* layers = nullptr;        // [n_layer] (device)
+  const PsRole* roles = nullptr; int n_roles = 0;   // one step's roles in dependency order (device)
+  int n_layer = 0, n_rows = 0, S = 0, d = 0, n_head = 0, nb_mlp = 0;
+  int* ctl = nullptr;                         // HX_* control words + arrival counters (device; set up by the host)
+  int step0 = 0, n_steps = 0;                 // first decode step of the chain, most steps to run
+  int mask_until_len = 0;                     // special-token mask while len <= this (transcribe.rs:271-275)
+  // logits role: LN(x_fin + b2 + sum P2) . E^T tile -> (best value, best id) per row and tile
+  const float* x_fin = nullptr; const float* P2 = nullptr; const float* b2_last = nullptr;
+  const float* ln_g = nullptr; const float* ln_b = nullptr; float ln_eps = 0.f; int ln_inside = 0;
+  const float* Et = nullptr; int vocab_ld = 0, V = 0; const float* mask = nullptr;
+  float* tstats = nullptr; int n_tiles = 0;   // [S][n_tiles][2]
+  // merge role: argmax over the tiles, chain bookkeeping, next step's embedding
+  int* gctl = nullptr; int* gtok = nullptr; int Lmax = 0, eot = 0;
+  const float* E = nullptr; const float* pos = nullptr; float* x0 = nullptr; int* tabs = nullptr;
+  int* dead = nullptr;                        // [S]: rows whose window has ended
+  unsigned long long* stamps = nullptr;       // optional timeline: [n_steps][n_roles][3] (role start, wait passed, done)
+};
+int ps_ctl_ints(int S, int n_layer);
+bool dec_persist_supported(int d, int n_rows);
+// grid: blocks of 512 threads that are co-resident on this device for (d, n_rows) -- 0 if the kernel cannot run
+int dec_persist_max_grid(int device, int d, int n_rows);
+int launch_dec_persist(hipStream_t st, const PersistArgs& a, int grid);
+
 constexpr int CROSS_FUSED_MAX_C = 768;   // keys per window the fused cross-attention block handles (n_audio_ctx / 2 = 750)
 void launch_dec_cross_fused(hipStream_t st, const CrossFusedArgs& a, int n_rows_hint);
 bool dec_fused_supported(int d);

@@ -24,7 +24,14 @@ struct PsStep {
   int n_rows = 0;                // rows of the chain (= windows: one beam per window)
   const int* dead = nullptr;     // [S]: rows whose window has ended (written by the merge role, sc1)
   int* lds_flag = nullptr;       // one LDS word for the wait's broadcast
+  unsigned long long* stamp = nullptr;   // optional timeline slot: when the wait was passed
 };
+// wait for the role's producers (all threads of the block); false: the decode was stopped -- leave the kernel
+__device__ __forceinline__ bool ps_wait(const PsStep& ps) {
+  const bool ok = hx_wait(ps.ctr, ps.target, ps.ctl, ps.step, ps.ctr_index, ps.lds_flag);
+  if (ps.stamp && threadIdx.x == 0) *ps.stamp = wall_clock64();
+  return ok;
+}
 
 // developer probe: tools/decode_probe.cpp builds this file with -DWB_STAMPS and prints the phase timeline of block 0
 #ifdef WB_STAMPS
@@ -232,11 +239,12 @@ __device__ __forceinline__ bool dec_mlp_body(const MlpFusedArgs& a, const int jb
         for (int i = 0; i < RPG; i++) w2[i] = *reinterpret_cast<const float4*>(wp + (int64_t)i * d);
       }
     };
+    const Buf16 pendb(a.pend);
     if constexpr (PS) {
       // persistent mode: nothing the block streams depends on its predecessor -- the weights are in flight (or
       // landed) while the block waits for the producers of its input planes; then the fold operands, L1 bypassed
       load_weights();
-      if (!hx_wait(ps.ctr, ps.target, ps.ctl, ps.step, ps.ctr_index, ps.lds_flag)) return false;
+      if (!ps_wait(ps)) return false;
     }
 #pragma unroll
     for (int i = 0; i < EPT; i++) { xv_fold[i] = ld_f<PS>(a.x_in + off[i]); acc0[i] = npl > 0 ? a.pbias[col[i]] : 0.f; }
@@ -250,7 +258,7 @@ __device__ __forceinline__ bool dec_mlp_body(const MlpFusedArgs& a, const int jb
       for (int j = 0; j < PC; j++)
         if (j < ch) {
 #pragma unroll
-          for (int i = 0; i < EPT; i++) t[j][i] = ld_f<PS>(a.pend + ((int64_t)min(j, npl - 1) * plane + poff[i]));
+          for (int i = 0; i < EPT; i++) t[j][i] = ld_fb<PS>(a.pend, pendb, (uint32_t)poff[i], (uint32_t)(min(j, npl - 1) * (int)plane));
         }
     }
     if constexpr (!PS) load_weights();
@@ -280,7 +288,7 @@ __device__ __forceinline__ bool dec_mlp_body(const MlpFusedArgs& a, const int jb
           for (int j = 0; j < PC; j++)
             if (j < ch) {
 #pragma unroll
-              for (int i = 0; i < EPT; i++) t[j][i] = ld_f<PS>(a.pend + ((int64_t)min(sp + j, npl - 1) * plane + poff[i]));
+              for (int i = 0; i < EPT; i++) t[j][i] = ld_fb<PS>(a.pend, pendb, (uint32_t)poff[i], (uint32_t)(min(sp + j, npl - 1) * (int)plane));
             }
         }
 #pragma unroll
@@ -459,9 +467,12 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
     if constexpr (PS) {
       // persistent mode: the first weight rounds are in flight (or landed) while the block waits for the MLP planes
       load_weights();
-      if (!hx_wait(ps.ctr, ps.target, ps.ctl, ps.step, ps.ctr_index, ps.lds_flag)) return false;
+      if (!ps_wait(ps)) return false;
       dead = ld_i<true>(ps.dead + r);
     }
+    // (persistent mode: buffer loads -- the plane offset rides in the scalar offset, one lane offset for all planes)
+    const Buf16 pendb(a.pend);
+    const uint32_t pvo = (uint32_t)(r * d + c);
     float v = ld_f<PS>(a.x_in + ((int64_t)r * d + c));
     constexpr int FP = 32;                          // planes per round: 4 d / 64 <= 32 MLP planes in ONE round trip
     float t[FP];
@@ -469,7 +480,7 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
     if (a.KSp > 0) {
       accp = a.pbias[c];
 #pragma unroll
-      for (int j = 0; j < FP; j++) t[j] = ld_f<PS>(pp + (int64_t)min(j, a.KSp - 1) * plane);
+      for (int j = 0; j < FP; j++) t[j] = ld_fb<PS>(a.pend, pendb, pvo, (uint32_t)(min(j, a.KSp - 1) * (int)plane));
     }
     if constexpr (!PS) load_weights();
     if (r >= n_rows || dead) return true;          // (block-uniform; the first wait of the kernel)
@@ -478,7 +489,7 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
       for (int j = 0; j < FP; j++) accp += (j < a.KSp) ? t[j] : 0.f;
       for (int sp = FP; sp < a.KSp; sp += FP) {
 #pragma unroll
-        for (int j = 0; j < FP; j++) t[j] = ld_f<PS>(pp + (int64_t)min(sp + j, a.KSp - 1) * plane);
+        for (int j = 0; j < FP; j++) t[j] = ld_fb<PS>(a.pend, pendb, pvo, (uint32_t)(min(sp + j, a.KSp - 1) * (int)plane));
 #pragma unroll
         for (int j = 0; j < FP; j++) accp += (sp + j < a.KSp) ? t[j] : 0.f;
       }
@@ -763,17 +774,19 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
       // the WHOLE K of the head are in flight (or landed) while the block waits for the self-attention planes
       load_weights();
       load_keys();
-      if (!hx_wait(ps.ctr, ps.target, ps.ctl, ps.step, ps.ctr_index, ps.lds_flag)) return false;
+      if (!ps_wait(ps)) return false;
       dead = ld_i<true>(ps.dead + r);
     }
+    const Buf16 pendb(a.pend);
+    const uint32_t pvo = (uint32_t)(r * d + c);
     float v = ld_f<PS>(a.x_in + ((int64_t)r * d + c));
-    constexpr int FP = 16;
+    constexpr int FP = PS ? 8 : 16;                 // (persistent mode: <= 8 head planes, the K ring owns the registers)
     float t[FP];
     float accp = 0.f;
     if (a.KSp > 0) {
       accp = a.pbias[c];
 #pragma unroll
-      for (int j = 0; j < FP; j++) t[j] = ld_f<PS>(pp + (int64_t)min(j, a.KSp - 1) * plane);
+      for (int j = 0; j < FP; j++) t[j] = ld_fb<PS>(a.pend, pendb, pvo, (uint32_t)(min(j, a.KSp - 1) * (int)plane));
     }
     if constexpr (!PS) load_weights();
     if (r >= n_live || dead) return true;          // (block-uniform; the first wait of the kernel)
@@ -782,7 +795,7 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
       for (int j = 0; j < FP; j++) accp += (j < a.KSp) ? t[j] : 0.f;
       for (int sp = FP; sp < a.KSp; sp += FP) {
 #pragma unroll
-        for (int j = 0; j < FP; j++) t[j] = ld_f<PS>(pp + (int64_t)min(sp + j, a.KSp - 1) * plane);
+        for (int j = 0; j < FP; j++) t[j] = ld_fb<PS>(a.pend, pendb, pvo, (uint32_t)(min(sp + j, a.KSp - 1) * (int)plane));
 #pragma unroll
         for (int j = 0; j < FP; j++) accp += (sp + j < a.KSp) ? t[j] : 0.f;
       }

@@ -1,0 +1,330 @@
+// Persistent, flag-chained greedy decode: ONE co-resident grid runs every sublayer of every decode step.
+//
+// Why: with a handful of live rows a decode step is a chain of 3 n_layer + 2 dependent sublayers, each of which streams
+// 0.2-0.6 MB of weights / cached K,V through ONE compute unit.  As separate launches (decode_fused.hip) every link pays its
+// dispatch, a memory round trip for its input planes, and -- the largest term -- the time a single CU needs to pull the
+// block's operands (~5 us of a ~10 us launch), none of which depends on the predecessor.  Here every role of a step is
+// resident at once: a block issues the loads of its weights (and, for cross-attention, of the window's whole cached K)
+// FIRST, then waits for the arrival counter of its producers, then folds their planes; the operand pull of sublayer
+// k + 1 runs under sublayer k.  The reference recomputes the whole decoder per token (/root/reference/src/transcribe.rs:
+// 253-307, src/model/mod.rs:345-350); the arithmetic of a step here is the arithmetic of the fused sublayer kernels
+// (decode_fused_bodies.h: same device templates, same fixed summation orders -> bit-reproducible).
+//
+// Roles of one step, in dependency order (a block runs roles blockIdx.x, + gridDim.x, ... of this list):
+//   per layer l: attn (head h, row r) x H R  ->  cross (h, r) x H R  ->  mlp (64-unit hidden slice j) x 4 d / 64
+//   logits (128-column vocabulary tile t) x ceil(V / 128)   ->   merge (row r) x R
+// Dependencies = arrival counters (handoff.h), monotonic within the launch:
+//   attn(0,.,r)  waits for merge(r) of the previous step (its x row)          c_x[r]       >= e
+//   attn(l,.,r)  waits for every MLP slice of layer l - 1                      c_mlp[l-1]   >= (e + 1) NB
+//   cross(l,.,r) waits for the H attention blocks of its row                   c_attn[l][r] >= (e + 1) H
+//   mlp(l,.)     waits for every cross-attention block of the layer            c_cross[l]   >= (e + 1) H R
+//   logits(t)    waits for every MLP slice of the last layer                   c_mlp[NL-1]  >= (e + 1) NB
+//   merge(r)     waits for every tile (8 counters, tile t arrives at t mod 8)  c_log[k]     >= (e + 1) n_k
+// A block never waits for a role with a larger index in the same step, and all blocks are co-resident (the host sizes
+// the grid from the occupancy query), so the smallest unfinished role can always run: no deadlock.  Reuse of the plane
+// buffers across steps is ordered by the same chain (a role arrives only after its last read).
+//
+// End of the decode: the merge role of the last window to end stores HX_STOP = first step that must not run; every wait
+// polls that word next to its counter, and a block that sees it leaves the kernel (without arriving).  Rows whose window
+// has ended are marked dead: their attention roles skip the work and arrive at once.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <vector>
+
+#include "decode.h"
+#include "decode_fused_bodies.h"
+#include "handoff.h"
+#include "wave_ops.h"
+
+namespace wb {
+namespace {
+
+using namespace fused;
+
+constexpr int PS_NT = 512;
+constexpr int PS_CT = 128;      // vocabulary columns per logits tile
+
+// ---- logits role: tile t of  ln(x + b2 + sum_j P2[j]) . E^T  (mod.rs:155-156), last position only -----------------
+// The E^T tile (d x 128 floats = d / 16 float4 per thread) is in flight before the wait.  Each block folds and
+// normalises the rows itself (R d (1 + NB) floats from L2).  Per row and tile the block leaves the best masked logit and
+// its id -- greedy needs the argmax only (log_softmax is monotone: transcribe.rs:276 with beam.rs k = 1).
+template <int MR, int DPL>
+__device__ __forceinline__ bool ps_logits_role(const PersistArgs& a, const int tile, const PsStep& ps) {
+  constexpr int d = 64 * DPL, NT = PS_NT, CT = PS_CT;
+  constexpr int NR = d / 16;                        // E^T rows per thread: k = 16 i + 2 wave + hh
+  constexpr int EPT = (MR * d + NT - 1) / NT;
+  constexpr int PCH = EPT <= 3 ? 8 : EPT <= 6 ? 4 : 2;
+  __shared__ __attribute__((aligned(16))) float xs[MR][d];
+  __shared__ __attribute__((aligned(16))) float red[8][MR][CT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, c4 = (lane & 31) * 4;
+  const int n0 = tile * CT;
+  float4 w[NR];
+  {
+    const bool col_ok = n0 + c4 < a.vocab_ld;      // lanes past the padded vocabulary re-read the tile's first columns
+    const float* wp = a.Et + (int64_t)(2 * wave + hh) * a.vocab_ld + n0 + (col_ok ? c4 : 0);
+#pragma unroll
+    for (int i = 0; i < NR; i++) w[i] = *reinterpret_cast<const float4*>(wp + (int64_t)(16 * i) * a.vocab_ld);
+  }
+  float gv[DPL], bv[DPL];
+#pragma unroll
+  for (int i = 0; i < DPL; i++) { gv[i] = a.ln_g[lane + 64 * i]; bv[i] = a.ln_b[lane + 64 * i]; }
+  const int use_mask = (ps.step + 1 <= a.mask_until_len) ? 1 : 0;          // transcribe.rs:271-275
+  float mk[MR * CT / NT > 0 ? MR * CT / NT : 1];
+#pragma unroll
+  for (int q = 0; q < MR * CT / NT; q++) {
+    const int col = n0 + ((tid + NT * q) & (CT - 1));
+    mk[q] = (use_mask && col < a.V) ? a.mask[col] : 0.f;
+  }
+  if (!ps_wait(ps)) return false;
+  {
+    // x + (bias + partial planes), plane order fixed (mod.rs:346-348): every load of a chunk of planes in flight together
+    int off[EPT], col[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; i++) {
+      int e = tid + NT * i;
+      if (e >= MR * d) e = tid;
+      off[i] = e; col[i] = e % d;
+    }
+    const int plane = a.S * d;
+    const Buf16 p2b(a.P2);
+    float v[EPT], acc[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; i++) { v[i] = ld_f<true>(a.x_fin + off[i]); acc[i] = a.b2_last[col[i]]; }
+    for (int sp = 0; sp < a.nb_mlp; sp += PCH) {
+      float t[PCH][EPT];
+#pragma unroll
+      for (int j = 0; j < PCH; j++)
+#pragma unroll
+        for (int i = 0; i < EPT; i++) t[j][i] = ld_fb<true>(a.P2, p2b, (uint32_t)off[i], (uint32_t)(min(sp + j, a.nb_mlp - 1) * plane));
+#pragma unroll
+      for (int j = 0; j < PCH; j++)
+#pragma unroll
+        for (int i = 0; i < EPT; i++) acc[i] += (sp + j < a.nb_mlp) ? t[j][i] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < EPT; i++) {
+      const int e = tid + NT * i;
+      if (e < MR * d) (&xs[0][0])[e] = v[i] + acc[i];
+    }
+  }
+  __syncthreads();
+  if (wave < MR) ln_row_lds<DPL>(xs[wave], d, lane, gv, bv, a.ln_eps, a.ln_inside);
+  __syncthreads();
+  float acc[MR][4];
+#pragma unroll
+  for (int r = 0; r < MR; r++) { acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < NR; i++) {
+    const int k = 16 * i + 2 * wave + hh;
+#pragma unroll
+    for (int r = 0; r < MR; r++) {
+      const float xv = xs[r][k];
+      acc[r][0] += xv * w[i].x; acc[r][1] += xv * w[i].y; acc[r][2] += xv * w[i].z; acc[r][3] += xv * w[i].w;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < MR; r++)
+#pragma unroll
+    for (int c = 0; c < 4; c++) acc[r][c] = xor32_sum(acc[r][c]);          // the two row halves of the wave
+  if (hh == 0) {
+#pragma unroll
+    for (int r = 0; r < MR; r++)
+      *reinterpret_cast<float4*>(&red[wave][r][c4]) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+  }
+  __syncthreads();
+  // column sums over the eight waves (fixed order), + mask; then one wave per row: best (value desc, id asc)
+  float* tilev = &xs[0][0];                         // [MR][CT] (the normalised rows are dead; MR d >= MR CT)
+  static_assert(d >= CT, "tile values alias the row buffer");
+#pragma unroll
+  for (int q = 0; q < MR * CT / NT; q++) {
+    const int e = tid + NT * q, r = e / CT, c = e & (CT - 1);
+    float v = 0.f;
+#pragma unroll
+    for (int w8 = 0; w8 < 8; w8++) v += red[w8][r][c];
+    v += mk[q];
+    if (n0 + c >= a.V) v = -INFINITY;
+    tilev[r * CT + c] = v;
+  }
+  __syncthreads();
+  if (wave < MR && wave < ps.n_rows) {
+    const int r = wave;
+    const float v0 = tilev[r * CT + lane], v1 = tilev[r * CT + lane + 64];
+    float bvv; int bi;
+    if (better(v0, lane, v1, lane + 64)) { bvv = v0; bi = lane; } else { bvv = v1; bi = lane + 64; }
+    wave_argmax(bvv, bi);
+    if (lane == 0) {
+      float* ts = a.tstats + ((int64_t)r * a.n_tiles + tile) * 2;
+      st_f<true>(ts, bvv);
+      st_f<true>(ts + 1, __int_as_float(n0 + bi));
+    }
+  }
+  return true;
+}
+
+// ---- merge role: row r's argmax over the tiles, the chain's bookkeeping, the next step's embedding -------------------
+// (what dec_topk_merge_kernel + chained_update do between two launches; transcribe.rs:235-241 for the end of a row)
+__device__ __forceinline__ bool ps_merge_role(const PersistArgs& a, const int r, const int e, const PsStep& ps0,
+                                              const unsigned* clog, const int* n_per_ctr) {
+  __shared__ float redv[8];
+  __shared__ int redi[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  PsStep ps = ps0;
+  for (int k = 0; k < 8; k++) {                     // every tile of this step has arrived (8 sharded counters)
+    if (n_per_ctr[k] == 0) continue;
+    ps.ctr = clog + k; ps.target = (unsigned)(e + 1) * (unsigned)n_per_ctr[k]; ps.ctr_index = 1000 + k;
+    if (!hx_wait(ps.ctr, ps.target, ps.ctl, ps.step, ps.ctr_index, ps.lds_flag)) return false;
+  }
+  if (ps.stamp && threadIdx.x == 0) *ps.stamp = wall_clock64();
+  const int len = ps.step + 1;                      // tokens in the row so far; the new one lands at index len
+  const int fin_now = ld_i<true>(a.dead + r);
+  const int tok_prev = ld_i<true>(a.gctl + GC_HDR + r);
+  float bv = -INFINITY; int bi = 0x7fffffff;
+  for (int t = tid; t < a.n_tiles; t += PS_NT) {
+    const float* ts = a.tstats + ((int64_t)r * a.n_tiles + t) * 2;
+    const float v = ld_f<true>(ts);
+    const int id = __float_as_int(ld_f<true>(ts + 1));
+    if (better(v, id, bv, bi)) { bv = v; bi = id; }
+  }
+  wave_argmax(bv, bi);
+  if (lane == 0) { redv[wave] = bv; redi[wave] = bi; }
+  __syncthreads();
+  float gv = redv[0]; int gi = redi[0];
+#pragma unroll
+  for (int j = 1; j < 8; j++)
+    if (better(redv[j], redi[j], gv, gi)) { gv = redv[j]; gi = redi[j]; }
+  const int finished = fin_now || gi == a.eot;
+  const int tok_next = fin_now ? tok_prev : gi;     // a finished row keeps its last token (its later argmax is stale)
+  if (tid == 0 && !fin_now) {
+    st_i_sc1(a.gctl + GC_HDR + r, gi);
+    a.gtok[r * a.Lmax + len] = gi;
+    a.gctl[GC_HDR + 2 * a.S + r] = len + 1;
+    if (gi == a.eot) {                              // transcribe.rs:235-241: the row has ended
+      a.gctl[GC_HDR + a.S + r] = 1;
+      st_i_sc1(a.dead + r, 1);
+      const unsigned n = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(a.ctl + HX_NDONE), 1u, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT) + 1u;
+      if ((int)n == ps.n_rows) st_i_sc1(a.ctl + HX_STOP, ps.step + 1);     // every window has ended: no further step
+    }
+  }
+  if (tid == 0 && r == 0) a.gctl[GC_STEP] = ps.step + 1;
+  if (len < a.Lmax) {
+    // next step: position len holds tok_next -> x0[r] = E[tok_next] + pos[len] (mod.rs:141-146); position tables
+    const Buf16 xb(a.x0);
+    const float4* ev = reinterpret_cast<const float4*>(a.E + (int64_t)tok_next * a.d);
+    const float4* pp = reinterpret_cast<const float4*>(a.pos + (int64_t)len * a.d);
+    for (int c = tid; c < (a.d >> 2); c += PS_NT) {
+      const float4 x = ev[c], y = pp[c];
+      st_f4<true>(a.x0, xb, (uint32_t)(r * a.d + 4 * c), make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w));
+    }
+    // (the persistent roles address the self-attention cache arithmetically; the tables are kept for host-driven steps
+    // that may follow the chain)
+    const int nstep = ps.step + 1;
+    int* tab_new = a.tabs + (size_t)(nstep & 1) * a.S * a.Lmax;
+    for (int p = tid; p <= len; p += PS_NT) tab_new[r * a.Lmax + p] = p * a.S + r;
+  }
+  (void)finished;
+  return true;
+}
+
+// ---- the grid ---------------------------------------------------------------------------------------------------------
+template <int DPL, int MR>
+__global__ __launch_bounds__(PS_NT) void dec_persist_kernel(PersistArgs a) {
+  __shared__ int wait_flag;
+  const int NL = a.n_layer, S = a.S, R = a.n_rows, H = a.n_head, NB = a.nb_mlp;
+  unsigned* const ctr = reinterpret_cast<unsigned*>(a.ctl + HX_HDR);
+  unsigned* const c_x = ctr;
+  unsigned* const c_attn = ctr + S;
+  unsigned* const c_cross = ctr + S + NL * S;
+  unsigned* const c_mlp = c_cross + NL;
+  unsigned* const c_log = c_mlp + NL;
+  int n_per_ctr[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) n_per_ctr[k] = (a.n_tiles + 7 - k) / 8;
+  for (int e = 0; e < a.n_steps; e++) {
+    for (int i = blockIdx.x; i < a.n_roles; i += gridDim.x) {
+      const PsRole role = a.roles[i];
+      PsStep ps;
+      ps.ctl = a.ctl; ps.step = a.step0 + e; ps.n_rows = R; ps.dead = a.dead; ps.lds_flag = &wait_flag;
+      unsigned long long* stp = a.stamps ? a.stamps + ((size_t)e * a.n_roles + i) * 3 : nullptr;
+      if (stp && threadIdx.x == 0) stp[0] = wall_clock64();
+      ps.stamp = stp ? stp + 1 : nullptr;
+      unsigned* out;
+      bool ok;
+      if (role.kind == PSR_ATTN) {
+        const AttnFusedArgs la = a.layers[role.layer].attn;
+        if (role.layer == 0) { ps.ctr = c_x + role.b; ps.target = (unsigned)e; ps.ctr_index = role.b; }
+        else { ps.ctr = c_mlp + role.layer - 1; ps.target = (unsigned)(e + 1) * NB; ps.ctr_index = 200 + role.layer - 1; }
+        ok = dec_attn_body<DPL, true>(la, role.a, role.b, ps);
+        out = c_attn + role.layer * S + role.b;
+      } else if (role.kind == PSR_CROSS) {
+        const CrossFusedArgs la = a.layers[role.layer].cross;
+        ps.ctr = c_attn + role.layer * S + role.b; ps.target = (unsigned)(e + 1) * H; ps.ctr_index = 300 + role.layer * S + role.b;
+        ok = dec_cross_body<DPL, true>(la, role.a, role.b, ps);
+        out = c_cross + role.layer;
+      } else if (role.kind == PSR_MLP) {
+        const MlpFusedArgs la = a.layers[role.layer].mlp;
+        ps.ctr = c_cross + role.layer; ps.target = (unsigned)(e + 1) * H * R; ps.ctr_index = 100 + role.layer;
+        ok = dec_mlp_body<MR, DPL, false, true>(la, role.a, ps);
+        out = c_mlp + role.layer;
+      } else if (role.kind == PSR_LOGITS) {
+        ps.ctr = c_mlp + NL - 1; ps.target = (unsigned)(e + 1) * NB; ps.ctr_index = 200 + NL - 1;
+        ok = ps_logits_role<MR, DPL>(a, role.a, ps);
+        out = c_log + (role.a & 7);
+      } else {
+        ok = ps_merge_role(a, role.b, e, ps, c_log, n_per_ctr);
+        out = c_x + role.b;
+      }
+      if (!ok) return;                               // the decode was stopped (or a wait gave up): leave
+      if (stp && threadIdx.x == 0) stp[2] = wall_clock64();
+      hx_arrive(out);
+    }
+  }
+}
+
+template <int DPL, int MR>
+int max_blocks_per_cu() {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (dec_persist_kernel<DPL, MR>), PS_NT, 0) != hipSuccess) return 0;
+  return nb;
+}
+
+}  // namespace
+
+int ps_ctl_ints(int S, int n_layer) { return HX_HDR + S + n_layer * S + 2 * n_layer + 8; }
+
+// d = 512 with more than 4 rows would need > 160 KB of LDS (every role's LDS is resident at once)
+bool dec_persist_supported(int d, int n_rows) {
+  if (n_rows < 1 || n_rows > 8) return false;
+  if (d == 128 || d == 384) return true;
+  return d == 512 && n_rows <= 4;
+}
+
+int dec_persist_max_grid(int device, int d, int n_rows) {
+  if (!dec_persist_supported(d, n_rows)) return 0;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) return 0;
+  int per = 0;
+  const bool big = n_rows > 4;
+  if (d == 128) per = big ? max_blocks_per_cu<2, 8>() : max_blocks_per_cu<2, 4>();
+  else if (d == 384) per = big ? max_blocks_per_cu<6, 8>() : max_blocks_per_cu<6, 4>();
+  else per = max_blocks_per_cu<8, 4>();
+  if (per <= 0) return 0;
+  // (one block per CU is what the roles are sized for; a second resident block per CU would only share its fill path)
+  return cus * 1;
+}
+
+int launch_dec_persist(hipStream_t st, const PersistArgs& a, int grid) {
+  const dim3 g(grid), b(PS_NT);
+  const bool big = a.n_rows > 4;
+  hipError_t e = hipErrorInvalidValue;
+#define WB_PS(DPL_, MR_) e = WB_LAUNCH_COOP((dec_persist_kernel<DPL_, MR_>), g, b, 0, st, a)
+  if (a.d == 128) { if (big) WB_PS(2, 8); else WB_PS(2, 4); }
+  else if (a.d == 384) { if (big) WB_PS(6, 8); else WB_PS(6, 4); }
+  else if (a.d == 512 && !big) WB_PS(8, 4);
+#undef WB_PS
+  return e == hipSuccess ? 0 : -1;
+}
+
+}  // namespace wb

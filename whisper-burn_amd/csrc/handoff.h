@@ -64,6 +64,13 @@ __device__ __forceinline__ float4 ld_f4(const float* base, const Buf16& b, uint3
     return *reinterpret_cast<const float4*>(base + elem_off);
   }
 }
+// 4-byte load at base[elem_soff + elem_voff]: `elem_soff` must be wave-uniform (it rides in the instruction's scalar
+// offset, so the per-lane offset register is shared by all planes of a fold)
+template <bool SC1>
+__device__ __forceinline__ float ld_fb(const float* base, const Buf16& b, uint32_t elem_voff, uint32_t elem_soff) {
+  if constexpr (SC1) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b.r, elem_voff * 4u, elem_soff * 4u, 16));
+  else return *(base + (int64_t)elem_soff + elem_voff);
+}
 template <bool SC1>
 __device__ __forceinline__ void st_f4(float* base, const Buf16& b, uint32_t elem_off, float4 v) {
   if constexpr (SC1) {

@@ -170,6 +170,7 @@ void launch_coop(void (*k)(P...), dim3 g, dim3 b, size_t sh, hipStream_t st, A&&
 constexpr int warpSize = 64;
 
 static inline void __syncthreads() { hipemu::syncthreads(); }
+static inline unsigned long long wall_clock64() { return 0; }   // (no timing in the model)
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline void __threadfence_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
@@ -219,6 +220,10 @@ static inline void hipemu_raw_buffer_store_b128(hipemu_u32x4 v, hipemu_rsrc r, u
   memcpy(r.base + voff + soff, &v, 16);
 }
 #define __builtin_amdgcn_make_buffer_rsrc(p, stride, n, flags) hipemu_make_buffer_rsrc((const void*)(p), stride, n, flags)
+static inline unsigned hipemu_raw_buffer_load_b32(hipemu_rsrc r, unsigned voff, unsigned soff, int) {
+  unsigned v; memcpy(&v, r.base + voff + soff, 4); return v;
+}
+#define __builtin_amdgcn_raw_buffer_load_b32 hipemu_raw_buffer_load_b32
 #define __builtin_amdgcn_raw_buffer_load_b128 hipemu_raw_buffer_load_b128
 #define __builtin_amdgcn_raw_buffer_store_b128 hipemu_raw_buffer_store_b128
 #define __builtin_amdgcn_s_sleep(n) hipemu::spin_yield()
