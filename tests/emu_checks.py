@@ -108,6 +108,21 @@ def main(which):
             ref = otr.mels_to_tokens(o2, pu.ost(st), mel, pad, 1, 6)
             assert rows[wi] == ref, (wi, rows[wi], ref)
         sess.close(); e2.close()
+    elif which.startswith("persist"):
+        # the persistent flag-chained decode kernel at the other template families: d = 384 (tiny.en's) with 4 rows (MR = 4)
+        # and 7 rows (MR = 8), d = 512 (base.en's) with 4 rows; two layers, windows of different length that end on
+        # <|endoftext|> at different steps.  HIPEMU_CUS (set by the test) forces several roles per block.
+        dd, n_s = {"persist384": (384, 50000), "persist384x7": (384, 96000), "persist512": (512, 50000)}[which]
+        dims = synth.micro_dims(n_state=dd, n_head=dd // 64, n_layer=2, n_vocab=2053, n_audio_ctx=400)
+        w2 = synth.synth_weights(dims, seed=90 + dd)
+        e2, o2 = wb.Whisper.from_tensors(w2), OracleWhisper(w2)
+        s2 = wb.SpecialTokens.for_vocab(2053)
+        a = synth.synth_audio(n_s, 51)
+        got, wins = wb.waveform_to_tokens(e2, s2, a, 16000, 1, 12)
+        ref, rw = otr.waveform_to_tokens(o2, pu.ost(s2), a, 16000, 1, 12, return_windows=True)
+        assert wins == rw and got == ref, (which, wins, rw)
+        assert len(wins) == (7 if which.endswith("x7") else 4)
+        e2.close()
     elif which == "beam":
         a = synth.synth_audio(16000 * 2, 9)
         got, _ = wb.waveform_to_tokens(eng, st, a, 16000, 3, 6)

@@ -191,7 +191,7 @@ __device__ __forceinline__ bool dec_mlp_body(const MlpFusedArgs& a, const int jb
   __shared__ float coef[REC ? MR : 1][48];                              // ... and its flash-combine weight
   WB_STAMP_DECL;
   WB_STAMP(0);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = role_tid<PS>(), lane = tid & 63, wave = tid >> 6;
   const int j0 = jblk * HS;
   const int rg = tid >> 4, c4 = (tid & 15) * 4;
   // Requested up front, in the order of use (loads return in order): fold operands, LayerNorm parameters, bias, the W1
@@ -426,7 +426,7 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
   __shared__ __attribute__((aligned(16))) float att[64];
   WB_STAMP_DECL;
   WB_STAMP(0);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = role_tid<PS>(), lane = tid & 63, wave = tid >> 6;
   // grid = (8, rows): workgroups go round-robin over the 8 XCDs by linear id, so x = head puts every beam's block of
   // one head on the SAME XCD -- the head's weight slices cross the fabric once and are shared through that L2
   if (h >= a.n_head) return true;
@@ -713,7 +713,7 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
   __shared__ __attribute__((aligned(16))) float part[32][64];
   __shared__ __attribute__((aligned(16))) float att[64];
   __shared__ __attribute__((aligned(16))) float obuf[(G - 1) * d];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = role_tid<PS>(), lane = tid & 63, wave = tid >> 6;
   if (h >= a.n_head) return true;
   int n_live, w_row, dead;
   if constexpr (PS) { n_live = ps.n_rows; w_row = r; dead = 0; }     // (one beam per window: slot == window)

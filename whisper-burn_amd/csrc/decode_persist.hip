@@ -57,7 +57,7 @@ __device__ __forceinline__ bool ps_logits_role(const PersistArgs& a, const int t
   constexpr int PCH = EPT <= 3 ? 8 : EPT <= 6 ? 4 : 2;
   __shared__ __attribute__((aligned(16))) float xs[MR][d];
   __shared__ __attribute__((aligned(16))) float red[8][MR][CT];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = role_tid<true>(), lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, c4 = (lane & 31) * 4;
   const int n0 = tile * CT;
   float4 w[NR];
@@ -169,7 +169,7 @@ __device__ __forceinline__ bool ps_merge_role(const PersistArgs& a, const int r,
                                               const unsigned* clog, const int* n_per_ctr) {
   __shared__ float redv[8];
   __shared__ int redi[8];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = role_tid<true>(), lane = tid & 63, wave = tid >> 6;
   PsStep ps = ps0;
   for (int k = 0; k < 8; k++) {                     // every tile of this step has arrived (8 sharded counters)
     if (n_per_ctr[k] == 0) continue;

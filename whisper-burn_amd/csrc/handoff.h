@@ -28,6 +28,18 @@ namespace wb {
   [&]() { void* _args[] = {(void*)&(arg)}; return hipLaunchCooperativeKernel((const void*)(kernel), grid, block, _args, shmem, stream); }()
 #endif
 
+// A role of the persistent kernel runs inside the step / role loops: without this, every thread-index-derived address of
+// every role is loop-invariant, gets hoisted in front of the loops and lives (spilled) across all of them.
+#ifndef WB_LAUNDER_V
+#define WB_LAUNDER_V(x) asm volatile("" : "+v"(x))
+#endif
+template <bool PS>
+__device__ __forceinline__ int role_tid() {
+  int t = threadIdx.x;
+  if constexpr (PS) WB_LAUNDER_V(t);
+  return t;
+}
+
 typedef unsigned hx_u32x4 __attribute__((ext_vector_type(4)));
 
 // ---- sc1 (agent-scope, L1-bypassing / write-through) accesses -----------------------------------------------------
@@ -83,7 +95,7 @@ __device__ __forceinline__ void st_f4(float* base, const Buf16& b, uint32_t elem
 }
 
 // ---- arrival counters ---------------------------------------------------------------------------------------------
-constexpr unsigned HX_SPIN_LIMIT = 40u * 1000u * 1000u;     // polls before a wait gives up (~ seconds): a bug, not a wait
+constexpr unsigned HX_SPIN_LIMIT = 4u * 1000u * 1000u;      // polls before a wait gives up (seconds; a real wait lasts microseconds)
 
 // Control words of one persistent launch (device memory, zeroed / initialised by the host before the launch)
 enum { HX_STOP = 0,        // first chain step that must NOT run (INT_MAX while the decode goes on)

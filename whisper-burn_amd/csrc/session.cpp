@@ -2,8 +2,11 @@
 // steps -- the result-equivalent fast path behind /root/reference/src/transcribe.rs:148-312.
 #include "session.h"
 
+#include <climits>
 #include <cstring>
 #include <mutex>
+
+#include "handoff.h"
 
 using namespace wb;
 
@@ -718,6 +721,124 @@ static int launch_step(wb_session* s, int n_launch, int k, int use_mask, bool fu
 }  // extern "C"
 
 namespace wb {
+// The whole chained greedy decode as ONE persistent launch (decode_persist.hip): every sublayer of every step runs in a
+// co-resident grid whose blocks hand their output planes to each other through arrival counters.  Enqueues the first
+// step's prepare kernel, the control block and the launch, then waits for the stream.  *steps_done = steps executed.
+static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_until_len, int* steps_done) {
+  wb_model* m = s->m;
+  const wb_dims& D = m->dims;
+  const int d = D.n_text_state, H = D.n_text_head, NL = D.n_text_layer, V = D.n_vocab, S = s->S, W = s->W;
+  const StepLayout& L = s->lay;
+  hipStream_t st = s->st;
+  const int NB = dec_mlp_fused_planes(d);
+  const int n_tiles = (V + 127) / 128;
+  const size_t pool = (size_t)s->Lmax * S;
+  const int ldkv = NL * 2 * d;
+  // ---- per-layer arguments: exactly what enqueue_step hands the fused sublayer kernels ----
+  std::vector<PsLayerArgs> la(NL);
+  float* xb[2] = {s->x.as<float>(), s->x.as<float>() + (size_t)S * d};
+  int xi = 0;
+  for (int l = 0; l < NL; l++) {
+    const DecBlockW& b = m->dec[l];
+    AttnFusedArgs& fa = la[l].attn;
+    fa.st = s->state.as<int>(); fa.lay = L; fa.S = S; fa.d = d; fa.n_head = H;
+    fa.x_in = xb[xi]; fa.pend = l == 0 ? nullptr : s->P2.as<float>(); fa.KSp = l == 0 ? 0 : NB;
+    fa.pbias = l == 0 ? nullptr : m->dec[l - 1].mlp2.b; fa.x_out = xb[xi ^ 1];
+    fa.ln_g = b.ln1.g; fa.ln_b = b.ln1.b; fa.ln_eps = b.ln1.eps; fa.ln_inside = m->ln_eps_inside_sqrt;
+    fa.Wqkv = b.qkv.w; fa.ldqkv = b.qkv.n; fa.bqkv = b.qkv.b; fa.scale = m->qk_scale;
+    fa.Kc = s->kc.as<float>() + (size_t)l * pool * d; fa.Vc = s->vc.as<float>() + (size_t)l * pool * d;
+    fa.tabs = s->tabs.as<int>(); fa.Lmax = s->Lmax; fa.Wo = b.out.w; fa.P = s->Pa.as<float>();
+    xi ^= 1;
+    CrossFusedArgs& ca = la[l].cross;
+    ca.st = s->state.as<int>(); ca.lay = L; ca.S = S; ca.d = d; ca.n_head = H;
+    ca.x_in = xb[xi]; ca.pend = s->Pa.as<float>(); ca.KSp = H; ca.pbias = b.out.b; ca.x_out = xb[xi ^ 1];
+    ca.ln_g = b.ln2.g; ca.ln_b = b.ln2.b; ca.ln_eps = b.ln2.eps; ca.ln_inside = m->ln_eps_inside_sqrt;
+    ca.Wq = b.cq.w; ca.bq = b.cq.b; ca.scale = m->qk_scale;
+    ca.ckv = s->ckv.as<float>(); ca.ldkv = ldkv; ca.koff = l * 2 * d;
+    ca.win_row0 = s->win_meta.as<int>(); ca.win_C = s->win_meta.as<int>() + W;
+    ca.Wo = b.cout.w; ca.P = s->Pc.as<float>();
+    xi ^= 1;
+    MlpFusedArgs& ma = la[l].mlp;
+    ma.st = s->state.as<int>(); ma.S = S; ma.d = d;
+    ma.x_in = xb[xi]; ma.pend = s->Pc.as<float>(); ma.KSp = H; ma.pbias = b.cout.b; ma.x_out = xb[xi ^ 1];
+    ma.ln_g = b.ln3.g; ma.ln_b = b.ln3.b; ma.ln_eps = b.ln3.eps; ma.ln_inside = m->ln_eps_inside_sqrt;
+    ma.W1 = b.mlp1.w; ma.ld1 = b.mlp1.n; ma.b1 = b.mlp1.b; ma.W2 = b.mlp2.w; ma.P = s->P2.as<float>();
+    xi ^= 1;
+  }
+  // ---- one step's roles in dependency order ----
+  std::vector<PsRole> roles;
+  for (int l = 0; l < NL; l++) {
+    for (int r = 0; r < W; r++) for (int h = 0; h < H; h++) roles.push_back(PsRole{PSR_ATTN, l, h, r});
+    for (int r = 0; r < W; r++) for (int h = 0; h < H; h++) roles.push_back(PsRole{PSR_CROSS, l, h, r});
+    for (int j = 0; j < NB; j++) roles.push_back(PsRole{PSR_MLP, l, j, 0});
+  }
+  for (int t = 0; t < n_tiles; t++) roles.push_back(PsRole{PSR_LOGITS, 0, t, 0});
+  for (int r = 0; r < W; r++) roles.push_back(PsRole{PSR_MERGE, 0, 0, r});
+  const int n_ctl = ps_ctl_ints(S, NL);
+  WB_TRY(s->ps_layers.ensure(la.size() * sizeof(PsLayerArgs)));
+  WB_TRY(s->ps_roles.ensure(roles.size() * sizeof(PsRole)));
+  WB_TRY(s->ps_ctl.ensure((size_t)n_ctl * 4));
+  WB_TRY(s->ps_dead.ensure((size_t)S * 4));
+  WB_TRY(s->ps_tstats.ensure((size_t)S * n_tiles * 2 * 4));
+  std::vector<int> ctl0(n_ctl, 0);
+  ctl0[HX_STOP] = INT_MAX;
+  WB_HIP(hipMemcpyAsync(s->ps_layers.p, la.data(), la.size() * sizeof(PsLayerArgs), hipMemcpyHostToDevice, st));
+  WB_HIP(hipMemcpyAsync(s->ps_roles.p, roles.data(), roles.size() * sizeof(PsRole), hipMemcpyHostToDevice, st));
+  WB_HIP(hipMemcpyAsync(s->ps_ctl.p, ctl0.data(), (size_t)n_ctl * 4, hipMemcpyHostToDevice, st));
+  WB_HIP(hipMemsetAsync(s->ps_dead.p, 0, (size_t)S * 4, st));
+  PersistArgs a;
+  a.layers = s->ps_layers.as<PsLayerArgs>(); a.roles = s->ps_roles.as<PsRole>(); a.n_roles = (int)roles.size();
+  a.n_layer = NL; a.n_rows = W; a.S = S; a.d = d; a.n_head = H; a.nb_mlp = NB;
+  a.ctl = s->ps_ctl.as<int>(); a.step0 = s->step; a.n_steps = max_depth; a.mask_until_len = mask_until_len;
+  a.x_fin = xb[xi]; a.P2 = s->P2.as<float>(); a.b2_last = m->dec[NL - 1].mlp2.b;
+  a.ln_g = m->ln_dec.g; a.ln_b = m->ln_dec.b; a.ln_eps = m->ln_dec.eps; a.ln_inside = m->ln_eps_inside_sqrt;
+  a.Et = m->tok_emb_t; a.vocab_ld = m->vocab_ld; a.V = V; a.mask = s->mask.as<float>();
+  a.tstats = s->ps_tstats.as<float>(); a.n_tiles = n_tiles;
+  a.gctl = s->gctl.as<int>(); a.gtok = s->gtok.as<int>(); a.Lmax = s->Lmax; a.eot = eot;
+  a.E = m->tok_emb; a.pos = m->dec_pos; a.x0 = xb[0]; a.tabs = s->tabs.as<int>(); a.dead = s->ps_dead.as<int>();
+  // optional role timeline (developer): WHISPER_HIP_PS_STAMPS=<file> dumps [n_steps][n_roles][3] 100 MHz clock values
+  static const char* stamps_path = getenv("WHISPER_HIP_PS_STAMPS");
+  const size_t n_stamps = stamps_path ? (size_t)max_depth * roles.size() * 3 : 0;
+  if (n_stamps) {
+    WB_TRY(s->ps_stamps.ensure(n_stamps * 8));
+    WB_HIP(hipMemsetAsync(s->ps_stamps.p, 0, n_stamps * 8, st));
+    a.stamps = s->ps_stamps.as<unsigned long long>();
+  }
+  // first step of the chain: token + position embedding of the last prompt token (every later step: the merge role)
+  launch_dec_prepare(st, reinterpret_cast<const int*>(s->host_block_dev), s->state.as<int>(), L, W, s->tabs.as<int>(),
+                     s->Lmax, m->tok_emb, m->dec_pos, d, s->x.as<float>(), s->gctl.as<int>());
+  WB_HIP(hipStreamSynchronize(st));            // (the staging vectors above are on the stack)
+  const int grid = std::min((int)roles.size(), s->ps_grid);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  prof_tag(KC_PERSIST, 0.0);                   // (its necessary bytes are known when the rows' lengths are: added by the caller)
+  const bool timed = prof_take_events(&e0, &e1);
+  if (timed) WB_HIP(hipEventRecord(e0, st));
+  WB_REQUIRE(launch_dec_persist(st, a, grid) == 0, WB_ERR_HIP, "persistent decode launch failed (grid %d): %s", grid,
+             hipGetErrorString(hipGetLastError()));
+  if (timed) WB_HIP(hipEventRecord(e1, st));
+  std::vector<int> ctl(n_ctl);
+  WB_HIP(hipMemcpyAsync(ctl.data(), s->ps_ctl.p, (size_t)n_ctl * 4, hipMemcpyDeviceToHost, st));
+  int gstep = 0;
+  WB_HIP(hipMemcpyAsync(&gstep, s->gctl.as<int>() + GC_STEP, 4, hipMemcpyDeviceToHost, st));
+  WB_HIP(hipStreamSynchronize(st));
+  WB_REQUIRE(ctl[HX_ERR] == 0, WB_ERR_HIP, "persistent decode: a wait gave up (counter %d) at step %d", ctl[HX_ERR] - 1, gstep);
+  if (n_stamps) {
+    std::vector<unsigned long long> hs(n_stamps);
+    WB_HIP(hipMemcpy(hs.data(), s->ps_stamps.p, n_stamps * 8, hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(stamps_path, "wb")) {
+      const int hdr[4] = {max_depth, (int)roles.size(), grid, 3};
+      fwrite(hdr, 4, 4, f);
+      std::vector<int> kinds(roles.size());
+      for (size_t i = 0; i < roles.size(); i++) kinds[i] = roles[i].kind | (roles[i].layer << 8);
+      fwrite(kinds.data(), 4, kinds.size(), f);
+      fwrite(hs.data(), 8, hs.size(), f);
+      fclose(f);
+    }
+  }
+  *steps_done = std::max(0, std::min(max_depth, gstep - s->step));
+  return WB_OK;
+}
+
 // Device-chained greedy decode (beam_size == 1): after the host-driven prompt prefill, every step's
 // argmax is fed to the next step on the device; the host only replays the step graph and checks the
 // per-window finished flags every `chunk` steps.  Equivalent to beam.rs with k = 1: the single beam is
@@ -754,7 +875,25 @@ int session_greedy_chain(wb_session* s, int first_token, int eot, int max_depth,
   const bool use_graph = graphs_enabled && !profile().on;
   const int chunk = 16;
   int depth = 0;                                   // steps enqueued so far
+  // the persistent flag-chained kernel: the small-batch fused path of exact-f32 models whose roles fit one co-resident
+  // grid (WHISPER_HIP_PERSIST=0: the graph-replayed chain of one launch per sublayer)
+  static const bool persist_enabled = []() { const char* e = getenv("WHISPER_HIP_PERSIST"); return !(e && e[0] == '0'); }();
+  static const bool fused_enabled = []() {
+    const char* a = getenv("WHISPER_HIP_FUSE_SUB"); const char* b = getenv("WHISPER_HIP_FUSE_X");
+    return !(a && a[0] == '0') && !(b && b[0] == '0');
+  }();
+  bool persist = persist_enabled && fused_enabled && fuse_ln && max_depth > 0 && m->compute_dtype != WB_BF16 &&
+                 dec_fused_supported(m->dims.n_text_state) && m->dims.n_text_state == 64 * m->dims.n_text_head &&
+                 s->maxC <= CROSS_FUSED_MAX_C && dec_persist_supported(m->dims.n_text_state, W);
+  if (persist) {
+    if (s->ps_grid < 0) s->ps_grid = dec_persist_max_grid(m->device, m->dims.n_text_state, W);
+    persist = s->ps_grid > 0;
+  }
   ScopedTimer tm(st, 3);
+  if (persist) {
+    WB_TRY(run_persistent_chain(s, eot, max_depth, mask_until_len, &depth));
+    if (profile().on) profile().ms[4] += depth;
+  } else {
   if (fuse_ln)   // first step of the chain; every later one is prepared by its predecessor's merge kernel
     launch_dec_prepare(st, reinterpret_cast<const int*>(s->host_block_dev), s->state.as<int>(), s->lay, n_launch,
                        s->tabs.as<int>(), s->Lmax, m->tok_emb, m->dec_pos, m->dims.n_text_state, s->x.as<float>(),
@@ -867,6 +1006,7 @@ int session_greedy_chain(wb_session* s, int first_token, int eot, int max_depth,
     }
     WB_HIP(hipStreamSynchronize(st));
   }
+  }   // (!persist)
   tm.stop();
   std::vector<int> toks((size_t)S * s->Lmax + 1);
   WB_HIP(hipMemcpyAsync(ctl.data(), s->gctl.p, ctl_ints * 4, hipMemcpyDeviceToHost, st));
@@ -893,6 +1033,17 @@ int session_greedy_chain(wb_session* s, int first_token, int eot, int max_depth,
     }
     prof_adjust_bytes(s->prof_cls_cross, -(double)NL * dead_ckv);
     prof_adjust_bytes(s->prof_cls_self, -(double)NL * dead_self);
+  }
+  if (profile().on && persist) {
+    // necessary bytes of the persistent launch: weights + E^T once per executed step, a row's cached cross K/V and
+    // self-attention rows only while its window is live
+    const double dm = m->dims.n_text_state, NL = m->dims.n_text_layer;
+    double bytes = (double)depth * 4.0 * (NL * 14.0 * dm * dm + (double)m->dims.n_vocab * dm);
+    for (int w = 0; w < W; w++) {
+      const int live = std::max(0, std::min(out_lens[w] - prompt_len, depth));
+      for (int t = 0; t < live; t++) bytes += NL * (8.0 * s->C[w] * dm + 8.0 * (s->step + t + 1) * dm);
+    }
+    prof_adjust_bytes(KC_PERSIST, bytes);
   }
   s->prof_step_off = 0;
   s->step += depth;

@@ -43,11 +43,14 @@
 #define __HIP_MEMORY_SCOPE_WORKGROUP 3
 #define __HIP_MEMORY_SCOPE_WAVEFRONT 2
 #define __HIP_MEMORY_SCOPE_SINGLETHREAD 1
-#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
-#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
+template <class T, class U> static inline void hipemu_atomic_store(T* p, U v) { T t = (T)v; __atomic_store(p, &t, __ATOMIC_SEQ_CST); }
+template <class T> static inline T hipemu_atomic_load(const T* p) { T v; __atomic_load(const_cast<T*>(p), &v, __ATOMIC_SEQ_CST); return v; }
+#define __hip_atomic_store(p, v, order, scope) hipemu_atomic_store((p), (v))
+#define __hip_atomic_load(p, order, scope) hipemu_atomic_load((p))
 #define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), (order))
 // hooks of the engine's cross-block hand-off helpers (csrc/wave_ops.h defines the gfx950 forms unless these exist)
 #define WB_DRAIN_VMEM() __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#define WB_LAUNDER_V(x) ((void)0)
 #define WB_LAUNCH_COOP(kernel, grid, block, shmem, stream, arg) \
   (hipemu::launch_coop(kernel, dim3(grid), dim3(block), (size_t)(shmem), stream, arg), hipSuccess)
 
