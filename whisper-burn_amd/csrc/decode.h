@@ -163,10 +163,12 @@ struct CrossFusedArgs {
 // planes with write-through stores (handoff.h).  No kernel boundary, no grid barrier, fixed summation orders.
 struct PsLayerArgs { AttnFusedArgs attn; CrossFusedArgs cross; MlpFusedArgs mlp; };
 enum { PSR_ATTN = 0, PSR_CROSS = 1, PSR_MLP = 2, PSR_LOGITS = 3, PSR_MERGE = 4 };
-struct PsRole { int kind, layer, a, b; };     // a: head / hidden slice / tile, b: row
+struct PsRole { int kind, layer, a, b; };     // a: head / hidden slice / first tile, b: row (logits: tiles of the role; layer: its ordinal)
 struct PersistArgs {
   const PsLayerArgs* layers = nullptr;        // [n_layer] (device)
-  const PsRole* roles = nullptr; int n_roles = 0;   // one step's roles in dependency order (device)
+  const PsRole* roles = nullptr; int n_roles = 0;   // one step's roles, grouped by block, each block's in dependency order (device)
+  const int* role_off = nullptr;              // [grid + 1]: block b runs roles [role_off[b], role_off[b + 1]) every step
+  int n_logits_roles = 0;
   int n_layer = 0, n_rows = 0, S = 0, d = 0, n_head = 0, nb_mlp = 0;
   int* ctl = nullptr;                         // HX_* control words + arrival counters (device; set up by the host)
   int step0 = 0, n_steps = 0;                 // first decode step of the chain, most steps to run

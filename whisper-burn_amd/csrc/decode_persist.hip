@@ -10,18 +10,20 @@
 // 253-307, src/model/mod.rs:345-350); the arithmetic of a step here is the arithmetic of the fused sublayer kernels
 // (decode_fused_bodies.h: same device templates, same fixed summation orders -> bit-reproducible).
 //
-// Roles of one step, in dependency order (a block runs roles blockIdx.x, + gridDim.x, ... of this list):
+// Roles of one step, in dependency order:
 //   per layer l: attn (head h, row r) x H R  ->  cross (h, r) x H R  ->  mlp (64-unit hidden slice j) x 4 d / 64
-//   logits (128-column vocabulary tile t) x ceil(V / 128)   ->   merge (row r) x R
+//   logits (a run of 128-column vocabulary tiles sharing one fold + LayerNorm)   ->   merge (row r) x R
+// The host deals the roles to the blocks (session.cpp): a block runs its own list, in dependency order, every step.  The
+// first sublayers' blocks take no logits work (they are back at their wait, weights requested, before the step ends).
 // Dependencies = arrival counters (handoff.h), monotonic within the launch:
 //   attn(0,.,r)  waits for merge(r) of the previous step (its x row)          c_x[r]       >= e
 //   attn(l,.,r)  waits for every MLP slice of layer l - 1                      c_mlp[l-1]   >= (e + 1) NB
 //   cross(l,.,r) waits for the H attention blocks of its row                   c_attn[l][r] >= (e + 1) H
 //   mlp(l,.)     waits for every cross-attention block of the layer            c_cross[l]   >= (e + 1) H R
-//   logits(t)    waits for every MLP slice of the last layer                   c_mlp[NL-1]  >= (e + 1) NB
-//   merge(r)     waits for every tile (8 counters, tile t arrives at t mod 8)  c_log[k]     >= (e + 1) n_k
-// A block never waits for a role with a larger index in the same step, and all blocks are co-resident (the host sizes
-// the grid from the occupancy query), so the smallest unfinished role can always run: no deadlock.  Reuse of the plane
+//   logits(.)    waits for every MLP slice of the last layer                   c_mlp[NL-1]  >= (e + 1) NB
+//   merge(r)     waits for every logits role (8 counters, role q arrives at q mod 8)  c_log[k] >= (e + 1) n_k
+// Every block's list follows one global dependency order and all blocks are co-resident (the host sizes the grid from
+// the occupancy query), so the smallest unfinished role can always run: no deadlock.  Reuse of the plane
 // buffers across steps is ordered by the same chain (a role arrives only after its last read).
 //
 // End of the decode: the merge role of the last window to end stores HX_STOP = first step that must not run; every wait
@@ -50,33 +52,30 @@ constexpr int PS_CT = 128;      // vocabulary columns per logits tile
 // normalises the rows itself (R d (1 + NB) floats from L2).  Per row and tile the block leaves the best masked logit and
 // its id -- greedy needs the argmax only (log_softmax is monotone: transcribe.rs:276 with beam.rs k = 1).
 template <int MR, int DPL>
-__device__ __forceinline__ bool ps_logits_role(const PersistArgs& a, const int tile, const PsStep& ps) {
+__device__ __forceinline__ bool ps_logits_role(const PersistArgs& a, const int tile0, const int n_t, const PsStep& ps) {
   constexpr int d = 64 * DPL, NT = PS_NT, CT = PS_CT;
   constexpr int NR = d / 16;                        // E^T rows per thread: k = 16 i + 2 wave + hh
   constexpr int EPT = (MR * d + NT - 1) / NT;
   constexpr int PCH = EPT <= 3 ? 8 : EPT <= 6 ? 4 : 2;
+  constexpr int NQ = MR * CT / NT;                  // tile values per thread in the column-sum pass
   __shared__ __attribute__((aligned(16))) float xs[MR][d];
   __shared__ __attribute__((aligned(16))) float red[8][MR][CT];
+  __shared__ float tilev[MR][CT];
   const int tid = role_tid<true>(), lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, c4 = (lane & 31) * 4;
-  const int n0 = tile * CT;
   float4 w[NR];
-  {
+  auto load_tile = [&](int tile) {
+    const int n0 = tile * CT;
     const bool col_ok = n0 + c4 < a.vocab_ld;      // lanes past the padded vocabulary re-read the tile's first columns
     const float* wp = a.Et + (int64_t)(2 * wave + hh) * a.vocab_ld + n0 + (col_ok ? c4 : 0);
 #pragma unroll
     for (int i = 0; i < NR; i++) w[i] = *reinterpret_cast<const float4*>(wp + (int64_t)(16 * i) * a.vocab_ld);
-  }
+  };
+  load_tile(tile0);
   float gv[DPL], bv[DPL];
 #pragma unroll
   for (int i = 0; i < DPL; i++) { gv[i] = a.ln_g[lane + 64 * i]; bv[i] = a.ln_b[lane + 64 * i]; }
   const int use_mask = (ps.step + 1 <= a.mask_until_len) ? 1 : 0;          // transcribe.rs:271-275
-  float mk[MR * CT / NT > 0 ? MR * CT / NT : 1];
-#pragma unroll
-  for (int q = 0; q < MR * CT / NT; q++) {
-    const int col = n0 + ((tid + NT * q) & (CT - 1));
-    mk[q] = (use_mask && col < a.V) ? a.mask[col] : 0.f;
-  }
   if (!ps_wait(ps)) return false;
   {
     // x + (bias + partial planes), plane order fixed (mod.rs:346-348): every load of a chunk of planes in flight together
@@ -112,52 +111,61 @@ __device__ __forceinline__ bool ps_logits_role(const PersistArgs& a, const int t
   __syncthreads();
   if (wave < MR) ln_row_lds<DPL>(xs[wave], d, lane, gv, bv, a.ln_eps, a.ln_inside);
   __syncthreads();
-  float acc[MR][4];
+  for (int t = 0; t < n_t; t++) {                   // the role's tiles share the fold + LayerNorm above
+    const int tile = tile0 + t, n0 = tile * CT;
+    float mk[NQ];
 #pragma unroll
-  for (int r = 0; r < MR; r++) { acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.f; }
-#pragma unroll
-  for (int i = 0; i < NR; i++) {
-    const int k = 16 * i + 2 * wave + hh;
-#pragma unroll
-    for (int r = 0; r < MR; r++) {
-      const float xv = xs[r][k];
-      acc[r][0] += xv * w[i].x; acc[r][1] += xv * w[i].y; acc[r][2] += xv * w[i].z; acc[r][3] += xv * w[i].w;
+    for (int q = 0; q < NQ; q++) {
+      const int col = n0 + ((tid + NT * q) & (CT - 1));
+      mk[q] = (use_mask && col < a.V) ? a.mask[col] : 0.f;
     }
-  }
+    float acc[MR][4];
 #pragma unroll
-  for (int r = 0; r < MR; r++)
+    for (int r = 0; r < MR; r++) { acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.f; }
 #pragma unroll
-    for (int c = 0; c < 4; c++) acc[r][c] = xor32_sum(acc[r][c]);          // the two row halves of the wave
-  if (hh == 0) {
+    for (int i = 0; i < NR; i++) {
+      const int k = 16 * i + 2 * wave + hh;
+#pragma unroll
+      for (int r = 0; r < MR; r++) {
+        const float xv = xs[r][k];
+        acc[r][0] += xv * w[i].x; acc[r][1] += xv * w[i].y; acc[r][2] += xv * w[i].z; acc[r][3] += xv * w[i].w;
+      }
+    }
+    if (t + 1 < n_t) load_tile(tile + 1);           // the weight registers are free: the next tile streams under this
+                                                    // tile's reduction and statistics
 #pragma unroll
     for (int r = 0; r < MR; r++)
-      *reinterpret_cast<float4*>(&red[wave][r][c4]) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
-  }
-  __syncthreads();
-  // column sums over the eight waves (fixed order), + mask; then one wave per row: best (value desc, id asc)
-  float* tilev = &xs[0][0];                         // [MR][CT] (the normalised rows are dead; MR d >= MR CT)
-  static_assert(d >= CT, "tile values alias the row buffer");
 #pragma unroll
-  for (int q = 0; q < MR * CT / NT; q++) {
-    const int e = tid + NT * q, r = e / CT, c = e & (CT - 1);
-    float v = 0.f;
+      for (int c = 0; c < 4; c++) acc[r][c] = xor32_sum(acc[r][c]);        // the two row halves of the wave
+    if (hh == 0) {
 #pragma unroll
-    for (int w8 = 0; w8 < 8; w8++) v += red[w8][r][c];
-    v += mk[q];
-    if (n0 + c >= a.V) v = -INFINITY;
-    tilev[r * CT + c] = v;
-  }
-  __syncthreads();
-  if (wave < MR && wave < ps.n_rows) {
-    const int r = wave;
-    const float v0 = tilev[r * CT + lane], v1 = tilev[r * CT + lane + 64];
-    float bvv; int bi;
-    if (better(v0, lane, v1, lane + 64)) { bvv = v0; bi = lane; } else { bvv = v1; bi = lane + 64; }
-    wave_argmax(bvv, bi);
-    if (lane == 0) {
-      float* ts = a.tstats + ((int64_t)r * a.n_tiles + tile) * 2;
-      st_f<true>(ts, bvv);
-      st_f<true>(ts + 1, __int_as_float(n0 + bi));
+      for (int r = 0; r < MR; r++)
+        *reinterpret_cast<float4*>(&red[wave][r][c4]) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+    }
+    __syncthreads();
+    // column sums over the eight waves (fixed order), + mask; then one wave per row: best (value desc, id asc)
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const int e = tid + NT * q, r = e / CT, c = e & (CT - 1);
+      float v = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; w8++) v += red[w8][r][c];
+      v += mk[q];
+      if (n0 + c >= a.V) v = -INFINITY;
+      tilev[r][c] = v;
+    }
+    __syncthreads();
+    if (wave < MR && wave < ps.n_rows) {
+      const int r = wave;
+      const float v0 = tilev[r][lane], v1 = tilev[r][lane + 64];
+      float bvv; int bi;
+      if (better(v0, lane, v1, lane + 64)) { bvv = v0; bi = lane; } else { bvv = v1; bi = lane + 64; }
+      wave_argmax(bvv, bi);
+      if (lane == 0) {
+        float* ts = a.tstats + ((int64_t)r * a.n_tiles + tile) * 2;
+        st_f<true>(ts, bvv);
+        st_f<true>(ts + 1, __int_as_float(n0 + bi));
+      }
     }
   }
   return true;
@@ -173,7 +181,7 @@ __device__ __forceinline__ bool ps_merge_role(const PersistArgs& a, const int r,
   PsStep ps = ps0;
   for (int k = 0; k < 8; k++) {                     // every tile of this step has arrived (8 sharded counters)
     if (n_per_ctr[k] == 0) continue;
-    ps.ctr = clog + k; ps.target = (unsigned)(e + 1) * (unsigned)n_per_ctr[k]; ps.ctr_index = 1000 + k;
+    ps.ctr = clog + k * HX_LINE; ps.target = (unsigned)(e + 1) * (unsigned)n_per_ctr[k]; ps.ctr_index = 1000 + k;
     if (!hx_wait(ps.ctr, ps.target, ps.ctl, ps.step, ps.ctr_index, ps.lds_flag)) return false;
   }
   if (ps.stamp && threadIdx.x == 0) *ps.stamp = wall_clock64();
@@ -233,52 +241,54 @@ template <int DPL, int MR>
 __global__ __launch_bounds__(PS_NT) void dec_persist_kernel(PersistArgs a) {
   __shared__ int wait_flag;
   const int NL = a.n_layer, S = a.S, R = a.n_rows, H = a.n_head, NB = a.nb_mlp;
-  unsigned* const ctr = reinterpret_cast<unsigned*>(a.ctl + HX_HDR);
-  unsigned* const c_x = ctr;
-  unsigned* const c_attn = ctr + S;
-  unsigned* const c_cross = ctr + S + NL * S;
-  unsigned* const c_mlp = c_cross + NL;
-  unsigned* const c_log = c_mlp + NL;
+  // arrival counter c lives at ctl[HX_HDR + c HX_LINE]: one 128-byte line each
+  auto cptr = [&](int c) { return reinterpret_cast<unsigned*>(a.ctl + HX_HDR + c * HX_LINE); };
+  const int C_X = 0, C_ATTN = S, C_CROSS = S + NL * S, C_MLP = C_CROSS + NL, C_LOG = C_MLP + NL;
   int n_per_ctr[8];
 #pragma unroll
-  for (int k = 0; k < 8; k++) n_per_ctr[k] = (a.n_tiles + 7 - k) / 8;
+  for (int k = 0; k < 8; k++) n_per_ctr[k] = (a.n_logits_roles + 7 - k) / 8;
+  const int i_lo = a.role_off[blockIdx.x], i_hi = a.role_off[blockIdx.x + 1];
   for (int e = 0; e < a.n_steps; e++) {
-    for (int i = blockIdx.x; i < a.n_roles; i += gridDim.x) {
+    for (int i = i_lo; i < i_hi; i++) {
       const PsRole role = a.roles[i];
       PsStep ps;
       ps.ctl = a.ctl; ps.step = a.step0 + e; ps.n_rows = R; ps.dead = a.dead; ps.lds_flag = &wait_flag;
       unsigned long long* stp = a.stamps ? a.stamps + ((size_t)e * a.n_roles + i) * 3 : nullptr;
       if (stp && threadIdx.x == 0) stp[0] = wall_clock64();
       ps.stamp = stp ? stp + 1 : nullptr;
-      unsigned* out;
+      int out;
       bool ok;
       if (role.kind == PSR_ATTN) {
         const AttnFusedArgs la = a.layers[role.layer].attn;
-        if (role.layer == 0) { ps.ctr = c_x + role.b; ps.target = (unsigned)e; ps.ctr_index = role.b; }
-        else { ps.ctr = c_mlp + role.layer - 1; ps.target = (unsigned)(e + 1) * NB; ps.ctr_index = 200 + role.layer - 1; }
+        if (role.layer == 0) { ps.ctr_index = C_X + role.b; ps.target = (unsigned)e; }
+        else { ps.ctr_index = C_MLP + role.layer - 1; ps.target = (unsigned)(e + 1) * NB; }
+        ps.ctr = cptr(ps.ctr_index);
         ok = dec_attn_body<DPL, true>(la, role.a, role.b, ps);
-        out = c_attn + role.layer * S + role.b;
+        out = C_ATTN + role.layer * S + role.b;
       } else if (role.kind == PSR_CROSS) {
         const CrossFusedArgs la = a.layers[role.layer].cross;
-        ps.ctr = c_attn + role.layer * S + role.b; ps.target = (unsigned)(e + 1) * H; ps.ctr_index = 300 + role.layer * S + role.b;
+        ps.ctr_index = C_ATTN + role.layer * S + role.b; ps.target = (unsigned)(e + 1) * H;
+        ps.ctr = cptr(ps.ctr_index);
         ok = dec_cross_body<DPL, true>(la, role.a, role.b, ps);
-        out = c_cross + role.layer;
+        out = C_CROSS + role.layer;
       } else if (role.kind == PSR_MLP) {
         const MlpFusedArgs la = a.layers[role.layer].mlp;
-        ps.ctr = c_cross + role.layer; ps.target = (unsigned)(e + 1) * H * R; ps.ctr_index = 100 + role.layer;
+        ps.ctr_index = C_CROSS + role.layer; ps.target = (unsigned)(e + 1) * H * R;
+        ps.ctr = cptr(ps.ctr_index);
         ok = dec_mlp_body<MR, DPL, false, true>(la, role.a, ps);
-        out = c_mlp + role.layer;
+        out = C_MLP + role.layer;
       } else if (role.kind == PSR_LOGITS) {
-        ps.ctr = c_mlp + NL - 1; ps.target = (unsigned)(e + 1) * NB; ps.ctr_index = 200 + NL - 1;
-        ok = ps_logits_role<MR, DPL>(a, role.a, ps);
-        out = c_log + (role.a & 7);
+        ps.ctr_index = C_MLP + NL - 1; ps.target = (unsigned)(e + 1) * NB;
+        ps.ctr = cptr(ps.ctr_index);
+        ok = ps_logits_role<MR, DPL>(a, role.a, role.b, ps);
+        out = C_LOG + (role.layer & 7);
       } else {
-        ok = ps_merge_role(a, role.b, e, ps, c_log, n_per_ctr);
-        out = c_x + role.b;
+        ok = ps_merge_role(a, role.b, e, ps, cptr(C_LOG), n_per_ctr);
+        out = C_X + role.b;
       }
       if (!ok) return;                               // the decode was stopped (or a wait gave up): leave
       if (stp && threadIdx.x == 0) stp[2] = wall_clock64();
-      hx_arrive(out);
+      hx_arrive(cptr(out));
     }
   }
 }
@@ -292,7 +302,7 @@ int max_blocks_per_cu() {
 
 }  // namespace
 
-int ps_ctl_ints(int S, int n_layer) { return HX_HDR + S + n_layer * S + 2 * n_layer + 8; }
+int ps_ctl_ints(int S, int n_layer) { return HX_HDR + (S + n_layer * S + 2 * n_layer + 8) * HX_LINE; }
 
 // d = 512 with more than 4 rows would need > 160 KB of LDS (every role's LDS is resident at once)
 bool dec_persist_supported(int d, int n_rows) {

@@ -97,11 +97,14 @@ __device__ __forceinline__ void st_f4(float* base, const Buf16& b, uint32_t elem
 // ---- arrival counters ---------------------------------------------------------------------------------------------
 constexpr unsigned HX_SPIN_LIMIT = 4u * 1000u * 1000u;      // polls before a wait gives up (seconds; a real wait lasts microseconds)
 
-// Control words of one persistent launch (device memory, zeroed / initialised by the host before the launch)
-enum { HX_STOP = 0,        // first chain step that must NOT run (INT_MAX while the decode goes on)
-       HX_ERR = 1,         // != 0: a wait gave up (value = 1 + index of the counter) -- every block leaves
-       HX_NDONE = 2,       // rows finished so far
-       HX_HDR = 8 };       // counters start here
+// Control words of one persistent launch (device memory, zeroed / initialised by the host before the launch).  Every
+// polled word owns a 128-byte line (HX_LINE ints apart): a few hundred pollers and the producers' atomics on ONE line
+// serialise at its memory channel (measured: 7-9 us per hand-off with all counters in one line, r03_c_ps_timeline_first).
+constexpr int HX_LINE = 32;
+enum { HX_STOP = 0,               // first chain step that must NOT run (INT_MAX while the decode goes on)
+       HX_ERR = HX_LINE,          // != 0: a wait gave up (value = 1 + index of the counter) -- every block leaves
+       HX_NDONE = 2 * HX_LINE,    // rows finished so far
+       HX_HDR = 3 * HX_LINE };    // counters start here, counter c at HX_HDR + c * HX_LINE
 
 // Publish: call with ALL threads of the block after the role's last payload store.
 __device__ __forceinline__ void hx_arrive(unsigned* ctr) {
@@ -118,8 +121,10 @@ __device__ __forceinline__ bool hx_wait(const unsigned* ctr, unsigned target, co
     int ok = 1;
     unsigned spins = 0;
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      if (__hip_atomic_load(ctl + HX_STOP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= step ||
-          __hip_atomic_load(ctl + HX_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
+      // (the stop / error words are everybody's: looked at every 16th poll only)
+      if ((spins & 15u) == 15u &&
+          (__hip_atomic_load(ctl + HX_STOP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= step ||
+           __hip_atomic_load(ctl + HX_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { ok = 0; break; }
       if (++spins > HX_SPIN_LIMIT) {
         __hip_atomic_store(const_cast<int*>(ctl) + HX_ERR, 1 + ctr_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok = 0;

@@ -765,18 +765,48 @@ static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_
     ma.W1 = b.mlp1.w; ma.ld1 = b.mlp1.n; ma.b1 = b.mlp1.b; ma.W2 = b.mlp2.w; ma.P = s->P2.as<float>();
     xi ^= 1;
   }
-  // ---- one step's roles in dependency order ----
-  std::vector<PsRole> roles;
+  // ---- one step's roles, dealt to the blocks: every block runs its own list, in dependency order, every step ----
+  std::vector<PsRole> lr;                            // the layer roles in dependency order
   for (int l = 0; l < NL; l++) {
-    for (int r = 0; r < W; r++) for (int h = 0; h < H; h++) roles.push_back(PsRole{PSR_ATTN, l, h, r});
-    for (int r = 0; r < W; r++) for (int h = 0; h < H; h++) roles.push_back(PsRole{PSR_CROSS, l, h, r});
-    for (int j = 0; j < NB; j++) roles.push_back(PsRole{PSR_MLP, l, j, 0});
+    for (int r = 0; r < W; r++) for (int h = 0; h < H; h++) lr.push_back(PsRole{PSR_ATTN, l, h, r});
+    for (int r = 0; r < W; r++) for (int h = 0; h < H; h++) lr.push_back(PsRole{PSR_CROSS, l, h, r});
+    for (int j = 0; j < NB; j++) lr.push_back(PsRole{PSR_MLP, l, j, 0});
   }
-  for (int t = 0; t < n_tiles; t++) roles.push_back(PsRole{PSR_LOGITS, 0, t, 0});
-  for (int r = 0; r < W; r++) roles.push_back(PsRole{PSR_MERGE, 0, 0, r});
+  const int grid = std::max(1, std::min(s->ps_grid, (int)lr.size() + n_tiles + W));
+  std::vector<std::vector<PsRole>> deal(grid);
+  for (size_t i = 0; i < lr.size(); i++) deal[i % grid].push_back(lr[i]);
+  // logits: blocks that hold a first-layer attention role stay free of it -- they are the first to be needed in the next
+  // step and should be back at their wait (weights requested) before this one ends.  Every logits block takes a run of
+  // consecutive 128-column tiles behind ONE fold + LayerNorm.
+  std::vector<int> cand;
+  for (int b = 0; b < grid; b++) {
+    bool early = false;
+    for (const PsRole& r : deal[b]) early |= r.layer == 0 && (r.kind == PSR_ATTN || r.kind == PSR_CROSS);
+    if (!early) cand.push_back(b);
+  }
+  if ((int)cand.size() * 4 < n_tiles) { cand.clear(); for (int b = 0; b < grid; b++) cand.push_back(b); }
+  std::stable_sort(cand.begin(), cand.end(), [&](int x, int y) { return deal[x].size() < deal[y].size(); });
+  const int tpb = (n_tiles + (int)cand.size() - 1) / (int)cand.size();
+  const int n_lg = (n_tiles + tpb - 1) / tpb;
+  for (int q = 0; q < n_lg; q++)
+    deal[cand[q]].push_back(PsRole{PSR_LOGITS, q, q * tpb, std::min(tpb, n_tiles - q * tpb)});
+  // merge (one per row): the least loaded blocks
+  {
+    std::vector<int> order(grid);
+    for (int b = 0; b < grid; b++) order[b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return deal[x].size() < deal[y].size(); });
+    for (int r = 0; r < W; r++) deal[order[r % grid]].push_back(PsRole{PSR_MERGE, 0, 0, r});
+  }
+  std::vector<PsRole> roles;
+  std::vector<int> role_off(grid + 1, 0);
+  for (int b = 0; b < grid; b++) {
+    role_off[b] = (int)roles.size();
+    roles.insert(roles.end(), deal[b].begin(), deal[b].end());
+  }
+  role_off[grid] = (int)roles.size();
   const int n_ctl = ps_ctl_ints(S, NL);
   WB_TRY(s->ps_layers.ensure(la.size() * sizeof(PsLayerArgs)));
-  WB_TRY(s->ps_roles.ensure(roles.size() * sizeof(PsRole)));
+  WB_TRY(s->ps_roles.ensure(roles.size() * sizeof(PsRole) + role_off.size() * 4));
   WB_TRY(s->ps_ctl.ensure((size_t)n_ctl * 4));
   WB_TRY(s->ps_dead.ensure((size_t)S * 4));
   WB_TRY(s->ps_tstats.ensure((size_t)S * n_tiles * 2 * 4));
@@ -784,10 +814,14 @@ static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_
   ctl0[HX_STOP] = INT_MAX;
   WB_HIP(hipMemcpyAsync(s->ps_layers.p, la.data(), la.size() * sizeof(PsLayerArgs), hipMemcpyHostToDevice, st));
   WB_HIP(hipMemcpyAsync(s->ps_roles.p, roles.data(), roles.size() * sizeof(PsRole), hipMemcpyHostToDevice, st));
+  WB_HIP(hipMemcpyAsync(static_cast<char*>(s->ps_roles.p) + roles.size() * sizeof(PsRole), role_off.data(), role_off.size() * 4,
+                        hipMemcpyHostToDevice, st));
   WB_HIP(hipMemcpyAsync(s->ps_ctl.p, ctl0.data(), (size_t)n_ctl * 4, hipMemcpyHostToDevice, st));
   WB_HIP(hipMemsetAsync(s->ps_dead.p, 0, (size_t)S * 4, st));
   PersistArgs a;
   a.layers = s->ps_layers.as<PsLayerArgs>(); a.roles = s->ps_roles.as<PsRole>(); a.n_roles = (int)roles.size();
+  a.role_off = reinterpret_cast<const int*>(static_cast<char*>(s->ps_roles.p) + roles.size() * sizeof(PsRole));
+  a.n_logits_roles = n_lg;
   a.n_layer = NL; a.n_rows = W; a.S = S; a.d = d; a.n_head = H; a.nb_mlp = NB;
   a.ctl = s->ps_ctl.as<int>(); a.step0 = s->step; a.n_steps = max_depth; a.mask_until_len = mask_until_len;
   a.x_fin = xb[xi]; a.P2 = s->P2.as<float>(); a.b2_last = m->dec[NL - 1].mlp2.b;
@@ -808,7 +842,6 @@ static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_
   launch_dec_prepare(st, reinterpret_cast<const int*>(s->host_block_dev), s->state.as<int>(), L, W, s->tabs.as<int>(),
                      s->Lmax, m->tok_emb, m->dec_pos, d, s->x.as<float>(), s->gctl.as<int>());
   WB_HIP(hipStreamSynchronize(st));            // (the staging vectors above are on the stack)
-  const int grid = std::min((int)roles.size(), s->ps_grid);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   prof_tag(KC_PERSIST, 0.0);                   // (its necessary bytes are known when the rows' lengths are: added by the caller)
   const bool timed = prof_take_events(&e0, &e1);
