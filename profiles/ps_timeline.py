@@ -1,40 +1,47 @@
 #!/usr/bin/env python3
-"""Role timeline of the persistent decode kernel (WHISPER_HIP_PS_STAMPS=<file> python bench.py ...): per role kind and layer,
-how long a role sat in its wait (prefetch issued -> producers arrived) and how long it ran after the wait; per step, the
-critical chain (merge done -> next merge done).  Clock: s_memrealtime, 100 MHz (10 ns ticks).
-    python profiles/ps_timeline.py stamps.bin [first_step last_step]"""
+"""Role timeline of the persistent decode kernel (WHISPER_HIP_PS_STAMPS=<file> python bench.py ...).
+Per role kind and layer, over the roles of LIVE rows only (a row whose window has ended skips its attention roles): the
+time from role start to the wait being passed, the phases after the wait, and the arrive; per step, the critical chain.
+Stamp slots: 0 role start, 1 wait passed, 2-5 phases inside the role, 6 done, 7 arrived.  Clock: 100 MHz (10 ns ticks).
+    python profiles/ps_timeline.py stamps.bin [first_step last_step] [row]"""
 import sys
 
 import numpy as np
 
 raw = np.fromfile(sys.argv[1], dtype=np.uint8)
-hdr = raw[:16].view(np.int32)
-n_steps, n_roles, grid, _ = [int(x) for x in hdr]
+n_steps, n_roles, grid, ns = [int(x) for x in raw[:16].view(np.int32)]
 kinds = raw[16:16 + 4 * n_roles].view(np.int32)
-st = raw[16 + 4 * n_roles:].view(np.uint64).reshape(n_steps, n_roles, 3).astype(np.int64)
+st = raw[16 + 4 * n_roles:].view(np.uint64).reshape(n_steps, n_roles, ns).astype(np.float64)
+st[st == 0] = np.nan
 names = {0: "attn", 1: "cross", 2: "mlp", 3: "logits", 4: "merge"}
-ran = st[:, :, 2] > 0
+kind, layer, row = kinds & 0xff, (kinds >> 8) & 0xff, kinds >> 16
+ran = ~np.isnan(st[:, :, 6])
 last = int(np.nonzero(ran.any(1))[0].max()) + 1 if ran.any() else 0
-lo = int(sys.argv[2]) if len(sys.argv) > 2 else min(8, last - 1)
+lo = int(sys.argv[2]) if len(sys.argv) > 2 else min(8, max(last - 1, 0))
 hi = int(sys.argv[3]) if len(sys.argv) > 3 else last
-print(f"steps stamped {last} of {n_steps}, roles/step {n_roles}, grid {grid}; statistics over steps [{lo}, {hi})")
-tick = 0.01   # us
+live_row = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+tick = 0.01
+print(f"steps stamped {last} of {n_steps}, roles/step {n_roles}, grid {grid}; statistics over steps [{lo}, {hi}), attention roles of row {live_row}")
 sel = st[lo:hi]
-t0 = sel[:, :, 0].astype(float); t1 = sel[:, :, 1].astype(float); t2 = sel[:, :, 2].astype(float)
-ok = sel[:, :, 2] > 0
-print(f"{'role':<14}{'n':>5}{'wait us':>10}{'run us':>10}{'done-after-step-start':>24}")
-merge_done = np.where(ok[:, kinds & 0xff == 4], t2[:, kinds & 0xff == 4], np.nan)
+merge_done = sel[:, kind == 4, 7]
 step_end = np.nanmax(merge_done, axis=1)
 step_start = np.concatenate([[np.nan], step_end[:-1]])
-for key in sorted(set(int(k) for k in kinds), key=lambda k: ((k & 0xff) >= 3, k >> 8, k & 0xff)):
-    cols = kinds == key
-    m = ok[:, cols]
-    if not m.any():
-        continue
-    w = (t1[:, cols] - t0[:, cols])[m] * tick
-    r = (t2[:, cols] - t1[:, cols])[m] * tick
-    rel = (np.nanmax(np.where(m, t2[:, cols], np.nan), axis=1) - step_start) * tick
-    nm = names[key & 0xff] + (f" L{key >> 8}" if (key & 0xff) < 3 else "")
-    print(f"{nm:<14}{int(cols.sum()):>5}{w.mean():>10.2f}{r.mean():>10.2f}{np.nanmean(rel):>24.2f}")
-d = np.diff(step_end) * tick
-print(f"step time (merge done -> next merge done): mean {np.nanmean(d):.2f} us, median {np.nanmedian(d):.2f}, min {np.nanmin(d):.2f}, max {np.nanmax(d):.2f}")
+hdr = f"{'role':<10}{'n':>4}{'wait':>8}{'w->p2':>8}{'p2->p3':>8}{'p3->p4':>8}{'p4->p5':>8}{'p5->done':>9}{'arrive':>8}{'run':>8}{'done@':>9}{'arrived@':>9}"
+print(hdr)
+for k in (0, 1, 2, 3, 4):
+    for l in sorted(set(layer[kind == k])):
+        cols = (kind == k) & (layer == l)
+        if k in (0, 1):
+            cols &= row == live_row
+        if not cols.any():
+            continue
+        s = sel[:, cols, :]
+        def d(a, b):
+            x = (s[:, :, b] - s[:, :, a]) * tick
+            return np.nanmean(x) if np.isfinite(x).any() else float("nan")
+        rel_done = np.nanmean((np.nanmax(s[:, :, 6], axis=1) - step_start) * tick)
+        rel_arr = np.nanmean((np.nanmax(s[:, :, 7], axis=1) - step_start) * tick)
+        nm = names[k] + (f" L{l}" if k < 3 else "")
+        print(f"{nm:<10}{int(cols.sum()):>4}{d(0,1):>8.2f}{d(1,2):>8.2f}{d(2,3):>8.2f}{d(3,4):>8.2f}{d(4,5):>8.2f}{d(5,6):>9.2f}{d(6,7):>8.2f}{d(1,6):>8.2f}{rel_done:>9.2f}{rel_arr:>9.2f}")
+dd = np.diff(step_end) * tick
+print(f"step time (merge arrived -> next merge arrived): mean {np.nanmean(dd):.2f} us, median {np.nanmedian(dd):.2f}, min {np.nanmin(dd):.2f}, max {np.nanmax(dd):.2f}")

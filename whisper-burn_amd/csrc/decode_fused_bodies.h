@@ -24,12 +24,16 @@ struct PsStep {
   int n_rows = 0;                // rows of the chain (= windows: one beam per window)
   const int* dead = nullptr;     // [S]: rows whose window has ended (written by the merge role, sc1)
   int* lds_flag = nullptr;       // one LDS word for the wait's broadcast
-  unsigned long long* stamp = nullptr;   // optional timeline slot: when the wait was passed
+  unsigned long long* stamp = nullptr;   // optional timeline slots of this role invocation (PS_STAMPS of them)
 };
+constexpr int PS_STAMPS = 8;     // 0 role start, 1 wait passed, 2-5 phases inside the role, 6 done, 7 arrived
+__device__ __forceinline__ void ps_stamp(const PsStep& ps, int k) {
+  if (ps.stamp && threadIdx.x == 0) ps.stamp[k] = wall_clock64();
+}
 // wait for the role's producers (all threads of the block); false: the decode was stopped -- leave the kernel
 __device__ __forceinline__ bool ps_wait(const PsStep& ps) {
   const bool ok = hx_wait(ps.ctr, ps.target, ps.ctl, ps.step, ps.ctr_index, ps.lds_flag);
-  if (ps.stamp && threadIdx.x == 0) *ps.stamp = wall_clock64();
+  ps_stamp(ps, 1);
   return ok;
 }
 
@@ -522,6 +526,7 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
 #pragma unroll
   for (int i = 0; i < PSL; i++) vc[i] = ld_f4<PS>(a.Vc, vbuf, (uint32_t)(slot[i] * d + h * 64 + pq4));
   WB_STAMP(1);
+  if constexpr (PS) ps_stamp(ps, 2);
   __syncthreads();
   if (wave == 0) ln_row_lds<DPL>(hs, d, lane, gv, bv, a.ln_eps, a.ln_inside);
   __syncthreads();
@@ -544,6 +549,7 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
     }
   }
   WB_STAMP(3);
+  if constexpr (PS) ps_stamp(ps, 3);
   __syncthreads();   // (also pins the loads below behind the FMAs: the weight registers are free now)
   // ---- requested now: the Wo slice (consumed last)
   const int cf = tid % CF, jg = tid / CF;
@@ -608,6 +614,7 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
   }
   __syncthreads();
   WB_STAMP(5);
+  if constexpr (PS) ps_stamp(ps, 4);
   // softmax statistics, redundantly per wave (no extra barrier): m, l over all positions
   float m = -INFINITY;
   for (int p = lane; p < len; p += 64) m = fmaxf(m, sc[p]);
@@ -651,6 +658,7 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
   }
   __syncthreads();
   WB_STAMP(6);
+  if constexpr (PS) ps_stamp(ps, 5);
   // ---- plane h, row r = att Wo[head h rows, :]
   float ov[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -806,6 +814,7 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
   }
   const float qbias = tid < 64 ? a.bq[h * 64 + tid] : 0.f;
   if constexpr (!PS) load_keys();
+  if constexpr (PS) ps_stamp(ps, 2);
   __syncthreads();
   if (wave == 0) ln_row_lds<DPL>(hs, d, lane, gv, bv, a.ln_eps, a.ln_inside);
   __syncthreads();
@@ -839,6 +848,7 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
     qv[tid] = (v + qbias) * a.scale;
   }
   __syncthreads();
+  if constexpr (PS) ps_stamp(ps, 3);
   // ---- scores: partial dot over this thread's quad, summed over the 16 lanes of the key row; the register then
   // takes the V row of the same key
   {
@@ -858,6 +868,7 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
       }
   }
   __syncthreads();
+  if constexpr (PS) ps_stamp(ps, 4);
   // softmax statistics, redundantly per wave (no extra barrier); then the probabilities, two keys per thread
   float m = -INFINITY;
   for (int j = lane; j < C; j += 64) m = fmaxf(m, sc[j]);
@@ -888,6 +899,7 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
     att[tid] = v / l;
   }
   __syncthreads();
+  if constexpr (PS) ps_stamp(ps, 5);
   // ---- plane h, row r = att Wo[head h rows, :]
   float ov[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

@@ -54,7 +54,7 @@ constexpr int PS_CT = 128;      // vocabulary columns per logits tile
 template <int MR, int DPL>
 __device__ __forceinline__ bool ps_logits_role(const PersistArgs& a, const int tile0, const int n_t, const PsStep& ps) {
   constexpr int d = 64 * DPL, NT = PS_NT, CT = PS_CT;
-  constexpr int NR = d / 16;                        // E^T rows per thread: k = 16 i + 2 wave + hh
+  constexpr int NR = d / 16;                        // E^T rows per thread: k = (2 wave + hh) NR + i
   constexpr int EPT = (MR * d + NT - 1) / NT;
   constexpr int PCH = EPT <= 3 ? 8 : EPT <= 6 ? 4 : 2;
   constexpr int NQ = MR * CT / NT;                  // tile values per thread in the column-sum pass
@@ -64,12 +64,15 @@ __device__ __forceinline__ bool ps_logits_role(const PersistArgs& a, const int t
   const int tid = role_tid<true>(), lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, c4 = (lane & 31) * 4;
   float4 w[NR];
+  // (buffer loads: one lane offset, the row offset 16 i vocab_ld rides in the scalar offset -- 24 64-bit addresses
+  // per lane would otherwise live across the tile loop)
+  const Buf16 etb(a.Et);
   auto load_tile = [&](int tile) {
     const int n0 = tile * CT;
     const bool col_ok = n0 + c4 < a.vocab_ld;      // lanes past the padded vocabulary re-read the tile's first columns
-    const float* wp = a.Et + (int64_t)(2 * wave + hh) * a.vocab_ld + n0 + (col_ok ? c4 : 0);
+    const uint32_t vo = (uint32_t)((2 * wave + hh) * NR * a.vocab_ld + n0 + (col_ok ? c4 : 0));
 #pragma unroll
-    for (int i = 0; i < NR; i++) w[i] = *reinterpret_cast<const float4*>(wp + (int64_t)(16 * i) * a.vocab_ld);
+    for (int i = 0; i < NR; i++) w[i] = ld_f4_plain(etb, vo, (uint32_t)(i * a.vocab_ld));
   };
   load_tile(tile0);
   float gv[DPL], bv[DPL];
@@ -108,9 +111,11 @@ __device__ __forceinline__ bool ps_logits_role(const PersistArgs& a, const int t
       if (e < MR * d) (&xs[0][0])[e] = v[i] + acc[i];
     }
   }
+  ps_stamp(ps, 2);
   __syncthreads();
   if (wave < MR) ln_row_lds<DPL>(xs[wave], d, lane, gv, bv, a.ln_eps, a.ln_inside);
   __syncthreads();
+  ps_stamp(ps, 3);
   for (int t = 0; t < n_t; t++) {                   // the role's tiles share the fold + LayerNorm above
     const int tile = tile0 + t, n0 = tile * CT;
     float mk[NQ];
@@ -122,15 +127,21 @@ __device__ __forceinline__ bool ps_logits_role(const PersistArgs& a, const int t
     float acc[MR][4];
 #pragma unroll
     for (int r = 0; r < MR; r++) { acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.f; }
+    // this thread's E^T rows are k = (2 wave + hh) NR + i: one 16-byte LDS read serves four of them; the reads of a
+    // group of four rows are fenced from the next group's (all 24 x MR hoisted to the top would not fit next to the tile)
 #pragma unroll
-    for (int i = 0; i < NR; i++) {
-      const int k = 16 * i + 2 * wave + hh;
+    for (int i4 = 0; i4 < NR; i4 += 4) {
 #pragma unroll
       for (int r = 0; r < MR; r++) {
-        const float xv = xs[r][k];
-        acc[r][0] += xv * w[i].x; acc[r][1] += xv * w[i].y; acc[r][2] += xv * w[i].z; acc[r][3] += xv * w[i].w;
+        const float4 xv = *reinterpret_cast<const float4*>(&xs[r][(2 * wave + hh) * NR + i4]);
+        acc[r][0] += xv.x * w[i4].x; acc[r][1] += xv.x * w[i4].y; acc[r][2] += xv.x * w[i4].z; acc[r][3] += xv.x * w[i4].w;
+        acc[r][0] += xv.y * w[i4 + 1].x; acc[r][1] += xv.y * w[i4 + 1].y; acc[r][2] += xv.y * w[i4 + 1].z; acc[r][3] += xv.y * w[i4 + 1].w;
+        acc[r][0] += xv.z * w[i4 + 2].x; acc[r][1] += xv.z * w[i4 + 2].y; acc[r][2] += xv.z * w[i4 + 2].z; acc[r][3] += xv.z * w[i4 + 2].w;
+        acc[r][0] += xv.w * w[i4 + 3].x; acc[r][1] += xv.w * w[i4 + 3].y; acc[r][2] += xv.w * w[i4 + 3].z; acc[r][3] += xv.w * w[i4 + 3].w;
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
+    if (t == 0) ps_stamp(ps, 4);
     if (t + 1 < n_t) load_tile(tile + 1);           // the weight registers are free: the next tile streams under this
                                                     // tile's reduction and statistics
 #pragma unroll
@@ -184,7 +195,7 @@ __device__ __forceinline__ bool ps_merge_role(const PersistArgs& a, const int r,
     ps.ctr = clog + k * HX_LINE; ps.target = (unsigned)(e + 1) * (unsigned)n_per_ctr[k]; ps.ctr_index = 1000 + k;
     if (!hx_wait(ps.ctr, ps.target, ps.ctl, ps.step, ps.ctr_index, ps.lds_flag)) return false;
   }
-  if (ps.stamp && threadIdx.x == 0) *ps.stamp = wall_clock64();
+  ps_stamp(ps, 1);
   const int len = ps.step + 1;                      // tokens in the row so far; the new one lands at index len
   const int fin_now = ld_i<true>(a.dead + r);
   const int tok_prev = ld_i<true>(a.gctl + GC_HDR + r);
@@ -253,9 +264,9 @@ __global__ __launch_bounds__(PS_NT) void dec_persist_kernel(PersistArgs a) {
       const PsRole role = a.roles[i];
       PsStep ps;
       ps.ctl = a.ctl; ps.step = a.step0 + e; ps.n_rows = R; ps.dead = a.dead; ps.lds_flag = &wait_flag;
-      unsigned long long* stp = a.stamps ? a.stamps + ((size_t)e * a.n_roles + i) * 3 : nullptr;
+      unsigned long long* stp = a.stamps ? a.stamps + ((size_t)e * a.n_roles + i) * PS_STAMPS : nullptr;
       if (stp && threadIdx.x == 0) stp[0] = wall_clock64();
-      ps.stamp = stp ? stp + 1 : nullptr;
+      ps.stamp = stp;
       int out;
       bool ok;
       if (role.kind == PSR_ATTN) {
@@ -287,8 +298,9 @@ __global__ __launch_bounds__(PS_NT) void dec_persist_kernel(PersistArgs a) {
         out = C_X + role.b;
       }
       if (!ok) return;                               // the decode was stopped (or a wait gave up): leave
-      if (stp && threadIdx.x == 0) stp[2] = wall_clock64();
+      if (stp && threadIdx.x == 0) stp[6] = wall_clock64();
       hx_arrive(cptr(out));
+      if (stp && threadIdx.x == 0) stp[7] = wall_clock64();
     }
   }
 }

@@ -76,6 +76,11 @@ __device__ __forceinline__ float4 ld_f4(const float* base, const Buf16& b, uint3
     return *reinterpret_cast<const float4*>(base + elem_off);
   }
 }
+// 16-byte load at element offset elem_soff (wave-uniform) + elem_voff, default cache policy
+__device__ __forceinline__ float4 ld_f4_plain(const Buf16& b, uint32_t elem_voff, uint32_t elem_soff) {
+  const hx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b.r, elem_voff * 4u, elem_soff * 4u, 0);
+  return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
 // 4-byte load at base[elem_soff + elem_voff]: `elem_soff` must be wave-uniform (it rides in the instruction's scalar
 // offset, so the per-lane offset register is shared by all planes of a fold)
 template <bool SC1>

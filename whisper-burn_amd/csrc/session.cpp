@@ -832,7 +832,7 @@ static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_
   a.E = m->tok_emb; a.pos = m->dec_pos; a.x0 = xb[0]; a.tabs = s->tabs.as<int>(); a.dead = s->ps_dead.as<int>();
   // optional role timeline (developer): WHISPER_HIP_PS_STAMPS=<file> dumps [n_steps][n_roles][3] 100 MHz clock values
   static const char* stamps_path = getenv("WHISPER_HIP_PS_STAMPS");
-  const size_t n_stamps = stamps_path ? (size_t)max_depth * roles.size() * 3 : 0;
+  const size_t n_stamps = stamps_path ? (size_t)max_depth * roles.size() * 8 : 0;
   if (n_stamps) {
     WB_TRY(s->ps_stamps.ensure(n_stamps * 8));
     WB_HIP(hipMemsetAsync(s->ps_stamps.p, 0, n_stamps * 8, st));
@@ -859,10 +859,11 @@ static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_
     std::vector<unsigned long long> hs(n_stamps);
     WB_HIP(hipMemcpy(hs.data(), s->ps_stamps.p, n_stamps * 8, hipMemcpyDeviceToHost));
     if (FILE* f = fopen(stamps_path, "wb")) {
-      const int hdr[4] = {max_depth, (int)roles.size(), grid, 3};
+      const int hdr[4] = {max_depth, (int)roles.size(), grid, 8};
       fwrite(hdr, 4, 4, f);
       std::vector<int> kinds(roles.size());
-      for (size_t i = 0; i < roles.size(); i++) kinds[i] = roles[i].kind | (roles[i].layer << 8);
+      for (size_t i = 0; i < roles.size(); i++)
+        kinds[i] = roles[i].kind | ((roles[i].kind <= PSR_MLP ? roles[i].layer : 0) << 8) | (roles[i].b << 16);
       fwrite(kinds.data(), 4, kinds.size(), f);
       fwrite(hs.data(), 8, hs.size(), f);
       fclose(f);

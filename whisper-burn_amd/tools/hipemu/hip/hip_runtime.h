@@ -230,6 +230,7 @@ static inline unsigned hipemu_raw_buffer_load_b32(hipemu_rsrc r, unsigned voff, 
 #define __builtin_amdgcn_raw_buffer_load_b128 hipemu_raw_buffer_load_b128
 #define __builtin_amdgcn_raw_buffer_store_b128 hipemu_raw_buffer_store_b128
 #define __builtin_amdgcn_s_sleep(n) hipemu::spin_yield()
+#define __builtin_amdgcn_sched_barrier(m) ((void)0)
 
 // ---- wave collectives (the builtins of the gfx950 target, by their ISA semantics) ------------------------------
 typedef unsigned hipemu_u32x2 __attribute__((ext_vector_type(2)));
