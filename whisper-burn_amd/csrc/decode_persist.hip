@@ -58,23 +58,28 @@ __device__ __forceinline__ bool ps_logits_role(const PersistArgs& a, const int t
   constexpr int EPT = (MR * d + NT - 1) / NT;
   constexpr int PCH = EPT <= 3 ? 8 : EPT <= 6 ? 4 : 2;
   constexpr int NQ = MR * CT / NT;                  // tile values per thread in the column-sum pass
+  constexpr bool TWO = DPL <= 6;                    // two tiles resident (2 x d / 16 float4 per thread) where they fit
   __shared__ __attribute__((aligned(16))) float xs[MR][d];
   __shared__ __attribute__((aligned(16))) float red[8][MR][CT];
   __shared__ float tilev[MR][CT];
   const int tid = role_tid<true>(), lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, c4 = (lane & 31) * 4;
-  float4 w[NR];
-  // (buffer loads: one lane offset, the row offset 16 i vocab_ld rides in the scalar offset -- 24 64-bit addresses
-  // per lane would otherwise live across the tile loop)
+  // (buffer loads: one lane offset, the row offset i vocab_ld rides in the scalar offset -- 24 64-bit addresses per lane
+  // would otherwise live across the tile loop)
   const Buf16 etb(a.Et);
-  auto load_tile = [&](int tile) {
+  auto load_tile = [&](float4 (&w)[NR], int tile) {
     const int n0 = tile * CT;
     const bool col_ok = n0 + c4 < a.vocab_ld;      // lanes past the padded vocabulary re-read the tile's first columns
     const uint32_t vo = (uint32_t)((2 * wave + hh) * NR * a.vocab_ld + n0 + (col_ok ? c4 : 0));
 #pragma unroll
     for (int i = 0; i < NR; i++) w[i] = ld_f4_plain(etb, vo, (uint32_t)(i * a.vocab_ld));
   };
-  load_tile(tile0);
+  // Both tiles of the role are requested BEFORE the wait where the registers allow it: streamed after the wait, the
+  // second tile of 203 blocks (40 MB at once, next to everybody's weight prefetch for the next step) took ~20 us
+  // (profiles/r03_c_ps_timeline_phases.txt).
+  float4 w0[NR], w1[TWO ? NR : 1];
+  load_tile(w0, tile0);
+  if constexpr (TWO) { if (n_t > 1) load_tile(w1, tile0 + 1); }
   float gv[DPL], bv[DPL];
 #pragma unroll
   for (int i = 0; i < DPL; i++) { gv[i] = a.ln_g[lane + 64 * i]; bv[i] = a.ln_b[lane + 64 * i]; }
@@ -116,8 +121,9 @@ __device__ __forceinline__ bool ps_logits_role(const PersistArgs& a, const int t
   if (wave < MR) ln_row_lds<DPL>(xs[wave], d, lane, gv, bv, a.ln_eps, a.ln_inside);
   __syncthreads();
   ps_stamp(ps, 3);
-  for (int t = 0; t < n_t; t++) {                   // the role's tiles share the fold + LayerNorm above
-    const int tile = tile0 + t, n0 = tile * CT;
+  // one tile: GEMV from the registers, column sums over the eight waves, mask, per-row best (value desc, id asc)
+  auto run_tile = [&](const float4 (&w)[NR], int tile) {
+    const int n0 = tile * CT;
     float mk[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
@@ -127,8 +133,6 @@ __device__ __forceinline__ bool ps_logits_role(const PersistArgs& a, const int t
     float acc[MR][4];
 #pragma unroll
     for (int r = 0; r < MR; r++) { acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.f; }
-    // this thread's E^T rows are k = (2 wave + hh) NR + i: one 16-byte LDS read serves four of them; the reads of a
-    // group of four rows are fenced from the next group's (all 24 x MR hoisted to the top would not fit next to the tile)
 #pragma unroll
     for (int i4 = 0; i4 < NR; i4 += 4) {
 #pragma unroll
@@ -139,22 +143,18 @@ __device__ __forceinline__ bool ps_logits_role(const PersistArgs& a, const int t
         acc[r][0] += xv.z * w[i4 + 2].x; acc[r][1] += xv.z * w[i4 + 2].y; acc[r][2] += xv.z * w[i4 + 2].z; acc[r][3] += xv.z * w[i4 + 2].w;
         acc[r][0] += xv.w * w[i4 + 3].x; acc[r][1] += xv.w * w[i4 + 3].y; acc[r][2] += xv.w * w[i4 + 3].z; acc[r][3] += xv.w * w[i4 + 3].w;
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
-    if (t == 0) ps_stamp(ps, 4);
-    if (t + 1 < n_t) load_tile(tile + 1);           // the weight registers are free: the next tile streams under this
-                                                    // tile's reduction and statistics
 #pragma unroll
     for (int r = 0; r < MR; r++)
 #pragma unroll
       for (int c = 0; c < 4; c++) acc[r][c] = xor32_sum(acc[r][c]);        // the two row halves of the wave
+    __syncthreads();                                // (the previous tile's readers of red / tilev are done)
     if (hh == 0) {
 #pragma unroll
       for (int r = 0; r < MR; r++)
         *reinterpret_cast<float4*>(&red[wave][r][c4]) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
     }
     __syncthreads();
-    // column sums over the eight waves (fixed order), + mask; then one wave per row: best (value desc, id asc)
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
       const int e = tid + NT * q, r = e / CT, c = e & (CT - 1);
@@ -178,6 +178,15 @@ __device__ __forceinline__ bool ps_logits_role(const PersistArgs& a, const int t
         st_f<true>(ts + 1, __int_as_float(n0 + bi));
       }
     }
+  };
+  run_tile(w0, tile0);
+  ps_stamp(ps, 4);
+  if constexpr (TWO) {
+    if (n_t > 1) run_tile(w1, tile0 + 1);
+    ps_stamp(ps, 5);
+    for (int t = 2; t < n_t; t++) { load_tile(w0, tile0 + t); run_tile(w0, tile0 + t); }
+  } else {
+    for (int t = 1; t < n_t; t++) { load_tile(w0, tile0 + t); run_tile(w0, tile0 + t); }
   }
   return true;
 }
