@@ -455,6 +455,7 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
   };
   float xfold;                                     // this thread's element of x + pending (kept for the final x_out store)
   float gv[DPL], bv[DPL];                          // LayerNorm parameters (wave 0 normalises)
+  float qbias = 0.f;
   {
     // x + (bias + partial planes), s ascending (mod.rs:346-348): one element per thread, all planes in flight together
     const int c = tid < d ? tid : 0;
@@ -467,6 +468,7 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
       }
       load_round(wr[0], 0);
       if (NIT > 1) load_round(wr[1], 1);
+      if constexpr (PS) { if (tid < 192) qbias = a.bqkv[(tid >> 6) * d + h * 64 + (tid & 63)]; }
     };
     if constexpr (PS) {
       // persistent mode: the first weight rounds are in flight (or landed) while the block waits for the MLP planes
@@ -502,7 +504,7 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
     xfold = v;
     if (tid < d) hs[tid] = v;
   }
-  const float qbias = tid < 192 ? a.bqkv[(tid >> 6) * d + h * 64 + (tid & 63)] : 0.f;   // key part is zero (mod.rs:402-404)
+  if constexpr (!PS) qbias = tid < 192 ? a.bqkv[(tid >> 6) * d + h * 64 + (tid & 63)] : 0.f;   // key part is zero (mod.rs:402-404)
   // ---- the cached K / V rows of the first 128 positions, the coalesced way (16 lanes x 16 B = one 256-byte head row;
   // thread (rg, pq4) holds quad pq4 of positions rg + 32 i): requested HERE, behind the first two weight rounds, so
   // that they arrive under the QKV FMAs instead of costing two dependent round trips after them.  Positions past the
@@ -741,11 +743,13 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
   float4 wqr[NWQ];
   float4 kv[NTILE][SL];
   const float* Kh; const float* Vh; int C;
+  float qbias = 0.f;
   auto load_weights = [&]() {
     if (wave == 0) {
 #pragma unroll
       for (int i = 0; i < DPL; i++) { gv[i] = a.ln_g[lane + 64 * i]; bv[i] = a.ln_b[lane + 64 * i]; }
     }
+    if constexpr (PS) { if (tid < 64) qbias = a.bq[h * 64 + tid]; }
     {
       const float* wp = a.Wq + (int64_t)rg * d + h * 64 + c4;
 #pragma unroll
@@ -812,7 +816,7 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
     xfold = v;
     if (tid < d) hs[tid] = v;
   }
-  const float qbias = tid < 64 ? a.bq[h * 64 + tid] : 0.f;
+  if constexpr (!PS) qbias = tid < 64 ? a.bq[h * 64 + tid] : 0.f;
   if constexpr (!PS) load_keys();
   if constexpr (PS) ps_stamp(ps, 2);
   __syncthreads();

@@ -46,6 +46,7 @@ using namespace fused;
 
 constexpr int PS_NT = 512;
 constexpr int PS_CT = 128;      // vocabulary columns per logits tile
+constexpr int PS_NGO = 16;      // wake-up words of the logits roles (a few hundred pollers: ~13 per word)
 
 // ---- logits role: tile t of  ln(x + b2 + sum_j P2[j]) . E^T  (mod.rs:155-156), last position only -----------------
 // The E^T tile (d x 128 floats = d / 16 float4 per thread) is in flight before the wait.  Each block folds and
@@ -198,11 +199,13 @@ __device__ __forceinline__ bool ps_merge_role(const PersistArgs& a, const int r,
   __shared__ float redv[8];
   __shared__ int redi[8];
   const int tid = role_tid<true>(), lane = tid & 63, wave = tid >> 6;
-  PsStep ps = ps0;
-  for (int k = 0; k < 8; k++) {                     // every tile of this step has arrived (8 sharded counters)
-    if (n_per_ctr[k] == 0) continue;
-    ps.ctr = clog + k * HX_LINE; ps.target = (unsigned)(e + 1) * (unsigned)n_per_ctr[k]; ps.ctr_index = 1000 + k;
-    if (!hx_wait(ps.ctr, ps.target, ps.ctl, ps.step, ps.ctr_index, ps.lds_flag)) return false;
+  const PsStep& ps = ps0;
+  {
+    // every logits role of this step has arrived (8 sharded counters, polled by 8 lanes at once)
+    __shared__ unsigned tgt[8];
+    if (tid < 8) tgt[tid] = (unsigned)(e + 1) * (unsigned)n_per_ctr[tid];
+    __syncthreads();
+    if (!hx_wait_many(clog, tgt, 8, ps.ctl, ps.step, 1000, ps.lds_flag)) return false;
   }
   ps_stamp(ps, 1);
   const int len = ps.step + 1;                      // tokens in the row so far; the new one lands at index len
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(PS_NT) void dec_persist_kernel(PersistArgs a) {
   const int NL = a.n_layer, S = a.S, R = a.n_rows, H = a.n_head, NB = a.nb_mlp;
   // arrival counter c lives at ctl[HX_HDR + c HX_LINE]: one 128-byte line each
   auto cptr = [&](int c) { return reinterpret_cast<unsigned*>(a.ctl + HX_HDR + c * HX_LINE); };
-  const int C_X = 0, C_ATTN = S, C_CROSS = S + NL * S, C_MLP = C_CROSS + NL, C_LOG = C_MLP + NL;
+  const int C_X = 0, C_ATTN = S, C_CROSS = S + NL * S, C_MLP = C_CROSS + NL, C_LOG = C_MLP + NL, C_GO = C_LOG + 8;
   int n_per_ctr[8];
 #pragma unroll
   for (int k = 0; k < 8; k++) n_per_ctr[k] = (a.n_logits_roles + 7 - k) / 8;
@@ -298,7 +301,8 @@ __global__ __launch_bounds__(PS_NT) void dec_persist_kernel(PersistArgs a) {
         ok = dec_mlp_body<MR, DPL, false, true>(la, role.a, ps);
         out = C_MLP + role.layer;
       } else if (role.kind == PSR_LOGITS) {
-        ps.ctr_index = C_MLP + NL - 1; ps.target = (unsigned)(e + 1) * NB;
+        // (woken by the last MLP block of the step through one of PS_NGO words: hx_arrive_broadcast)
+        ps.ctr_index = C_GO + (role.layer % PS_NGO); ps.target = (unsigned)(e + 1);
         ps.ctr = cptr(ps.ctr_index);
         ok = ps_logits_role<MR, DPL>(a, role.a, role.b, ps);
         out = C_LOG + (role.layer & 7);
@@ -308,7 +312,10 @@ __global__ __launch_bounds__(PS_NT) void dec_persist_kernel(PersistArgs a) {
       }
       if (!ok) return;                               // the decode was stopped (or a wait gave up): leave
       if (stp && threadIdx.x == 0) stp[6] = wall_clock64();
-      hx_arrive(cptr(out));
+      if (role.kind == PSR_MLP && role.layer == NL - 1)
+        hx_arrive_broadcast(cptr(out), (unsigned)(e + 1) * NB, cptr(C_GO), PS_NGO, (unsigned)(e + 1));
+      else
+        hx_arrive(cptr(out));
       if (stp && threadIdx.x == 0) stp[7] = wall_clock64();
     }
   }
@@ -323,7 +330,7 @@ int max_blocks_per_cu() {
 
 }  // namespace
 
-int ps_ctl_ints(int S, int n_layer) { return HX_HDR + (S + n_layer * S + 2 * n_layer + 8) * HX_LINE; }
+int ps_ctl_ints(int S, int n_layer) { return HX_HDR + (S + n_layer * S + 2 * n_layer + 8 + PS_NGO) * HX_LINE; }
 
 // d = 512 with more than 4 rows would need > 160 KB of LDS (every role's LDS is resident at once)
 bool dec_persist_supported(int d, int n_rows) {

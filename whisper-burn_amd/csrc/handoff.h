@@ -146,4 +146,50 @@ __device__ __forceinline__ bool hx_wait(const unsigned* ctr, unsigned target, co
   return ok != 0;
 }
 
+// Wait until ctr[k HX_LINE] >= target[k] for every k < n (n <= 64): lane k of wave 0 polls counter k, so that the wait costs
+// ONE detection latency instead of n.  Same contract as hx_wait.
+__device__ __forceinline__ bool hx_wait_many(const unsigned* ctr, const unsigned* target, int n, const int* ctl, int step,
+                                             int ctr_index, int* lds_flag) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const bool mine = lane < n;
+    const unsigned tgt = mine ? target[lane] : 0u;
+    int ok = 1;
+    unsigned spins = 0;
+    for (;;) {
+      const bool have = !mine || __hip_atomic_load(ctr + lane * HX_LINE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= tgt;
+      if (__ballot(!have) == 0ull) break;
+      if ((spins & 15u) == 15u &&
+          (__hip_atomic_load(ctl + HX_STOP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= step ||
+           __hip_atomic_load(ctl + HX_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { ok = 0; break; }
+      if (++spins > HX_SPIN_LIMIT) {
+        if (lane == 0) __hip_atomic_store(const_cast<int*>(ctl) + HX_ERR, 1 + ctr_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (ok && __hip_atomic_load(ctl + HX_STOP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= step) ok = 0;
+    if (lane == 0) *lds_flag = ok;
+  }
+  __syncthreads();
+  const int ok = *lds_flag;
+  __syncthreads();
+  return ok != 0;
+}
+
+// Arrive, and if this block is the LAST of the epoch's `total` arrivals (the counter reaches `full`), wake the many
+// consumers of this stage through `n_go` words on lines of their own: hundreds of blocks polling ONE word see a new
+// value only after the whole queue of polls in front of it has been served (measured ~6 us for 203 pollers).  Every
+// earlier arriver drained its stores before its add, so the payload of all of them is in memory when the words change.
+__device__ __forceinline__ void hx_arrive_broadcast(unsigned* ctr, unsigned full, unsigned* go, int n_go, unsigned epoch) {
+  WB_DRAIN_VMEM();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1u == full)
+      for (int k = 0; k < n_go; k++) __hip_atomic_store(go + k * HX_LINE, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 }  // namespace wb
