@@ -9,7 +9,7 @@ timeout 600 python -m pytest tests/test_gpu_workloads.py tests/test_gpu_session.
 tail -3 "$OUT/pytest_persist.log"
 for i in 1 2; do
   WHISPER_HIP_PERSIST=0 timeout 300 python bench.py --steps 30 --warmup 3 --no-cpu-baseline --mel-windows 8 2>&1 | grep '^{"metric' > "$OUT/bench_chain_$i.json"
-  timeout 300 python bench.py --steps 30 --warmup 3 --no-cpu-baseline --mel-windows 8 2>&1 | grep '^{"metric' > "$OUT/bench_persist_$i.json"
+  WHISPER_HIP_PERSIST=1 timeout 300 python bench.py --steps 30 --warmup 3 --no-cpu-baseline --mel-windows 8 2>&1 | grep '^{"metric' > "$OUT/bench_persist_$i.json"
 done
 python - <<'PY'
 import json, glob
@@ -19,6 +19,6 @@ for f in sorted(glob.glob("gpurun_out/r03c/bench_*.json")):
     except Exception as e:
         print(f, "unreadable", e)
 PY
-WHISPER_HIP_PS_STAMPS=$OUT/stamps.bin timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --mel-windows 8 > "$OUT/bench_stamps.log" 2>&1
+WHISPER_HIP_PERSIST=1 WHISPER_HIP_PS_STAMPS=$OUT/stamps.bin timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --mel-windows 8 > "$OUT/bench_stamps.log" 2>&1
 python profiles/ps_timeline.py "$OUT/stamps.bin" > "$OUT/ps_timeline.txt" 2>&1
 cat "$OUT/ps_timeline.txt"

@@ -53,15 +53,19 @@ def test_chained_greedy_windows_ending_at_different_steps(emu_lib, which, env):
     assert p.returncode == 0 and f"EMU_CHECK_OK {which}" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
-@pytest.mark.parametrize("which,env", [("chain_eot", {"HIPEMU_CUS": "7"}), ("chain_eot", {"WHISPER_HIP_PERSIST": "0"}),
+@pytest.mark.parametrize("which,env", [("chain_eot", {"HIPEMU_CUS": "7"}), ("greedy", {}),
                                        ("persist384", {}), ("persist384x7", {"HIPEMU_CUS": "40"}),
                                        ("persist512", {"HIPEMU_CUS": "33", "HIPEMU_ORDER": "reverse"})])
 def test_persistent_flag_chained_decode_under_the_functional_model(emu_lib, which, env):
     """decode_persist.hip: ONE co-resident grid runs every sublayer of every greedy step, blocks hand planes to each other
     through arrival counters (the functional model runs every block on its own thread and passes a baton whenever a block
     spins).  Token-exact against the oracle for d = 128 / 384 / 512, 4 and 7 rows, one role per block and several roles
-    per block (HIPEMU_CUS shrinks the grid), both block orders; and the launch-per-sublayer chain (PERSIST=0) still agrees."""
+    per block (HIPEMU_CUS shrinks the grid), both block orders.  The path is opt-in (WHISPER_HIP_PERSIST=1)."""
+    env = dict(env, WHISPER_HIP_PERSIST="1", WHISPER_HIP_PS_STAMPS=os.path.join(os.environ.get("TMPDIR", "/tmp"), "ps_stamps_test.bin"))
+    if os.path.exists(env["WHISPER_HIP_PS_STAMPS"]):
+        os.remove(env["WHISPER_HIP_PS_STAMPS"])
     p = _run(emu_lib, which, env)
+    assert os.path.exists(env["WHISPER_HIP_PS_STAMPS"]), "the persistent kernel did not run"
     assert p.returncode == 0 and f"EMU_CHECK_OK {which}" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
