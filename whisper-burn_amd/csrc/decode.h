@@ -133,6 +133,8 @@ struct MlpFusedArgs {
   const float* W2 = nullptr;                                             // [4d][d]
   float* P = nullptr;                                                    // out: planes [4d / 64][S][d] (lin2 bias NOT added)
   unsigned long long* stamps = nullptr;                                  // developer probe (-DWB_STAMPS): phase clock of block 0
+  // persistent mode only: the same streams / planes as 8-byte {tag, value} granules (handoff.h)
+  const void* g_x_in = nullptr; const void* g_pend = nullptr; void* g_x_out = nullptr; void* g_P = nullptr;
 };
 struct AttnFusedArgs {
   const int* st = nullptr; StepLayout lay; int S = 0, d = 0, n_head = 0;
@@ -143,6 +145,7 @@ struct AttnFusedArgs {
   const float* Wo = nullptr;                                                                    // [d][d]
   float* P = nullptr;                                                    // out: planes [n_head][S][d] (out bias NOT added)
   unsigned long long* stamps = nullptr;                                  // developer probe (-DWB_STAMPS): phase clock of block 0
+  const void* g_x_in = nullptr; const void* g_pend = nullptr; void* g_x_out = nullptr; void* g_P = nullptr;   // persistent mode
 };
 struct CrossFusedArgs {
   const int* st = nullptr; StepLayout lay; int S = 0, d = 0, n_head = 0;
@@ -154,6 +157,7 @@ struct CrossFusedArgs {
   const float* Wo = nullptr;                                                      // [d][d]
   float* P = nullptr;                                                             // out: planes [n_head][S][d] (out bias NOT added)
   unsigned long long* stamps = nullptr;
+  const void* g_x_in = nullptr; const void* g_pend = nullptr; void* g_x_out = nullptr; void* g_P = nullptr;   // persistent mode
 };
 // ---- persistent flag-chained greedy decode (decode_persist.hip) --------------------------------------------------
 // ONE co-resident grid runs every sublayer of every step of the device-chained greedy loop: a block executes the
@@ -173,14 +177,15 @@ struct PersistArgs {
   int* ctl = nullptr;                         // HX_* control words + arrival counters (device; set up by the host)
   int step0 = 0, n_steps = 0;                 // first decode step of the chain, most steps to run
   int mask_until_len = 0;                     // special-token mask while len <= this (transcribe.rs:271-275)
-  // logits role: LN(x_fin + b2 + sum P2) . E^T tile -> (best value, best id) per row and tile
-  const float* x_fin = nullptr; const float* P2 = nullptr; const float* b2_last = nullptr;
+  // logits role: LN(x_fin + b2 + sum P2) . E^T tile -> (best value, best id) per row and tile (x_fin, P2: granules)
+  const void* x_fin = nullptr; const void* P2 = nullptr; const float* b2_last = nullptr;
+  unsigned tag_base = 0;                      // granule tags of this launch: tag_base + 2 + 3 (e n_layer + l) + sublayer
   const float* ln_g = nullptr; const float* ln_b = nullptr; float ln_eps = 0.f; int ln_inside = 0;
   const float* Et = nullptr; int vocab_ld = 0, V = 0; const float* mask = nullptr;
   float* tstats = nullptr; int n_tiles = 0;   // [S][n_tiles][2]
   // merge role: argmax over the tiles, chain bookkeeping, next step's embedding
   int* gctl = nullptr; int* gtok = nullptr; int Lmax = 0, eot = 0;
-  const float* E = nullptr; const float* pos = nullptr; float* x0 = nullptr; int* tabs = nullptr;
+  const float* E = nullptr; const float* pos = nullptr; void* x0 = nullptr; int* tabs = nullptr;   // x0: granules
   int* dead = nullptr;                        // [S]: rows whose window has ended
   unsigned long long* stamps = nullptr;       // optional timeline: [n_steps][n_roles][3] (role start, wait passed, done)
 };
@@ -189,6 +194,8 @@ bool dec_persist_supported(int d, int n_rows);
 // grid: blocks of 512 threads that are co-resident on this device for (d, n_rows) -- 0 if the kernel cannot run
 int dec_persist_max_grid(int device, int d, int n_rows);
 int launch_dec_persist(hipStream_t st, const PersistArgs& a, int grid);
+// seeds the granule copy of the first step's x rows: tag = tag_base + 1 (what the first self-attention blocks expect)
+void launch_ps_seed(hipStream_t st, const float* x, int n, void* gx, unsigned tag);
 
 constexpr int CROSS_FUSED_MAX_C = 768;   // keys per window the fused cross-attention block handles (n_audio_ctx / 2 = 750)
 void launch_dec_cross_fused(hipStream_t st, const CrossFusedArgs& a, int n_rows_hint);

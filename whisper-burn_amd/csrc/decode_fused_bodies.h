@@ -25,6 +25,9 @@ struct PsStep {
   const int* dead = nullptr;     // [S]: rows whose window has ended (written by the merge role, sc1)
   int* lds_flag = nullptr;       // one LDS word for the wait's broadcast
   unsigned long long* stamp = nullptr;   // optional timeline slots of this role invocation (PS_STAMPS of them)
+  int n_ctr = 1;                 // the wait covers n_ctr consecutive counters (HX_LINE apart), all with `target`
+  // granule tags (handoff.h): what the role's producers stamp their planes with / what the role stamps its own output with
+  unsigned tag_in = 0, tag_out = 0;
 };
 constexpr int PS_STAMPS = 8;     // 0 role start, 1 wait passed, 2-5 phases inside the role, 6 done, 7 arrived
 __device__ __forceinline__ void ps_stamp(const PsStep& ps, int k) {
@@ -32,10 +35,25 @@ __device__ __forceinline__ void ps_stamp(const PsStep& ps, int k) {
 }
 // wait for the role's producers (all threads of the block); false: the decode was stopped -- leave the kernel
 __device__ __forceinline__ bool ps_wait(const PsStep& ps) {
-  const bool ok = hx_wait(ps.ctr, ps.target, ps.ctl, ps.step, ps.ctr_index, ps.lds_flag);
+  const bool ok = ps.n_ctr > 1 ? hx_wait_same(ps.ctr, ps.target, ps.n_ctr, ps.ctl, ps.step, ps.ctr_index, ps.lds_flag)
+                               : hx_wait(ps.ctr, ps.target, ps.ctl, ps.step, ps.ctr_index, ps.lds_flag);
   ps_stamp(ps, 1);
   return ok;
 }
+// A granule sweep found stale tags: give way, and (rarely) look at the stop / error words.  true = give up -- the caller
+// clears *ps.lds_flag, which every thread of the block reads behind the next barrier (ps_sweeps_ok).
+__device__ __forceinline__ bool ps_sweep_retry(unsigned& sweeps, const PsStep& ps) {
+  if ((sweeps & 31u) == 31u &&
+      (__hip_atomic_load(ps.ctl + HX_STOP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= ps.step ||
+       __hip_atomic_load(ps.ctl + HX_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) return true;
+  if (++sweeps > HX_SWEEP_LIMIT) {
+    __hip_atomic_store(const_cast<int*>(ps.ctl) + HX_ERR, 5000 + ps.ctr_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+  }
+  __builtin_amdgcn_s_sleep(1);
+  return false;
+}
+__device__ __forceinline__ bool ps_sweeps_ok(const PsStep& ps) { return *ps.lds_flag != 0; }   // call BEHIND a barrier
 
 // developer probe: tools/decode_probe.cpp builds this file with -DWB_STAMPS and prints the phase timeline of block 0
 #ifdef WB_STAMPS
@@ -209,6 +227,7 @@ __device__ __forceinline__ bool dec_mlp_body(const MlpFusedArgs& a, const int jb
   float4 w2[RPG];
   float gv[DPL], bv[DPL];
   float b1v;
+  int deadm = 0;                                   // (persistent mode) bit r: row r takes no part (its window has ended)
   {
     int off[EPT], col[EPT];
 #pragma unroll
@@ -243,15 +262,62 @@ __device__ __forceinline__ bool dec_mlp_body(const MlpFusedArgs& a, const int jb
         for (int i = 0; i < RPG; i++) w2[i] = *reinterpret_cast<const float4*>(wp + (int64_t)i * d);
       }
     };
-    const Buf16 pendb(a.pend);
     if constexpr (PS) {
-      // persistent mode: nothing the block streams depends on its predecessor -- the weights are in flight (or
-      // landed) while the block waits for the producers of its input planes; then the fold operands, L1 bypassed
+      // persistent mode: nothing the block streams depends on its predecessor -- the weights are in flight (or landed)
+      // while the block waits (pre-wake: the self-attention blocks of every row have finished); the cross-attention
+      // planes arrive as tagged granules, re-read until every tag is the producers'
       load_weights();
       if (!ps_wait(ps)) return false;
-    }
 #pragma unroll
-    for (int i = 0; i < EPT; i++) { xv_fold[i] = ld_f<PS>(a.x_in + off[i]); acc0[i] = npl > 0 ? a.pbias[col[i]] : 0.f; }
+      for (int r = 0; r < MR; r++)
+        if (r >= ps.n_rows || ld_i<true>(ps.dead + min(r, ps.n_rows - 1)) != 0) deadm |= 1 << r;
+      const Buf16 xgb(a.g_x_in), pgb(a.g_pend);
+      const int iplane = a.S * d;
+      bool rdead[EPT];
+#pragma unroll
+      for (int i = 0; i < EPT; i++) { rdead[i] = ((deadm >> (off[i] / d)) & 1) != 0; acc0[i] = a.pbias[col[i]]; xv_fold[i] = 0.f; }
+      constexpr int GP = EPT <= 3 ? 8 : 4;           // planes per sweep
+      unsigned sweeps = 0;
+      bool bad = false;
+      for (int sp = 0; sp < npl && !bad; sp += GP) {
+        for (;;) {
+          Gran gx[EPT], g[GP][EPT];
+          if (sp == 0) {
+#pragma unroll
+            for (int i = 0; i < EPT; i++) gx[i] = ld_gran(xgb, (uint32_t)off[i], 0u);
+          }
+#pragma unroll
+          for (int j = 0; j < GP; j++)
+#pragma unroll
+            for (int i = 0; i < EPT; i++) g[j][i] = ld_gran(pgb, (uint32_t)off[i], (uint32_t)(min(sp + j, npl - 1) * iplane));
+          bool ok = true;
+#pragma unroll
+          for (int i = 0; i < EPT; i++) {
+            if (sp == 0) ok &= rdead[i] || gx[i].tag == ps.tag_in;
+#pragma unroll
+            for (int j = 0; j < GP; j++) ok &= rdead[i] || sp + j >= npl || g[j][i].tag == ps.tag_in;
+          }
+          if (ok) {
+#pragma unroll
+            for (int i = 0; i < EPT; i++) {
+              if (sp == 0) xv_fold[i] = gx[i].v;
+#pragma unroll
+              for (int j = 0; j < GP; j++) acc0[i] += (sp + j < npl) ? g[j][i].v : 0.f;      // plane order fixed
+            }
+            break;
+          }
+          if (ps_sweep_retry(sweeps, ps)) { *ps.lds_flag = 0; bad = true; break; }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < EPT; i++) {
+        xv_fold[i] = rdead[i] ? 0.f : xv_fold[i] + acc0[i];                              // x + (bias + partials)  (mod.rs:346-348)
+        const int e = tid + NT * i;
+        if (e < MR * d) (&hs[0][0])[e] = xv_fold[i];
+      }
+    } else {
+#pragma unroll
+    for (int i = 0; i < EPT; i++) { xv_fold[i] = a.x_in[off[i]]; acc0[i] = npl > 0 ? a.pbias[col[i]] : 0.f; }
     float mlv0 = -1.0e30f, mlv1 = 0.f;
     if (rec && tid < MR * npl) {                     // (m, l) of record (row tid / npl, plane tid % npl)
       const float* rp = a.pend + (int64_t)(tid % npl) * plane + (int64_t)(tid / npl) * (d + 2);
@@ -262,10 +328,10 @@ __device__ __forceinline__ bool dec_mlp_body(const MlpFusedArgs& a, const int jb
       for (int j = 0; j < PC; j++)
         if (j < ch) {
 #pragma unroll
-          for (int i = 0; i < EPT; i++) t[j][i] = ld_fb<PS>(a.pend, pendb, (uint32_t)poff[i], (uint32_t)(min(j, npl - 1) * (int)plane));
+          for (int i = 0; i < EPT; i++) t[j][i] = a.pend[(int64_t)min(j, npl - 1) * plane + poff[i]];
         }
     }
-    if constexpr (!PS) load_weights();
+    load_weights();
     if constexpr (REC) {
       // flash-combine weights: coef[r][h][c] = exp(m_hc - M_h) / sum_c' exp(m_hc' - M_h) l_hc'  (mod.rs:529 softmax,
       // split over key chunks by dec_cross_attn_kernel)
@@ -292,7 +358,7 @@ __device__ __forceinline__ bool dec_mlp_body(const MlpFusedArgs& a, const int jb
           for (int j = 0; j < PC; j++)
             if (j < ch) {
 #pragma unroll
-              for (int i = 0; i < EPT; i++) t[j][i] = ld_fb<PS>(a.pend, pendb, (uint32_t)poff[i], (uint32_t)(min(sp + j, npl - 1) * (int)plane));
+              for (int i = 0; i < EPT; i++) t[j][i] = a.pend[(int64_t)min(sp + j, npl - 1) * plane + poff[i]];
             }
         }
 #pragma unroll
@@ -315,12 +381,14 @@ __device__ __forceinline__ bool dec_mlp_body(const MlpFusedArgs& a, const int jb
       const int e = tid + NT * i;
       if (e < MR * d) (&hs[0][0])[e] = xv_fold[i];
     }
+    }
   }
   int n_rows;
   if constexpr (PS) n_rows = ps.n_rows; else n_rows = a.st[ST_N];
   if (n_rows == 0) return true;                    // chained decode, every window finished (block-uniform)
   WB_STAMP(1);
   __syncthreads();
+  if constexpr (PS) { if (!ps_sweeps_ok(ps)) return false; }
   if (wave < MR) ln_row_lds<DPL>(hs[wave], d, lane, gv, bv, a.ln_eps, a.ln_inside);
   __syncthreads();
   WB_STAMP(2);
@@ -382,17 +450,33 @@ __device__ __forceinline__ bool dec_mlp_body(const MlpFusedArgs& a, const int jb
         o[r][0] += t.x; o[r][1] += t.y; o[r][2] += t.z; o[r][3] += t.w;
       }
     }
-    const Buf16 pbuf(a.P);
+    if constexpr (PS) {
+      const Buf16 pgo(a.g_P);
 #pragma unroll
-    for (int r = 0; r < MR; r++)
-      if (r < n_rows)
-        st_f4<PS>(a.P, pbuf, (uint32_t)((jblk * a.S + r) * d + cf * 4), make_float4(o[r][0], o[r][1], o[r][2], o[r][3]));
+      for (int r = 0; r < MR; r++)
+        if (r < n_rows && !((deadm >> r) & 1))
+          st_gran4(pgo, (uint32_t)((jblk * a.S + r) * d + cf * 4), ps.tag_out, make_float4(o[r][0], o[r][1], o[r][2], o[r][3]));
+    } else {
+#pragma unroll
+      for (int r = 0; r < MR; r++)
+        if (r < n_rows)
+          *reinterpret_cast<float4*>(&a.P[((int64_t)jblk * a.S + r) * d + cf * 4]) = make_float4(o[r][0], o[r][1], o[r][2], o[r][3]);
+    }
   }
   if (jblk == 0) {                                 // the folded residual stream, off the critical path
+    if constexpr (PS) {
+      const Buf16 xgo(a.g_x_out);
 #pragma unroll
-    for (int i = 0; i < EPT; i++) {
-      const int e = tid + NT * i;
-      if (e < n_rows * d) st_f<PS>(a.x_out + e, xv_fold[i]);
+      for (int i = 0; i < EPT; i++) {
+        const int e = tid + NT * i;
+        if (e < n_rows * d && !((deadm >> (e / d)) & 1)) st_gran(xgo, (uint32_t)e, ps.tag_out, xv_fold[i]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < EPT; i++) {
+        const int e = tid + NT * i;
+        if (e < n_rows * d) a.x_out[e] = xv_fold[i];
+      }
     }
   }
   WB_STAMP(4);
@@ -471,31 +555,62 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
       if constexpr (PS) { if (tid < 192) qbias = a.bqkv[(tid >> 6) * d + h * 64 + (tid & 63)]; }
     };
     if constexpr (PS) {
-      // persistent mode: the first weight rounds are in flight (or landed) while the block waits for the MLP planes
+      // persistent mode: the first weight rounds are in flight (or landed) while the block waits; the wait is a PRE-wake
+      // (the stage before the producers has finished) -- the planes themselves arrive as tagged granules, re-read until
+      // every tag is the producers' (arrival and payload in one round trip)
       load_weights();
       if (!ps_wait(ps)) return false;
       dead = ld_i<true>(ps.dead + r);
-    }
-    // (persistent mode: buffer loads -- the plane offset rides in the scalar offset, one lane offset for all planes)
-    const Buf16 pendb(a.pend);
-    const uint32_t pvo = (uint32_t)(r * d + c);
-    float v = ld_f<PS>(a.x_in + ((int64_t)r * d + c));
+      if (r >= n_rows || dead) return true;
+      const Buf16 xgb(a.g_x_in), pgb(a.g_pend);
+      const uint32_t pvo = (uint32_t)(r * d + c);
+      const int iplane = a.S * d;
+      constexpr int FP = 4 * DPL;                   // the 4 d / 64 planes of the previous layer's MLP
+      float v = 0.f, accp = a.KSp > 0 ? a.pbias[c] : 0.f;
+      unsigned sweeps = 0;
+      for (;;) {
+        const Gran gx = ld_gran(xgb, pvo, 0u);
+        Gran g[FP];
+        if (a.KSp > 0) {
+#pragma unroll
+          for (int j = 0; j < FP; j++) g[j] = ld_gran(pgb, pvo, (uint32_t)(min(j, a.KSp - 1) * iplane));
+        }
+        bool ok = gx.tag == ps.tag_in;
+        if (a.KSp > 0) {
+#pragma unroll
+          for (int j = 0; j < FP; j++) ok &= (j >= a.KSp) || g[j].tag == ps.tag_in;
+        }
+        if (ok) {
+          v = gx.v;
+          if (a.KSp > 0) {
+#pragma unroll
+            for (int j = 0; j < FP; j++) accp += (j < a.KSp) ? g[j].v : 0.f;       // s ascending (mod.rs:346-348)
+            v += accp;
+          }
+          break;
+        }
+        if (ps_sweep_retry(sweeps, ps)) { *ps.lds_flag = 0; break; }
+      }
+      xfold = v;
+      if (tid < d) hs[tid] = v;
+    } else {
+    float v = a.x_in[(int64_t)r * d + c];
     constexpr int FP = 32;                          // planes per round: 4 d / 64 <= 32 MLP planes in ONE round trip
     float t[FP];
     float accp = 0.f;
     if (a.KSp > 0) {
       accp = a.pbias[c];
 #pragma unroll
-      for (int j = 0; j < FP; j++) t[j] = ld_fb<PS>(a.pend, pendb, pvo, (uint32_t)(min(j, a.KSp - 1) * (int)plane));
+      for (int j = 0; j < FP; j++) t[j] = pp[(int64_t)min(j, a.KSp - 1) * plane];
     }
-    if constexpr (!PS) load_weights();
+    load_weights();
     if (r >= n_rows || dead) return true;          // (block-uniform; the first wait of the kernel)
     if (a.KSp > 0) {
 #pragma unroll
       for (int j = 0; j < FP; j++) accp += (j < a.KSp) ? t[j] : 0.f;
       for (int sp = FP; sp < a.KSp; sp += FP) {
 #pragma unroll
-        for (int j = 0; j < FP; j++) t[j] = ld_fb<PS>(a.pend, pendb, pvo, (uint32_t)(min(sp + j, a.KSp - 1) * (int)plane));
+        for (int j = 0; j < FP; j++) t[j] = pp[(int64_t)min(sp + j, a.KSp - 1) * plane];
 #pragma unroll
         for (int j = 0; j < FP; j++) accp += (sp + j < a.KSp) ? t[j] : 0.f;
       }
@@ -503,6 +618,7 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
     }
     xfold = v;
     if (tid < d) hs[tid] = v;
+    }
   }
   if constexpr (!PS) qbias = tid < 192 ? a.bqkv[(tid >> 6) * d + h * 64 + (tid & 63)] : 0.f;   // key part is zero (mod.rs:402-404)
   // ---- the cached K / V rows of the first 128 positions, the coalesced way (16 lanes x 16 B = one 256-byte head row;
@@ -530,6 +646,7 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
   WB_STAMP(1);
   if constexpr (PS) ps_stamp(ps, 2);
   __syncthreads();
+  if constexpr (PS) { if (!ps_sweeps_ok(ps)) return false; }
   if (wave == 0) ln_row_lds<DPL>(hs, d, lane, gv, bv, a.ln_eps, a.ln_inside);
   __syncthreads();
   WB_STAMP(2);
@@ -677,15 +794,22 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
       const float4 t = *reinterpret_cast<const float4*>(&red[(g2 - 1) * d + cf * 4]);
       ov[0] += t.x; ov[1] += t.y; ov[2] += t.z; ov[3] += t.w;
     }
-    const Buf16 pbuf(a.P);
-    st_f4<PS>(a.P, pbuf, (uint32_t)((h * a.S + r) * d + cf * 4), make_float4(ov[0], ov[1], ov[2], ov[3]));
+    if constexpr (PS) {
+      const Buf16 pgo(a.g_P);
+      st_gran4(pgo, (uint32_t)((h * a.S + r) * d + cf * 4), ps.tag_out, make_float4(ov[0], ov[1], ov[2], ov[3]));
+    } else {
+      *reinterpret_cast<float4*>(&a.P[((int64_t)h * a.S + r) * d + cf * 4]) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    }
   }
   // ---- the stores that are not on anybody's critical path: k * s, v of the new token into the cache, the folded stream
   if (tid >= 64 && tid < 192) {
     float* dst = (tid < 128 ? a.Kc : a.Vc) + (int64_t)slot_new * d + h * 64 + (tid & 63);
     st_f<PS>(dst, qkv[tid]);
   }
-  if (h == 0 && tid < d) st_f<PS>(a.x_out + ((int64_t)r * d + tid), xfold);
+  if (h == 0 && tid < d) {
+    if constexpr (PS) { const Buf16 xgo(a.g_x_out); st_gran(xgo, (uint32_t)(r * d + tid), ps.tag_out, xfold); }
+    else a.x_out[(int64_t)r * d + tid] = xfold;
+  }
   WB_STAMP(7);
   WB_STAMP_FLUSH(a, 8);
   return true;
@@ -783,31 +907,55 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
     const int64_t plane = (int64_t)a.S * d;
     if constexpr (PS) {
       // persistent mode: neither the weights nor the window's cached keys depend on the predecessor -- the Wq slice and
-      // the WHOLE K of the head are in flight (or landed) while the block waits for the self-attention planes
+      // the WHOLE K of the head are in flight (or landed) while the block waits (pre-wake); the self-attention planes
+      // arrive as tagged granules
       load_weights();
       load_keys();
       if (!ps_wait(ps)) return false;
       dead = ld_i<true>(ps.dead + r);
-    }
-    const Buf16 pendb(a.pend);
-    const uint32_t pvo = (uint32_t)(r * d + c);
-    float v = ld_f<PS>(a.x_in + ((int64_t)r * d + c));
-    constexpr int FP = PS ? 8 : 16;                 // (persistent mode: <= 8 head planes, the K ring owns the registers)
+      if (r >= n_live || dead) return true;
+      const Buf16 xgb(a.g_x_in), pgb(a.g_pend);
+      const uint32_t pvo = (uint32_t)(r * d + c);
+      const int iplane = a.S * d;
+      constexpr int FP = 8;                         // <= 8 head planes
+      float v = 0.f, accp = a.pbias[c];
+      unsigned sweeps = 0;
+      for (;;) {
+        const Gran gx = ld_gran(xgb, pvo, 0u);
+        Gran g[FP];
+#pragma unroll
+        for (int j = 0; j < FP; j++) g[j] = ld_gran(pgb, pvo, (uint32_t)(min(j, a.KSp - 1) * iplane));
+        bool ok = gx.tag == ps.tag_in;
+#pragma unroll
+        for (int j = 0; j < FP; j++) ok &= (j >= a.KSp) || g[j].tag == ps.tag_in;
+        if (ok) {
+#pragma unroll
+          for (int j = 0; j < FP; j++) accp += (j < a.KSp) ? g[j].v : 0.f;         // s ascending (mod.rs:346-348)
+          v = gx.v + accp;
+          break;
+        }
+        if (ps_sweep_retry(sweeps, ps)) { *ps.lds_flag = 0; break; }
+      }
+      xfold = v;
+      if (tid < d) hs[tid] = v;
+    } else {
+    float v = a.x_in[(int64_t)r * d + c];
+    constexpr int FP = 16;
     float t[FP];
     float accp = 0.f;
     if (a.KSp > 0) {
       accp = a.pbias[c];
 #pragma unroll
-      for (int j = 0; j < FP; j++) t[j] = ld_fb<PS>(a.pend, pendb, pvo, (uint32_t)(min(j, a.KSp - 1) * (int)plane));
+      for (int j = 0; j < FP; j++) t[j] = pp[(int64_t)min(j, a.KSp - 1) * plane];
     }
-    if constexpr (!PS) load_weights();
+    load_weights();
     if (r >= n_live || dead) return true;          // (block-uniform; the first wait of the kernel)
     if (a.KSp > 0) {
 #pragma unroll
       for (int j = 0; j < FP; j++) accp += (j < a.KSp) ? t[j] : 0.f;
       for (int sp = FP; sp < a.KSp; sp += FP) {
 #pragma unroll
-        for (int j = 0; j < FP; j++) t[j] = ld_fb<PS>(a.pend, pendb, pvo, (uint32_t)(min(sp + j, a.KSp - 1) * (int)plane));
+        for (int j = 0; j < FP; j++) t[j] = pp[(int64_t)min(sp + j, a.KSp - 1) * plane];
 #pragma unroll
         for (int j = 0; j < FP; j++) accp += (sp + j < a.KSp) ? t[j] : 0.f;
       }
@@ -815,11 +963,13 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
     }
     xfold = v;
     if (tid < d) hs[tid] = v;
+    }
   }
   if constexpr (!PS) qbias = tid < 64 ? a.bq[h * 64 + tid] : 0.f;
   if constexpr (!PS) load_keys();
   if constexpr (PS) ps_stamp(ps, 2);
   __syncthreads();
+  if constexpr (PS) { if (!ps_sweeps_ok(ps)) return false; }
   if (wave == 0) ln_row_lds<DPL>(hs, d, lane, gv, bv, a.ln_eps, a.ln_inside);
   __syncthreads();
   // ---- q = (cross_attn_ln(x) Wq + bq) * s for head h  (mod.rs:483, :506-509)
@@ -919,10 +1069,17 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
       const float4 t = *reinterpret_cast<const float4*>(&obuf[(g2 - 1) * d + cf * 4]);
       ov[0] += t.x; ov[1] += t.y; ov[2] += t.z; ov[3] += t.w;
     }
-    const Buf16 pbuf16(a.P);
-    st_f4<PS>(a.P, pbuf16, (uint32_t)((h * a.S + r) * d + cf * 4), make_float4(ov[0], ov[1], ov[2], ov[3]));
+    if constexpr (PS) {
+      const Buf16 pgo(a.g_P);
+      st_gran4(pgo, (uint32_t)((h * a.S + r) * d + cf * 4), ps.tag_out, make_float4(ov[0], ov[1], ov[2], ov[3]));
+    } else {
+      *reinterpret_cast<float4*>(&a.P[((int64_t)h * a.S + r) * d + cf * 4]) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    }
   }
-  if (h == 0 && tid < d) st_f<PS>(a.x_out + ((int64_t)r * d + tid), xfold);      // the folded stream, off the critical path
+  if (h == 0 && tid < d) {                         // the folded stream, off the critical path
+    if constexpr (PS) { const Buf16 xgo(a.g_x_out); st_gran(xgo, (uint32_t)(r * d + tid), ps.tag_out, xfold); }
+    else a.x_out[(int64_t)r * d + tid] = xfold;
+  }
   return true;
 }
 

@@ -85,9 +85,10 @@ __device__ __forceinline__ bool ps_logits_role(const PersistArgs& a, const int t
 #pragma unroll
   for (int i = 0; i < DPL; i++) { gv[i] = a.ln_g[lane + 64 * i]; bv[i] = a.ln_b[lane + 64 * i]; }
   const int use_mask = (ps.step + 1 <= a.mask_until_len) ? 1 : 0;          // transcribe.rs:271-275
-  if (!ps_wait(ps)) return false;
+  if (!ps_wait(ps)) return false;                   // pre-wake: the last layer's cross-attention blocks have finished
   {
-    // x + (bias + partial planes), plane order fixed (mod.rs:346-348): every load of a chunk of planes in flight together
+    // x + (bias + partial planes), plane order fixed (mod.rs:346-348).  The last MLP's planes arrive as tagged granules,
+    // re-read until every tag is that stage's; rows whose window has ended take no part (nobody writes them).
     int off[EPT], col[EPT];
 #pragma unroll
     for (int i = 0; i < EPT; i++) {
@@ -95,30 +96,57 @@ __device__ __forceinline__ bool ps_logits_role(const PersistArgs& a, const int t
       if (e >= MR * d) e = tid;
       off[i] = e; col[i] = e % d;
     }
+    int deadm = 0;
+#pragma unroll
+    for (int r = 0; r < MR; r++)
+      if (r >= ps.n_rows || ld_i<true>(ps.dead + min(r, ps.n_rows - 1)) != 0) deadm |= 1 << r;
     const int plane = a.S * d;
-    const Buf16 p2b(a.P2);
+    const Buf16 xgb(a.x_fin), p2b(a.P2);
     float v[EPT], acc[EPT];
+    bool rdead[EPT];
 #pragma unroll
-    for (int i = 0; i < EPT; i++) { v[i] = ld_f<true>(a.x_fin + off[i]); acc[i] = a.b2_last[col[i]]; }
-    for (int sp = 0; sp < a.nb_mlp; sp += PCH) {
-      float t[PCH][EPT];
+    for (int i = 0; i < EPT; i++) { rdead[i] = ((deadm >> (off[i] / d)) & 1) != 0; v[i] = 0.f; acc[i] = a.b2_last[col[i]]; }
+    unsigned sweeps = 0;
+    bool bad = false;
+    for (int sp = 0; sp < a.nb_mlp && !bad; sp += PCH) {
+      for (;;) {
+        Gran gx[EPT], t[PCH][EPT];
+        if (sp == 0) {
 #pragma unroll
-      for (int j = 0; j < PCH; j++)
+          for (int i = 0; i < EPT; i++) gx[i] = ld_gran(xgb, (uint32_t)off[i], 0u);
+        }
 #pragma unroll
-        for (int i = 0; i < EPT; i++) t[j][i] = ld_fb<true>(a.P2, p2b, (uint32_t)off[i], (uint32_t)(min(sp + j, a.nb_mlp - 1) * plane));
+        for (int j = 0; j < PCH; j++)
 #pragma unroll
-      for (int j = 0; j < PCH; j++)
+          for (int i = 0; i < EPT; i++) t[j][i] = ld_gran(p2b, (uint32_t)off[i], (uint32_t)(min(sp + j, a.nb_mlp - 1) * plane));
+        bool ok = true;
 #pragma unroll
-        for (int i = 0; i < EPT; i++) acc[i] += (sp + j < a.nb_mlp) ? t[j][i] : 0.f;
+        for (int i = 0; i < EPT; i++) {
+          if (sp == 0) ok &= rdead[i] || gx[i].tag == ps.tag_in;
+#pragma unroll
+          for (int j = 0; j < PCH; j++) ok &= rdead[i] || sp + j >= a.nb_mlp || t[j][i].tag == ps.tag_in;
+        }
+        if (ok) {
+#pragma unroll
+          for (int i = 0; i < EPT; i++) {
+            if (sp == 0) v[i] = gx[i].v;
+#pragma unroll
+            for (int j = 0; j < PCH; j++) acc[i] += (sp + j < a.nb_mlp) ? t[j][i].v : 0.f;
+          }
+          break;
+        }
+        if (ps_sweep_retry(sweeps, ps)) { *ps.lds_flag = 0; bad = true; break; }
+      }
     }
 #pragma unroll
     for (int i = 0; i < EPT; i++) {
       const int e = tid + NT * i;
-      if (e < MR * d) (&xs[0][0])[e] = v[i] + acc[i];
+      if (e < MR * d) (&xs[0][0])[e] = rdead[i] ? 0.f : v[i] + acc[i];
     }
   }
   ps_stamp(ps, 2);
   __syncthreads();
+  if (!ps_sweeps_ok(ps)) return false;
   if (wave < MR) ln_row_lds<DPL>(xs[wave], d, lane, gv, bv, a.ln_eps, a.ln_inside);
   __syncthreads();
   ps_stamp(ps, 3);
@@ -245,9 +273,10 @@ __device__ __forceinline__ bool ps_merge_role(const PersistArgs& a, const int r,
     const Buf16 xb(a.x0);
     const float4* ev = reinterpret_cast<const float4*>(a.E + (int64_t)tok_next * a.d);
     const float4* pp = reinterpret_cast<const float4*>(a.pos + (int64_t)len * a.d);
+    const unsigned tag_x = a.tag_base + 1u + 3u * (unsigned)((e + 1) * a.n_layer);   // what attn(0) of step e + 1 expects
     for (int c = tid; c < (a.d >> 2); c += PS_NT) {
       const float4 x = ev[c], y = pp[c];
-      st_f4<true>(a.x0, xb, (uint32_t)(r * a.d + 4 * c), make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w));
+      st_gran4(xb, (uint32_t)(r * a.d + 4 * c), tag_x, make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w));
     }
     // (the persistent roles address the self-attention cache arithmetically; the tables are kept for host-driven steps
     // that may follow the chain)
@@ -281,29 +310,40 @@ __global__ __launch_bounds__(PS_NT) void dec_persist_kernel(PersistArgs a) {
       ps.stamp = stp;
       int out;
       bool ok;
+      // granule tags: a stage's planes and folded stream carry tag(e, layer, sublayer); a role consumes tag - 1
+      const unsigned tag_l = a.tag_base + 2u + 3u * (unsigned)(e * NL + (role.kind <= PSR_MLP ? role.layer : NL - 1));
       if (role.kind == PSR_ATTN) {
         const AttnFusedArgs la = a.layers[role.layer].attn;
+        // layer 0: the merge role's flag (its x row follows as granules); else pre-wake = the previous layer's
+        // cross-attention blocks have finished (its MLP, the producer, is running)
         if (role.layer == 0) { ps.ctr_index = C_X + role.b; ps.target = (unsigned)e; }
-        else { ps.ctr_index = C_MLP + role.layer - 1; ps.target = (unsigned)(e + 1) * NB; }
+        else { ps.ctr_index = C_CROSS + role.layer - 1; ps.target = (unsigned)(e + 1) * H * R; }
         ps.ctr = cptr(ps.ctr_index);
+        ps.tag_out = tag_l; ps.tag_in = tag_l - 1u;
         ok = dec_attn_body<DPL, true>(la, role.a, role.b, ps);
         out = C_ATTN + role.layer * S + role.b;
       } else if (role.kind == PSR_CROSS) {
         const CrossFusedArgs la = a.layers[role.layer].cross;
-        ps.ctr_index = C_ATTN + role.layer * S + role.b; ps.target = (unsigned)(e + 1) * H;
+        // pre-wake = the stage before the self-attention blocks: the previous layer's MLP (layer 0: the merge role)
+        if (role.layer == 0) { ps.ctr_index = C_X + role.b; ps.target = (unsigned)e; }
+        else { ps.ctr_index = C_MLP + role.layer - 1; ps.target = (unsigned)(e + 1) * NB; }
         ps.ctr = cptr(ps.ctr_index);
+        ps.tag_out = tag_l + 1u; ps.tag_in = tag_l;
         ok = dec_cross_body<DPL, true>(la, role.a, role.b, ps);
         out = C_CROSS + role.layer;
       } else if (role.kind == PSR_MLP) {
         const MlpFusedArgs la = a.layers[role.layer].mlp;
-        ps.ctr_index = C_CROSS + role.layer; ps.target = (unsigned)(e + 1) * H * R;
+        // pre-wake = the self-attention blocks of every row have finished (the cross-attention blocks are running)
+        ps.ctr_index = C_ATTN + role.layer * S; ps.target = (unsigned)(e + 1) * H; ps.n_ctr = R;
         ps.ctr = cptr(ps.ctr_index);
+        ps.tag_out = tag_l + 2u; ps.tag_in = tag_l + 1u;
         ok = dec_mlp_body<MR, DPL, false, true>(la, role.a, ps);
         out = C_MLP + role.layer;
       } else if (role.kind == PSR_LOGITS) {
-        // (woken by the last MLP block of the step through one of PS_NGO words: hx_arrive_broadcast)
+        // pre-wake: the last cross-attention block of the step wakes the logits roles through one of PS_NGO words
         ps.ctr_index = C_GO + (role.layer % PS_NGO); ps.target = (unsigned)(e + 1);
         ps.ctr = cptr(ps.ctr_index);
+        ps.tag_in = tag_l + 2u;
         ok = ps_logits_role<MR, DPL>(a, role.a, role.b, ps);
         out = C_LOG + (role.layer & 7);
       } else {
@@ -312,13 +352,19 @@ __global__ __launch_bounds__(PS_NT) void dec_persist_kernel(PersistArgs a) {
       }
       if (!ok) return;                               // the decode was stopped (or a wait gave up): leave
       if (stp && threadIdx.x == 0) stp[6] = wall_clock64();
-      if (role.kind == PSR_MLP && role.layer == NL - 1)
-        hx_arrive_broadcast(cptr(out), (unsigned)(e + 1) * NB, cptr(C_GO), PS_NGO, (unsigned)(e + 1));
+      if (role.kind == PSR_CROSS && role.layer == NL - 1)
+        hx_arrive_broadcast(cptr(out), (unsigned)(e + 1) * H * R, cptr(C_GO), PS_NGO, (unsigned)(e + 1));
       else
         hx_arrive(cptr(out));
       if (stp && threadIdx.x == 0) stp[7] = wall_clock64();
     }
   }
+}
+
+// the first step's x rows (dec_prepare_kernel wrote plain floats) as granules with the tag attn(0) of step 0 expects
+__global__ void ps_seed_kernel(const float* __restrict__ x, int n, void* gx, unsigned tag) {
+  const Buf16 b(gx);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) st_gran(b, (uint32_t)i, tag, x[i]);
 }
 
 template <int DPL, int MR>
@@ -351,6 +397,10 @@ int dec_persist_max_grid(int device, int d, int n_rows) {
   if (per <= 0) return 0;
   // (one block per CU is what the roles are sized for; a second resident block per CU would only share its fill path)
   return cus * 1;
+}
+
+void launch_ps_seed(hipStream_t st, const float* x, int n, void* gx, unsigned tag) {
+  hipLaunchKernelGGL(ps_seed_kernel, dim3((n + 255) / 256), dim3(256), 0, st, x, n, gx, tag);
 }
 
 int launch_dec_persist(hipStream_t st, const PersistArgs& a, int grid) {

@@ -99,6 +99,31 @@ __device__ __forceinline__ void st_f4(float* base, const Buf16& b, uint32_t elem
   }
 }
 
+// ---- granules: the data IS the flag (Guideline 16, R2) ----------------------------------------------------------------
+// A value another block waits for travels as an aligned 8-byte {tag, value} pair written by ONE write-through store (16-byte
+// stores carry two pairs; observed untorn on gfx950).  The consumer re-reads its granules until every tag equals the tag
+// of the producing stage: arrival and payload come back in the SAME round trip, where a flag costs one round trip to see
+// the flag and a second one to fetch the data.  Tags are unique per (launch, step, layer, sublayer) and never 0; the
+// buffers are zero-filled when allocated.
+typedef unsigned hx_u32x2 __attribute__((ext_vector_type(2)));
+struct Gran { unsigned tag; float v; };
+__device__ __forceinline__ Gran ld_gran(const Buf16& b, uint32_t gran_voff, uint32_t gran_soff) {
+  const hx_u32x2 u = __builtin_amdgcn_raw_buffer_load_b64(b.r, gran_voff * 8u, gran_soff * 8u, 16);
+  return Gran{u[0], __uint_as_float(u[1])};
+}
+__device__ __forceinline__ void st_gran(const Buf16& b, uint32_t gran_off, unsigned tag, float v) {
+  hx_u32x2 u; u[0] = tag; u[1] = __float_as_uint(v);
+  __builtin_amdgcn_raw_buffer_store_b64(u, b.r, gran_off * 8u, 0, 16);
+}
+__device__ __forceinline__ void st_gran4(const Buf16& b, uint32_t gran_off, unsigned tag, float4 v) {   // gran_off even
+  hx_u32x4 u;
+  u[0] = tag; u[1] = __float_as_uint(v.x); u[2] = tag; u[3] = __float_as_uint(v.y);
+  __builtin_amdgcn_raw_buffer_store_b128(u, b.r, gran_off * 8u, 0, 16);
+  u[1] = __float_as_uint(v.z); u[3] = __float_as_uint(v.w);
+  __builtin_amdgcn_raw_buffer_store_b128(u, b.r, gran_off * 8u + 16u, 0, 16);
+}
+constexpr unsigned HX_SWEEP_LIMIT = 1u << 20;     // sweeps before a granule wait gives up
+
 // ---- arrival counters ---------------------------------------------------------------------------------------------
 constexpr unsigned HX_SPIN_LIMIT = 4u * 1000u * 1000u;      // polls before a wait gives up (seconds; a real wait lasts microseconds)
 
@@ -158,6 +183,36 @@ __device__ __forceinline__ bool hx_wait_many(const unsigned* ctr, const unsigned
     unsigned spins = 0;
     for (;;) {
       const bool have = !mine || __hip_atomic_load(ctr + lane * HX_LINE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= tgt;
+      if (__ballot(!have) == 0ull) break;
+      if ((spins & 15u) == 15u &&
+          (__hip_atomic_load(ctl + HX_STOP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= step ||
+           __hip_atomic_load(ctl + HX_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { ok = 0; break; }
+      if (++spins > HX_SPIN_LIMIT) {
+        if (lane == 0) __hip_atomic_store(const_cast<int*>(ctl) + HX_ERR, 1 + ctr_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (ok && __hip_atomic_load(ctl + HX_STOP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= step) ok = 0;
+    if (lane == 0) *lds_flag = ok;
+  }
+  __syncthreads();
+  const int ok = *lds_flag;
+  __syncthreads();
+  return ok != 0;
+}
+
+// The same for n consecutive counters that share one target.
+__device__ __forceinline__ bool hx_wait_same(const unsigned* ctr, unsigned target, int n, const int* ctl, int step,
+                                             int ctr_index, int* lds_flag) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const bool mine = lane < n;
+    int ok = 1;
+    unsigned spins = 0;
+    for (;;) {
+      const bool have = !mine || __hip_atomic_load(ctr + lane * HX_LINE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
       if (__ballot(!have) == 0ull) break;
       if ((spins & 15u) == 15u &&
           (__hip_atomic_load(ctl + HX_STOP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= step ||

@@ -734,6 +734,19 @@ static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_
   const int n_tiles = (V + 127) / 128;
   const size_t pool = (size_t)s->Lmax * S;
   const int ldkv = NL * 2 * d;
+  // ---- the hand-off buffers: residual streams and partial planes as {tag, value} granules (zero-filled once: tag 0 is
+  // never used; the tags of a launch live above launch_count << 16, so leftovers of earlier decodes never match)
+  WB_REQUIRE(NB <= 32 && H <= 8, WB_ERR_SHAPE, "persistent decode: more planes than its folds hold");
+  WB_TRY(s->ps_gx.ensure_zeroed(((size_t)2 * S + 8) * d * 8));
+  WB_TRY(s->ps_gpa.ensure_zeroed(((size_t)H * S + 8) * d * 8));
+  WB_TRY(s->ps_gpc.ensure_zeroed(((size_t)H * S + 8) * d * 8));
+  WB_TRY(s->ps_gp2.ensure_zeroed(((size_t)NB * S + 8) * d * 8));
+  if (((s->ps_launches + 1) & 0xffffu) == 0) {     // the 16-bit launch count wraps: forget every old tag
+    for (DevMem* b : {&s->ps_gx, &s->ps_gpa, &s->ps_gpc, &s->ps_gp2}) WB_HIP(hipMemsetAsync(b->p, 0, b->bytes, st));
+    s->ps_launches++;
+  }
+  const unsigned tag_base = ((++s->ps_launches) & 0xffffu) << 16;
+  char* gxb[2] = {static_cast<char*>(s->ps_gx.p), static_cast<char*>(s->ps_gx.p) + (size_t)S * d * 8};
   // ---- per-layer arguments: exactly what enqueue_step hands the fused sublayer kernels ----
   std::vector<PsLayerArgs> la(NL);
   float* xb[2] = {s->x.as<float>(), s->x.as<float>() + (size_t)S * d};
@@ -748,6 +761,7 @@ static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_
     fa.Wqkv = b.qkv.w; fa.ldqkv = b.qkv.n; fa.bqkv = b.qkv.b; fa.scale = m->qk_scale;
     fa.Kc = s->kc.as<float>() + (size_t)l * pool * d; fa.Vc = s->vc.as<float>() + (size_t)l * pool * d;
     fa.tabs = s->tabs.as<int>(); fa.Lmax = s->Lmax; fa.Wo = b.out.w; fa.P = s->Pa.as<float>();
+    fa.g_x_in = gxb[xi]; fa.g_pend = l == 0 ? nullptr : s->ps_gp2.p; fa.g_x_out = gxb[xi ^ 1]; fa.g_P = s->ps_gpa.p;
     xi ^= 1;
     CrossFusedArgs& ca = la[l].cross;
     ca.st = s->state.as<int>(); ca.lay = L; ca.S = S; ca.d = d; ca.n_head = H;
@@ -757,12 +771,14 @@ static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_
     ca.ckv = s->ckv.as<float>(); ca.ldkv = ldkv; ca.koff = l * 2 * d;
     ca.win_row0 = s->win_meta.as<int>(); ca.win_C = s->win_meta.as<int>() + W;
     ca.Wo = b.cout.w; ca.P = s->Pc.as<float>();
+    ca.g_x_in = gxb[xi]; ca.g_pend = s->ps_gpa.p; ca.g_x_out = gxb[xi ^ 1]; ca.g_P = s->ps_gpc.p;
     xi ^= 1;
     MlpFusedArgs& ma = la[l].mlp;
     ma.st = s->state.as<int>(); ma.S = S; ma.d = d;
     ma.x_in = xb[xi]; ma.pend = s->Pc.as<float>(); ma.KSp = H; ma.pbias = b.cout.b; ma.x_out = xb[xi ^ 1];
     ma.ln_g = b.ln3.g; ma.ln_b = b.ln3.b; ma.ln_eps = b.ln3.eps; ma.ln_inside = m->ln_eps_inside_sqrt;
     ma.W1 = b.mlp1.w; ma.ld1 = b.mlp1.n; ma.b1 = b.mlp1.b; ma.W2 = b.mlp2.w; ma.P = s->P2.as<float>();
+    ma.g_x_in = gxb[xi]; ma.g_pend = s->ps_gpc.p; ma.g_x_out = gxb[xi ^ 1]; ma.g_P = s->ps_gp2.p;
     xi ^= 1;
   }
   // ---- one step's roles, dealt to the blocks: every block runs its own list, in dependency order, every step ----
@@ -824,12 +840,12 @@ static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_
   a.n_logits_roles = n_lg;
   a.n_layer = NL; a.n_rows = W; a.S = S; a.d = d; a.n_head = H; a.nb_mlp = NB;
   a.ctl = s->ps_ctl.as<int>(); a.step0 = s->step; a.n_steps = max_depth; a.mask_until_len = mask_until_len;
-  a.x_fin = xb[xi]; a.P2 = s->P2.as<float>(); a.b2_last = m->dec[NL - 1].mlp2.b;
+  a.x_fin = gxb[xi]; a.P2 = s->ps_gp2.p; a.b2_last = m->dec[NL - 1].mlp2.b; a.tag_base = tag_base;
   a.ln_g = m->ln_dec.g; a.ln_b = m->ln_dec.b; a.ln_eps = m->ln_dec.eps; a.ln_inside = m->ln_eps_inside_sqrt;
   a.Et = m->tok_emb_t; a.vocab_ld = m->vocab_ld; a.V = V; a.mask = s->mask.as<float>();
   a.tstats = s->ps_tstats.as<float>(); a.n_tiles = n_tiles;
   a.gctl = s->gctl.as<int>(); a.gtok = s->gtok.as<int>(); a.Lmax = s->Lmax; a.eot = eot;
-  a.E = m->tok_emb; a.pos = m->dec_pos; a.x0 = xb[0]; a.tabs = s->tabs.as<int>(); a.dead = s->ps_dead.as<int>();
+  a.E = m->tok_emb; a.pos = m->dec_pos; a.x0 = gxb[0]; a.tabs = s->tabs.as<int>(); a.dead = s->ps_dead.as<int>();
   // optional role timeline (developer): WHISPER_HIP_PS_STAMPS=<file> dumps [n_steps][n_roles][3] 100 MHz clock values
   static const char* stamps_path = getenv("WHISPER_HIP_PS_STAMPS");
   const size_t n_stamps = stamps_path ? (size_t)max_depth * roles.size() * 8 : 0;
@@ -841,6 +857,7 @@ static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_
   // first step of the chain: token + position embedding of the last prompt token (every later step: the merge role)
   launch_dec_prepare(st, reinterpret_cast<const int*>(s->host_block_dev), s->state.as<int>(), L, W, s->tabs.as<int>(),
                      s->Lmax, m->tok_emb, m->dec_pos, d, s->x.as<float>(), s->gctl.as<int>());
+  launch_ps_seed(st, s->x.as<float>(), W * d, gxb[0], tag_base + 1u);
   WB_HIP(hipStreamSynchronize(st));            // (the staging vectors above are on the stack)
   hipEvent_t e0 = nullptr, e1 = nullptr;
   prof_tag(KC_PERSIST, 0.0);                   // (its necessary bytes are known when the rows' lengths are: added by the caller)

@@ -226,6 +226,15 @@ static inline void hipemu_raw_buffer_store_b128(hipemu_u32x4 v, hipemu_rsrc r, u
 static inline unsigned hipemu_raw_buffer_load_b32(hipemu_rsrc r, unsigned voff, unsigned soff, int) {
   unsigned v; memcpy(&v, r.base + voff + soff, 4); return v;
 }
+typedef unsigned hipemu_u32x2v __attribute__((ext_vector_type(2)));
+static inline hipemu_u32x2v hipemu_raw_buffer_load_b64(hipemu_rsrc r, unsigned voff, unsigned soff, int) {
+  hipemu_u32x2v v; memcpy(&v, r.base + voff + soff, 8); return v;
+}
+static inline void hipemu_raw_buffer_store_b64(hipemu_u32x2v v, hipemu_rsrc r, unsigned voff, unsigned soff, int) {
+  memcpy(r.base + voff + soff, &v, 8);
+}
+#define __builtin_amdgcn_raw_buffer_load_b64 hipemu_raw_buffer_load_b64
+#define __builtin_amdgcn_raw_buffer_store_b64 hipemu_raw_buffer_store_b64
 #define __builtin_amdgcn_raw_buffer_load_b32 hipemu_raw_buffer_load_b32
 #define __builtin_amdgcn_raw_buffer_load_b128 hipemu_raw_buffer_load_b128
 #define __builtin_amdgcn_raw_buffer_store_b128 hipemu_raw_buffer_store_b128
