@@ -54,6 +54,14 @@ __device__ __forceinline__ bool ps_sweep_retry(unsigned& sweeps, const PsStep& p
   return false;
 }
 __device__ __forceinline__ bool ps_sweeps_ok(const PsStep& ps) { return *ps.lds_flag != 0; }   // call BEHIND a barrier
+// The pre-wake fires when the producers START; their planes land one stage later.  Napping through most of that stage
+// keeps a block's re-reads (tens of KB per sweep) out of the memory system while nothing can have arrived yet.  Purely a
+// matter of load: correctness never depends on it.  (s_sleep 64 ~ 1.7 us)
+template <int UNITS>
+__device__ __forceinline__ void ps_nap() {
+#pragma unroll
+  for (int i = 0; i < UNITS; i++) __builtin_amdgcn_s_sleep(64);
+}
 
 // developer probe: tools/decode_probe.cpp builds this file with -DWB_STAMPS and prints the phase timeline of block 0
 #ifdef WB_STAMPS
@@ -273,6 +281,7 @@ __device__ __forceinline__ bool dec_mlp_body(const MlpFusedArgs& a, const int jb
         if (r >= ps.n_rows || ld_i<true>(ps.dead + min(r, ps.n_rows - 1)) != 0) deadm |= 1 << r;
       const Buf16 xgb(a.g_x_in), pgb(a.g_pend);
       const int iplane = a.S * d;
+      ps_nap<3>();                                  // (the cross-attention blocks have only just started)
       bool rdead[EPT];
 #pragma unroll
       for (int i = 0; i < EPT; i++) { rdead[i] = ((deadm >> (off[i] / d)) & 1) != 0; acc0[i] = a.pbias[col[i]]; xv_fold[i] = 0.f; }
@@ -565,6 +574,7 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
       const Buf16 xgb(a.g_x_in), pgb(a.g_pend);
       const uint32_t pvo = (uint32_t)(r * d + c);
       const int iplane = a.S * d;
+      if (a.KSp > 0) ps_nap<2>();                   // (the previous layer's MLP has only just started)
       constexpr int FP = 4 * DPL;                   // the 4 d / 64 planes of the previous layer's MLP
       float v = 0.f, accp = a.KSp > 0 ? a.pbias[c] : 0.f;
       unsigned sweeps = 0;
@@ -917,6 +927,7 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
       const Buf16 xgb(a.g_x_in), pgb(a.g_pend);
       const uint32_t pvo = (uint32_t)(r * d + c);
       const int iplane = a.S * d;
+      ps_nap<4>();                                  // (the self-attention blocks have only just started)
       constexpr int FP = 8;                         // <= 8 head planes
       float v = 0.f, accp = a.pbias[c];
       unsigned sweeps = 0;

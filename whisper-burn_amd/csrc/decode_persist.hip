@@ -85,7 +85,7 @@ __device__ __forceinline__ bool ps_logits_role(const PersistArgs& a, const int t
 #pragma unroll
   for (int i = 0; i < DPL; i++) { gv[i] = a.ln_g[lane + 64 * i]; bv[i] = a.ln_b[lane + 64 * i]; }
   const int use_mask = (ps.step + 1 <= a.mask_until_len) ? 1 : 0;          // transcribe.rs:271-275
-  if (!ps_wait(ps)) return false;                   // pre-wake: the last layer's cross-attention blocks have finished
+  if (!ps_wait(ps)) return false;                   // the last MLP block of the step has arrived
   {
     // x + (bias + partial planes), plane order fixed (mod.rs:346-348).  The last MLP's planes arrive as tagged granules,
     // re-read until every tag is that stage's; rows whose window has ended take no part (nobody writes them).
@@ -340,7 +340,9 @@ __global__ __launch_bounds__(PS_NT) void dec_persist_kernel(PersistArgs a) {
         ok = dec_mlp_body<MR, DPL, false, true>(la, role.a, ps);
         out = C_MLP + role.layer;
       } else if (role.kind == PSR_LOGITS) {
-        // pre-wake: the last cross-attention block of the step wakes the logits roles through one of PS_NGO words
+        // a few hundred blocks: woken by the last MLP block of the step through one of PS_NGO words (their granule sweeps,
+        // started a stage early, flooded the memory system: 22 MB per round -- profiles/r03_c_ps_timeline_granules_v1.txt);
+        // the planes are read as granules all the same (one pass)
         ps.ctr_index = C_GO + (role.layer % PS_NGO); ps.target = (unsigned)(e + 1);
         ps.ctr = cptr(ps.ctr_index);
         ps.tag_in = tag_l + 2u;
@@ -352,8 +354,8 @@ __global__ __launch_bounds__(PS_NT) void dec_persist_kernel(PersistArgs a) {
       }
       if (!ok) return;                               // the decode was stopped (or a wait gave up): leave
       if (stp && threadIdx.x == 0) stp[6] = wall_clock64();
-      if (role.kind == PSR_CROSS && role.layer == NL - 1)
-        hx_arrive_broadcast(cptr(out), (unsigned)(e + 1) * H * R, cptr(C_GO), PS_NGO, (unsigned)(e + 1));
+      if (role.kind == PSR_MLP && role.layer == NL - 1)
+        hx_arrive_broadcast(cptr(out), (unsigned)(e + 1) * NB, cptr(C_GO), PS_NGO, (unsigned)(e + 1));
       else
         hx_arrive(cptr(out));
       if (stp && threadIdx.x == 0) stp[7] = wall_clock64();
