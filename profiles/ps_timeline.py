@@ -13,7 +13,7 @@ n_steps, n_roles, grid, ns = [int(x) for x in raw[:16].view(np.int32)]
 kinds = raw[16:16 + 4 * n_roles].view(np.int32)
 st = raw[16 + 4 * n_roles:].view(np.uint64).reshape(n_steps, n_roles, ns).astype(np.float64)
 st[st == 0] = np.nan
-names = {0: "attn", 1: "cross", 2: "mlp", 3: "logits", 4: "merge"}
+names = {0: "attn", 1: "cross", 2: "mlp", 3: "logits", 4: "merge", 5: "finln"}
 kind, layer, row = kinds & 0xff, (kinds >> 8) & 0xff, kinds >> 16
 ran = ~np.isnan(st[:, :, 6])
 last = int(np.nonzero(ran.any(1))[0].max()) + 1 if ran.any() else 0
@@ -28,10 +28,10 @@ step_end = np.nanmax(merge_done, axis=1)
 step_start = np.concatenate([[np.nan], step_end[:-1]])
 hdr = f"{'role':<10}{'n':>4}{'wait':>8}{'w->p2':>8}{'p2->p3':>8}{'p3->p4':>8}{'p4->p5':>8}{'p5->done':>9}{'arrive':>8}{'run':>8}{'done@':>9}{'arrived@':>9}"
 print(hdr)
-for k in (0, 1, 2, 3, 4):
+for k in (0, 1, 2, 5, 3, 4):
     for l in sorted(set(layer[kind == k])):
         cols = (kind == k) & (layer == l)
-        if k in (0, 1):
+        if k in (0, 1, 5):
             cols &= row == live_row
         if not cols.any():
             continue

@@ -166,7 +166,7 @@ struct CrossFusedArgs {
 // streams each role's weights BEFORE it waits for the arrival counter of the role's producers, and publishes its output
 // planes with write-through stores (handoff.h).  No kernel boundary, no grid barrier, fixed summation orders.
 struct PsLayerArgs { AttnFusedArgs attn; CrossFusedArgs cross; MlpFusedArgs mlp; };
-enum { PSR_ATTN = 0, PSR_CROSS = 1, PSR_MLP = 2, PSR_LOGITS = 3, PSR_MERGE = 4 };
+enum { PSR_ATTN = 0, PSR_CROSS = 1, PSR_MLP = 2, PSR_LOGITS = 3, PSR_MERGE = 4, PSR_FINLN = 5 };
 struct PsRole { int kind, layer, a, b; };     // a: head / hidden slice / first tile, b: row (logits: tiles of the role; layer: its ordinal)
 struct PersistArgs {
   const PsLayerArgs* layers = nullptr;        // [n_layer] (device)
@@ -179,6 +179,7 @@ struct PersistArgs {
   int mask_until_len = 0;                     // special-token mask while len <= this (transcribe.rs:271-275)
   // logits role: LN(x_fin + b2 + sum P2) . E^T tile -> (best value, best id) per row and tile (x_fin, P2: granules)
   const void* x_fin = nullptr; const void* P2 = nullptr; const float* b2_last = nullptr;
+  void* g_xn = nullptr;                       // [S][d] granules: ln(x + last MLP), written once per row by the final-LN role
   unsigned tag_base = 0;                      // granule tags of this launch: tag_base + 2 + 3 (e n_layer + l) + sublayer
   const float* ln_g = nullptr; const float* ln_b = nullptr; float ln_eps = 0.f; int ln_inside = 0;
   const float* Et = nullptr; int vocab_ld = 0, V = 0; const float* mask = nullptr;

@@ -12,7 +12,8 @@
 //
 // Roles of one step, in dependency order:
 //   per layer l: attn (head h, row r) x H R  ->  cross (h, r) x H R  ->  mlp (64-unit hidden slice j) x 4 d / 64
-//   logits (a run of 128-column vocabulary tiles sharing one fold + LayerNorm)   ->   merge (row r) x R
+//   final LN (row r) x R: ln(x + last MLP planes), once per row   ->   logits (a run of 128-column vocabulary tiles)
+//   ->   merge (row r) x R
 // The host deals the roles to the blocks (session.cpp): a block runs its own list, in dependency order, every step.  The
 // first sublayers' blocks take no logits work (they are back at their wait, weights requested, before the step ends).
 // Dependencies = arrival counters (handoff.h), monotonic within the launch:
@@ -48,10 +49,59 @@ constexpr int PS_NT = 512;
 constexpr int PS_CT = 128;      // vocabulary columns per logits tile
 constexpr int PS_NGO = 16;      // wake-up words of the logits roles (a few hundred pollers: ~13 per word)
 
-// ---- logits role: tile t of  ln(x + b2 + sum_j P2[j]) . E^T  (mod.rs:155-156), last position only -----------------
-// The E^T tile (d x 128 floats = d / 16 float4 per thread) is in flight before the wait.  Each block folds and
-// normalises the rows itself (R d (1 + NB) floats from L2).  Per row and tile the block leaves the best masked logit and
-// its id -- greedy needs the argmax only (log_softmax is monotone: transcribe.rs:276 with beam.rs k = 1).
+// ---- final LayerNorm role: row r of  ln(x + b2 + sum_j P2[j])  (mod.rs:155), once per row ---------------------------------
+// A few hundred logits blocks each folding the 4 d / 64 planes themselves pulled 22 MB through the fabric per step (write-
+// through data is not shared through the L2s); one block per row folds and normalises, and the logits blocks read d values.
+template <int DPL>
+__device__ __forceinline__ bool ps_finln_role(const PersistArgs& a, const int r, const PsStep& ps) {
+  constexpr int d = 64 * DPL, FP = 4 * DPL;
+  __shared__ __attribute__((aligned(16))) float hs[d];
+  const int tid = role_tid<true>(), lane = tid & 63, wave = tid >> 6;
+  float gv[DPL], bv[DPL];
+  if (wave == 0) {
+#pragma unroll
+    for (int i = 0; i < DPL; i++) { gv[i] = a.ln_g[lane + 64 * i]; bv[i] = a.ln_b[lane + 64 * i]; }
+  }
+  const int c = tid < d ? tid : 0;
+  float accp = a.b2_last[c];
+  if (!ps_wait(ps)) return false;                   // pre-wake: the last layer's cross-attention blocks have finished
+  if (ld_i<true>(ps.dead + r) != 0) return true;
+  ps_nap<2>();
+  const Buf16 xgb(a.x_fin), pgb(a.P2);
+  const uint32_t pvo = (uint32_t)(r * d + c);
+  const int iplane = a.S * d;
+  float v = 0.f;
+  unsigned sweeps = 0;
+  for (;;) {
+    const Gran gx = ld_gran(xgb, pvo, 0u);
+    Gran g[FP];
+#pragma unroll
+    for (int j = 0; j < FP; j++) g[j] = ld_gran(pgb, pvo, (uint32_t)(min(j, a.nb_mlp - 1) * iplane));
+    bool ok = gx.tag == ps.tag_in;
+#pragma unroll
+    for (int j = 0; j < FP; j++) ok &= (j >= a.nb_mlp) || g[j].tag == ps.tag_in;
+    if (ok) {
+#pragma unroll
+      for (int j = 0; j < FP; j++) accp += (j < a.nb_mlp) ? g[j].v : 0.f;             // s ascending (mod.rs:346-348)
+      v = gx.v + accp;
+      break;
+    }
+    if (ps_sweep_retry(sweeps, ps)) { *ps.lds_flag = 0; break; }
+  }
+  if (tid < d) hs[tid] = v;
+  ps_stamp(ps, 2);
+  __syncthreads();
+  if (!ps_sweeps_ok(ps)) return false;
+  if (wave == 0) ln_row_lds<DPL>(hs, d, lane, gv, bv, a.ln_eps, a.ln_inside);
+  __syncthreads();
+  if (tid < d) { const Buf16 xo(a.g_xn); st_gran(xo, (uint32_t)(r * d + tid), ps.tag_out, hs[tid]); }
+  return true;
+}
+
+// ---- logits role: tiles of  xn . E^T  (mod.rs:156), last position only ----------------------------------------------------
+// Both E^T tiles of the role (d x 128 floats = d / 16 float4 per thread each) are in flight before the wait.  The normalised
+// rows arrive as granules from the final-LN roles.  Per row and tile the block leaves the best masked logit and its id --
+// greedy needs the argmax only (log_softmax is monotone: transcribe.rs:276 with beam.rs k = 1).
 template <int MR, int DPL>
 __device__ __forceinline__ bool ps_logits_role(const PersistArgs& a, const int tile0, const int n_t, const PsStep& ps) {
   constexpr int d = 64 * DPL, NT = PS_NT, CT = PS_CT;
@@ -81,74 +131,48 @@ __device__ __forceinline__ bool ps_logits_role(const PersistArgs& a, const int t
   float4 w0[NR], w1[TWO ? NR : 1];
   load_tile(w0, tile0);
   if constexpr (TWO) { if (n_t > 1) load_tile(w1, tile0 + 1); }
-  float gv[DPL], bv[DPL];
-#pragma unroll
-  for (int i = 0; i < DPL; i++) { gv[i] = a.ln_g[lane + 64 * i]; bv[i] = a.ln_b[lane + 64 * i]; }
   const int use_mask = (ps.step + 1 <= a.mask_until_len) ? 1 : 0;          // transcribe.rs:271-275
-  if (!ps_wait(ps)) return false;                   // the last MLP block of the step has arrived
+  if (!ps_wait(ps)) return false;                   // pre-wake: the last layer's cross-attention blocks have finished
+  ps_nap<4>();                                      // (its MLP and the final LayerNorm are still to run)
   {
-    // x + (bias + partial planes), plane order fixed (mod.rs:346-348).  The last MLP's planes arrive as tagged granules,
-    // re-read until every tag is that stage's; rows whose window has ended take no part (nobody writes them).
-    int off[EPT], col[EPT];
+    // the normalised rows: MR d granules, re-read until every live row carries the final-LN roles' tag
+    int off[EPT];
 #pragma unroll
     for (int i = 0; i < EPT; i++) {
       int e = tid + NT * i;
       if (e >= MR * d) e = tid;
-      off[i] = e; col[i] = e % d;
+      off[i] = e;
     }
     int deadm = 0;
 #pragma unroll
     for (int r = 0; r < MR; r++)
       if (r >= ps.n_rows || ld_i<true>(ps.dead + min(r, ps.n_rows - 1)) != 0) deadm |= 1 << r;
-    const int plane = a.S * d;
-    const Buf16 xgb(a.x_fin), p2b(a.P2);
-    float v[EPT], acc[EPT];
-    bool rdead[EPT];
-#pragma unroll
-    for (int i = 0; i < EPT; i++) { rdead[i] = ((deadm >> (off[i] / d)) & 1) != 0; v[i] = 0.f; acc[i] = a.b2_last[col[i]]; }
+    const Buf16 xgb(a.g_xn);
+    float v[EPT];
     unsigned sweeps = 0;
-    bool bad = false;
-    for (int sp = 0; sp < a.nb_mlp && !bad; sp += PCH) {
-      for (;;) {
-        Gran gx[EPT], t[PCH][EPT];
-        if (sp == 0) {
+    for (;;) {
+      Gran gx[EPT];
 #pragma unroll
-          for (int i = 0; i < EPT; i++) gx[i] = ld_gran(xgb, (uint32_t)off[i], 0u);
-        }
+      for (int i = 0; i < EPT; i++) gx[i] = ld_gran(xgb, (uint32_t)off[i], 0u);
+      bool ok = true;
 #pragma unroll
-        for (int j = 0; j < PCH; j++)
+      for (int i = 0; i < EPT; i++) ok &= ((deadm >> (off[i] / d)) & 1) != 0 || gx[i].tag == ps.tag_in;
+      if (ok) {
 #pragma unroll
-          for (int i = 0; i < EPT; i++) t[j][i] = ld_gran(p2b, (uint32_t)off[i], (uint32_t)(min(sp + j, a.nb_mlp - 1) * plane));
-        bool ok = true;
-#pragma unroll
-        for (int i = 0; i < EPT; i++) {
-          if (sp == 0) ok &= rdead[i] || gx[i].tag == ps.tag_in;
-#pragma unroll
-          for (int j = 0; j < PCH; j++) ok &= rdead[i] || sp + j >= a.nb_mlp || t[j][i].tag == ps.tag_in;
-        }
-        if (ok) {
-#pragma unroll
-          for (int i = 0; i < EPT; i++) {
-            if (sp == 0) v[i] = gx[i].v;
-#pragma unroll
-            for (int j = 0; j < PCH; j++) acc[i] += (sp + j < a.nb_mlp) ? t[j][i].v : 0.f;
-          }
-          break;
-        }
-        if (ps_sweep_retry(sweeps, ps)) { *ps.lds_flag = 0; bad = true; break; }
+        for (int i = 0; i < EPT; i++) v[i] = ((deadm >> (off[i] / d)) & 1) ? 0.f : gx[i].v;
+        break;
       }
+      if (ps_sweep_retry(sweeps, ps)) { *ps.lds_flag = 0; break; }
     }
 #pragma unroll
     for (int i = 0; i < EPT; i++) {
       const int e = tid + NT * i;
-      if (e < MR * d) (&xs[0][0])[e] = rdead[i] ? 0.f : v[i] + acc[i];
+      if (e < MR * d) (&xs[0][0])[e] = v[i];
     }
   }
   ps_stamp(ps, 2);
   __syncthreads();
   if (!ps_sweeps_ok(ps)) return false;
-  if (wave < MR) ln_row_lds<DPL>(xs[wave], d, lane, gv, bv, a.ln_eps, a.ln_inside);
-  __syncthreads();
   ps_stamp(ps, 3);
   // one tile: GEMV from the registers, column sums over the eight waves, mask, per-row best (value desc, id asc)
   auto run_tile = [&](const float4 (&w)[NR], int tile) {
@@ -339,10 +363,16 @@ __global__ __launch_bounds__(PS_NT) void dec_persist_kernel(PersistArgs a) {
         ps.tag_out = tag_l + 2u; ps.tag_in = tag_l + 1u;
         ok = dec_mlp_body<MR, DPL, false, true>(la, role.a, ps);
         out = C_MLP + role.layer;
+      } else if (role.kind == PSR_FINLN) {
+        ps.ctr_index = C_CROSS + NL - 1; ps.target = (unsigned)(e + 1) * H * R;
+        ps.ctr = cptr(ps.ctr_index);
+        ps.tag_in = tag_l + 2u; ps.tag_out = tag_l + 2u;
+        ok = ps_finln_role<DPL>(a, role.b, ps);
+        out = C_GO + PS_NGO;                         // (nobody waits for it: the logits roles watch the granules)
       } else if (role.kind == PSR_LOGITS) {
-        // a few hundred blocks: woken by the last MLP block of the step through one of PS_NGO words (their granule sweeps,
-        // started a stage early, flooded the memory system: 22 MB per round -- profiles/r03_c_ps_timeline_granules_v1.txt);
-        // the planes are read as granules all the same (one pass)
+        // a few hundred blocks: pre-woken by the last cross-attention block of the step through one of PS_NGO words; they
+        // nap, then watch the final-LN roles' d granules per row (a sweep of all 4 d / 64 MLP planes by every logits block
+        // was 22 MB per round: profiles/r03_c_ps_timeline_granules_v1.txt)
         ps.ctr_index = C_GO + (role.layer % PS_NGO); ps.target = (unsigned)(e + 1);
         ps.ctr = cptr(ps.ctr_index);
         ps.tag_in = tag_l + 2u;
@@ -354,8 +384,8 @@ __global__ __launch_bounds__(PS_NT) void dec_persist_kernel(PersistArgs a) {
       }
       if (!ok) return;                               // the decode was stopped (or a wait gave up): leave
       if (stp && threadIdx.x == 0) stp[6] = wall_clock64();
-      if (role.kind == PSR_MLP && role.layer == NL - 1)
-        hx_arrive_broadcast(cptr(out), (unsigned)(e + 1) * NB, cptr(C_GO), PS_NGO, (unsigned)(e + 1));
+      if (role.kind == PSR_CROSS && role.layer == NL - 1)
+        hx_arrive_broadcast(cptr(out), (unsigned)(e + 1) * H * R, cptr(C_GO), PS_NGO, (unsigned)(e + 1));
       else
         hx_arrive(cptr(out));
       if (stp && threadIdx.x == 0) stp[7] = wall_clock64();
@@ -378,7 +408,7 @@ int max_blocks_per_cu() {
 
 }  // namespace
 
-int ps_ctl_ints(int S, int n_layer) { return HX_HDR + (S + n_layer * S + 2 * n_layer + 8 + PS_NGO) * HX_LINE; }
+int ps_ctl_ints(int S, int n_layer) { return HX_HDR + (S + n_layer * S + 2 * n_layer + 8 + PS_NGO + 1) * HX_LINE; }
 
 // d = 512 with more than 4 rows would need > 160 KB of LDS (every role's LDS is resident at once)
 bool dec_persist_supported(int d, int n_rows) {

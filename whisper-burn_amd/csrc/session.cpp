@@ -741,8 +741,9 @@ static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_
   WB_TRY(s->ps_gpa.ensure_zeroed(((size_t)H * S + 8) * d * 8));
   WB_TRY(s->ps_gpc.ensure_zeroed(((size_t)H * S + 8) * d * 8));
   WB_TRY(s->ps_gp2.ensure_zeroed(((size_t)NB * S + 8) * d * 8));
+  WB_TRY(s->ps_gxn.ensure_zeroed(((size_t)S + 8) * d * 8));
   if (((s->ps_launches + 1) & 0xffffu) == 0) {     // the 16-bit launch count wraps: forget every old tag
-    for (DevMem* b : {&s->ps_gx, &s->ps_gpa, &s->ps_gpc, &s->ps_gp2}) WB_HIP(hipMemsetAsync(b->p, 0, b->bytes, st));
+    for (DevMem* b : {&s->ps_gx, &s->ps_gpa, &s->ps_gpc, &s->ps_gp2, &s->ps_gxn}) WB_HIP(hipMemsetAsync(b->p, 0, b->bytes, st));
     s->ps_launches++;
   }
   const unsigned tag_base = ((++s->ps_launches) & 0xffffu) << 16;
@@ -788,7 +789,7 @@ static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_
     for (int r = 0; r < W; r++) for (int h = 0; h < H; h++) lr.push_back(PsRole{PSR_CROSS, l, h, r});
     for (int j = 0; j < NB; j++) lr.push_back(PsRole{PSR_MLP, l, j, 0});
   }
-  const int grid = std::max(1, std::min(s->ps_grid, (int)lr.size() + n_tiles + W));
+  const int grid = std::max(1, std::min(s->ps_grid, (int)lr.size() + n_tiles + 2 * W));
   std::vector<std::vector<PsRole>> deal(grid);
   for (size_t i = 0; i < lr.size(); i++) deal[i % grid].push_back(lr[i]);
   // logits: blocks that hold a first-layer attention role stay free of it -- they are the first to be needed in the next
@@ -801,6 +802,16 @@ static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_
     if (!early) cand.push_back(b);
   }
   if ((int)cand.size() * 4 < n_tiles) { cand.clear(); for (int b = 0; b < grid; b++) cand.push_back(b); }
+  // final LayerNorm (one per row): blocks without any layer role if there are some (they sit between the last MLP and
+  // the logits on the critical path), else the least loaded ones; they take no logits work
+  std::vector<char> is_fin(grid, 0);
+  {
+    std::vector<int> order(grid);
+    for (int b = 0; b < grid; b++) order[b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return deal[x].size() < deal[y].size(); });
+    for (int r = 0; r < W; r++) { deal[order[r % grid]].push_back(PsRole{PSR_FINLN, 0, 0, r}); is_fin[order[r % grid]] = 1; }
+  }
+  if ((int)cand.size() > 2 * W) cand.erase(std::remove_if(cand.begin(), cand.end(), [&](int b) { return is_fin[b] != 0; }), cand.end());
   std::stable_sort(cand.begin(), cand.end(), [&](int x, int y) { return deal[x].size() < deal[y].size(); });
   const int tpb = (n_tiles + (int)cand.size() - 1) / (int)cand.size();
   const int n_lg = (n_tiles + tpb - 1) / tpb;
@@ -840,6 +851,7 @@ static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_
   a.n_logits_roles = n_lg;
   a.n_layer = NL; a.n_rows = W; a.S = S; a.d = d; a.n_head = H; a.nb_mlp = NB;
   a.ctl = s->ps_ctl.as<int>(); a.step0 = s->step; a.n_steps = max_depth; a.mask_until_len = mask_until_len;
+  a.g_xn = s->ps_gxn.p;
   a.x_fin = gxb[xi]; a.P2 = s->ps_gp2.p; a.b2_last = m->dec[NL - 1].mlp2.b; a.tag_base = tag_base;
   a.ln_g = m->ln_dec.g; a.ln_b = m->ln_dec.b; a.ln_eps = m->ln_dec.eps; a.ln_inside = m->ln_eps_inside_sqrt;
   a.Et = m->tok_emb_t; a.vocab_ld = m->vocab_ld; a.V = V; a.mask = s->mask.as<float>();
@@ -880,7 +892,8 @@ static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_
       fwrite(hdr, 4, 4, f);
       std::vector<int> kinds(roles.size());
       for (size_t i = 0; i < roles.size(); i++)
-        kinds[i] = roles[i].kind | ((roles[i].kind <= PSR_MLP ? roles[i].layer : 0) << 8) | (roles[i].b << 16);
+        kinds[i] = roles[i].kind | ((roles[i].kind <= PSR_MLP ? roles[i].layer : 0) << 8) |
+                   ((roles[i].kind == PSR_LOGITS ? 0 : roles[i].b) << 16);
       fwrite(kinds.data(), 4, kinds.size(), f);
       fwrite(hs.data(), 8, hs.size(), f);
       fclose(f);

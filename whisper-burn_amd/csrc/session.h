@@ -32,7 +32,7 @@ struct wb_session {
   float* topk_lp_host = nullptr;
   wb::DevMem x, h, att, Pqkv, Po, Pq, P1, P2, Pa, Pc, carec, ca, logits, tstats, row_stats, mask, lp_tmp, gctl, gtok, hm;
   wb::DevMem ps_layers, ps_roles, ps_ctl, ps_dead, ps_tstats, ps_stamps;   // persistent flag-chained decode (decode_persist.hip)
-  wb::DevMem ps_gx, ps_gpa, ps_gpc, ps_gp2;     // ... its residual streams / planes as 8-byte {tag, value} granules
+  wb::DevMem ps_gx, ps_gpa, ps_gpc, ps_gp2, ps_gxn;     // ... its residual streams / planes as 8-byte {tag, value} granules
   unsigned ps_launches = 0;                     // launches so far: the high half of the granule tags
   int ps_grid = -1;                                                    // co-resident blocks for this model (-1: not asked yet)
   int n_tiles_v = 0, ct_v = 128;
