@@ -133,7 +133,7 @@ __device__ __forceinline__ bool ps_logits_role(const PersistArgs& a, const int t
   if constexpr (TWO) { if (n_t > 1) load_tile(w1, tile0 + 1); }
   const int use_mask = (ps.step + 1 <= a.mask_until_len) ? 1 : 0;          // transcribe.rs:271-275
   if (!ps_wait(ps)) return false;                   // pre-wake: the last layer's cross-attention blocks have finished
-  ps_nap<4>();                                      // (its MLP and the final LayerNorm are still to run)
+  // (no nap: the wake-up word reaches a few hundred pollers ~9 us after the broadcast -- the last MLP has finished by then)
   {
     // the normalised rows: MR d granules, re-read until every live row carries the final-LN roles' tag
     int off[EPT];
