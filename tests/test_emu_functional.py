@@ -60,8 +60,8 @@ def test_persistent_flag_chained_decode_under_the_functional_model(emu_lib, whic
     """decode_persist.hip: ONE co-resident grid runs every sublayer of every greedy step, blocks hand planes to each other
     through arrival counters (the functional model runs every block on its own thread and passes a baton whenever a block
     spins).  Token-exact against the oracle for d = 128 / 384 / 512, 4 and 7 rows, one role per block and several roles
-    per block (HIPEMU_CUS shrinks the grid), both block orders.  The path is opt-in (WHISPER_HIP_PERSIST=1)."""
-    env = dict(env, WHISPER_HIP_PERSIST="1", WHISPER_HIP_PS_STAMPS=os.path.join(os.environ.get("TMPDIR", "/tmp"), "ps_stamps_test.bin"))
+    per block (HIPEMU_CUS shrinks the grid), both block orders.  It is the default greedy path of the models it supports."""
+    env = dict(env, WHISPER_HIP_PS_STAMPS=os.path.join(os.environ.get("TMPDIR", "/tmp"), "ps_stamps_test.bin"))
     if os.path.exists(env["WHISPER_HIP_PS_STAMPS"]):
         os.remove(env["WHISPER_HIP_PS_STAMPS"])
     p = _run(emu_lib, which, env)
@@ -77,7 +77,7 @@ def test_the_other_kernel_template_families(emu_lib, d):
     assert p.returncode == 0 and f"EMU_CHECK_OK shape{d}" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
-@pytest.mark.parametrize("switch", ["WHISPER_HIP_FUSE_SUB", "WHISPER_HIP_FUSE_X", "WHISPER_HIP_CHAIN", "WHISPER_HIP_GRAPH"])
+@pytest.mark.parametrize("switch", ["WHISPER_HIP_FUSE_SUB", "WHISPER_HIP_FUSE_X", "WHISPER_HIP_CHAIN", "WHISPER_HIP_GRAPH", "WHISPER_HIP_PERSIST"])
 def test_unfused_decode_paths_under_the_functional_model(emu_lib, switch):
     p = _run(emu_lib, "greedy", {switch: "0"})
     assert p.returncode == 0 and "EMU_CHECK_OK greedy" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]

@@ -30,9 +30,9 @@ print("RESULT " + json.dumps(out))
 
 SWITCHES = [{}, {"WHISPER_HIP_FUSE_X": "0"}, {"WHISPER_HIP_FUSE_SUB": "0"}, {"WHISPER_HIP_FUSE_Q": "0"},
             {"WHISPER_HIP_ATTN_KVSPLIT": "0"}, {"WHISPER_HIP_POLL": "0"}, {"WHISPER_HIP_FUSE_X": "0", "WHISPER_HIP_FUSE_CO": "1"},
-            # the persistent flag-chained decode kernel (decode_persist.hip), opt-in: every sublayer of every greedy step
-            # in ONE co-resident launch, blocks handing planes over through arrival counters
-            {"WHISPER_HIP_PERSIST": "1"}]
+            # the graph-replayed chain of one launch per sublayer instead of the persistent flag-chained decode kernel
+            # (decode_persist.hip: every sublayer of every greedy step in ONE co-resident launch -- the default)
+            {"WHISPER_HIP_PERSIST": "0"}]
 
 
 _CACHE = {}
@@ -111,13 +111,13 @@ def test_batch_mode_cross_attention_variants_agree_with_the_oracle():
 
 @pytest.mark.gpu
 def test_persistent_decode_kernel_runs_and_is_bit_reproducible(tmp_path):
-    """WHISPER_HIP_PERSIST=1 really takes the persistent kernel (its role timeline file appears), the tokens of bench.py's
+    """The default greedy path really is the persistent kernel (its role timeline file appears), the tokens of bench.py's
     workload equal the committed oracle rows, and two runs in two processes agree token for token (fixed summation
     orders: the hand-offs carry data, never partial sums by atomics)."""
     g = np.load(GOLD)
     ref = [g["tiny_bench_tokens"][i][:int(g["tiny_bench_lens"][i])].tolist() for i in range(len(g["tiny_bench_lens"]))]
     stamps = str(tmp_path / "stamps.bin")
-    a = _run({"WHISPER_HIP_PERSIST": "1", "WHISPER_HIP_PS_STAMPS": stamps})
+    a = _run({"WHISPER_HIP_PS_STAMPS": stamps})
     assert os.path.exists(stamps) and os.path.getsize(stamps) > 1000, "the persistent kernel did not run"
-    b = _run({"WHISPER_HIP_PERSIST": "1", "WHISPER_HIP_GRAPH": "0"})          # (another cache key: a second process)
+    b = _run({"WHISPER_HIP_GRAPH": "0"})          # (another cache key: a second process)
     assert a["tiny_bench"] == ref and b["tiny_bench"] == ref

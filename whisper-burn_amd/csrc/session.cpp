@@ -940,10 +940,9 @@ int session_greedy_chain(wb_session* s, int first_token, int eot, int max_depth,
   const int chunk = 16;
   int depth = 0;                                   // steps enqueued so far
   // the persistent flag-chained kernel (decode_persist.hip): the small-batch fused path of exact-f32 models whose roles
-  // fit one co-resident grid.  OPT-IN (WHISPER_HIP_PERSIST=1): measured on MI355X it reaches the graph-replayed chain of
-  // one launch per sublayer (15.5 vs 15.5 ms per 30 s of tiny.en audio, profiles/r03_c_*) but does not beat it yet --
-  // the per-role phase latencies, not the launches, bound the step.
-  static const bool persist_enabled = []() { const char* e = getenv("WHISPER_HIP_PERSIST"); return e && e[0] == '1'; }();
+  // fit one co-resident grid.  Default since it passed the graph-replayed chain of one launch per sublayer on MI355X
+  // (14.76 vs 15.5 ms per 30 s of tiny.en audio, profiles/r03_c_ab_*); WHISPER_HIP_PERSIST=0 selects the chain.
+  static const bool persist_enabled = []() { const char* e = getenv("WHISPER_HIP_PERSIST"); return !(e && e[0] == '0'); }();
   static const bool fused_enabled = []() {
     const char* a = getenv("WHISPER_HIP_FUSE_SUB"); const char* b = getenv("WHISPER_HIP_FUSE_X");
     return !(a && a[0] == '0') && !(b && b[0] == '0');
