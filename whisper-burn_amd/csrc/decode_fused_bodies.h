@@ -289,16 +289,25 @@ __device__ __forceinline__ bool dec_mlp_body(const MlpFusedArgs& a, const int jb
       unsigned sweeps = 0;
       bool bad = false;
       for (int sp = 0; sp < npl && !bad; sp += GP) {
+        Gran gx[EPT], g[GP][EPT];
+#pragma unroll
+        for (int i = 0; i < EPT; i++) {
+          gx[i] = Gran{0u, 0.f};
+#pragma unroll
+          for (int j = 0; j < GP; j++) g[j][i] = Gran{0u, 0.f};
+        }
         for (;;) {
-          Gran gx[EPT], g[GP][EPT];
           if (sp == 0) {
 #pragma unroll
-            for (int i = 0; i < EPT; i++) gx[i] = ld_gran(xgb, (uint32_t)off[i], 0u);
+            for (int i = 0; i < EPT; i++)
+              if (!rdead[i] && gx[i].tag != ps.tag_in) gx[i] = ld_gran(xgb, (uint32_t)off[i], 0u);
           }
 #pragma unroll
           for (int j = 0; j < GP; j++)
 #pragma unroll
-            for (int i = 0; i < EPT; i++) g[j][i] = ld_gran(pgb, (uint32_t)off[i], (uint32_t)(min(sp + j, npl - 1) * iplane));
+            for (int i = 0; i < EPT; i++)
+              if (!rdead[i] && sp + j < npl && g[j][i].tag != ps.tag_in)
+                g[j][i] = ld_gran(pgb, (uint32_t)off[i], (uint32_t)((sp + j) * iplane));
           bool ok = true;
 #pragma unroll
           for (int i = 0; i < EPT; i++) {
@@ -578,12 +587,16 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
       constexpr int FP = 4 * DPL;                   // the 4 d / 64 planes of the previous layer's MLP
       float v = 0.f, accp = a.KSp > 0 ? a.pbias[c] : 0.f;
       unsigned sweeps = 0;
+      // (a granule that has arrived is not read again: the retries of the last planes are short round trips)
+      Gran gx{0u, 0.f}, g[FP];
+#pragma unroll
+      for (int j = 0; j < FP; j++) g[j] = Gran{0u, 0.f};
       for (;;) {
-        const Gran gx = ld_gran(xgb, pvo, 0u);
-        Gran g[FP];
+        if (gx.tag != ps.tag_in) gx = ld_gran(xgb, pvo, 0u);
         if (a.KSp > 0) {
 #pragma unroll
-          for (int j = 0; j < FP; j++) g[j] = ld_gran(pgb, pvo, (uint32_t)(min(j, a.KSp - 1) * iplane));
+          for (int j = 0; j < FP; j++)
+            if (j < a.KSp && g[j].tag != ps.tag_in) g[j] = ld_gran(pgb, pvo, (uint32_t)(j * iplane));
         }
         bool ok = gx.tag == ps.tag_in;
         if (a.KSp > 0) {
@@ -931,11 +944,14 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
       constexpr int FP = 8;                         // <= 8 head planes
       float v = 0.f, accp = a.pbias[c];
       unsigned sweeps = 0;
-      for (;;) {
-        const Gran gx = ld_gran(xgb, pvo, 0u);
-        Gran g[FP];
+      Gran gx{0u, 0.f}, g[FP];
 #pragma unroll
-        for (int j = 0; j < FP; j++) g[j] = ld_gran(pgb, pvo, (uint32_t)(min(j, a.KSp - 1) * iplane));
+      for (int j = 0; j < FP; j++) g[j] = Gran{0u, 0.f};
+      for (;;) {
+        if (gx.tag != ps.tag_in) gx = ld_gran(xgb, pvo, 0u);
+#pragma unroll
+        for (int j = 0; j < FP; j++)
+          if (j < a.KSp && g[j].tag != ps.tag_in) g[j] = ld_gran(pgb, pvo, (uint32_t)(j * iplane));
         bool ok = gx.tag == ps.tag_in;
 #pragma unroll
         for (int j = 0; j < FP; j++) ok &= (j >= a.KSp) || g[j].tag == ps.tag_in;

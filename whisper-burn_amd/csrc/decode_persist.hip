@@ -72,11 +72,14 @@ __device__ __forceinline__ bool ps_finln_role(const PersistArgs& a, const int r,
   const int iplane = a.S * d;
   float v = 0.f;
   unsigned sweeps = 0;
-  for (;;) {
-    const Gran gx = ld_gran(xgb, pvo, 0u);
-    Gran g[FP];
+  Gran gx{0u, 0.f}, g[FP];
 #pragma unroll
-    for (int j = 0; j < FP; j++) g[j] = ld_gran(pgb, pvo, (uint32_t)(min(j, a.nb_mlp - 1) * iplane));
+  for (int j = 0; j < FP; j++) g[j] = Gran{0u, 0.f};
+  for (;;) {
+    if (gx.tag != ps.tag_in) gx = ld_gran(xgb, pvo, 0u);
+#pragma unroll
+    for (int j = 0; j < FP; j++)
+      if (j < a.nb_mlp && g[j].tag != ps.tag_in) g[j] = ld_gran(pgb, pvo, (uint32_t)(j * iplane));
     bool ok = gx.tag == ps.tag_in;
 #pragma unroll
     for (int j = 0; j < FP; j++) ok &= (j >= a.nb_mlp) || g[j].tag == ps.tag_in;
