@@ -413,6 +413,18 @@ __device__ __forceinline__ bool dec_mlp_body(const MlpFusedArgs& a, const int jb
   float acc[MR][4];
 #pragma unroll
   for (int r = 0; r < MR; r++) { acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.f; }
+  if constexpr (PS) {
+    // (rows whose window has ended cost nothing: block-uniform branches around their FMAs)
+#pragma unroll
+    for (int r = 0; r < MR; r++) {
+      if ((deadm >> r) & 1) continue;
+#pragma unroll
+      for (int i = 0; i < NW1; i++) {
+        const float xv = hs[r][rg + 32 * i];
+        acc[r][0] += xv * w1[i].x; acc[r][1] += xv * w1[i].y; acc[r][2] += xv * w1[i].z; acc[r][3] += xv * w1[i].w;
+      }
+    }
+  } else {
 #pragma unroll
   for (int i = 0; i < NW1; i++) {
     const int k = rg + 32 * i;
@@ -421,6 +433,7 @@ __device__ __forceinline__ bool dec_mlp_body(const MlpFusedArgs& a, const int jb
       const float xv = hs[r][k];
       acc[r][0] += xv * w1[i].x; acc[r][1] += xv * w1[i].y; acc[r][2] += xv * w1[i].z; acc[r][3] += xv * w1[i].w;
     }
+  }
   }
   // lanes l, l ^ 16, l ^ 32, l ^ 48 hold the same columns for different rows: fold them, then the eight waves
 #pragma unroll
@@ -445,6 +458,17 @@ __device__ __forceinline__ bool dec_mlp_body(const MlpFusedArgs& a, const int jb
   float o[MR][4];
 #pragma unroll
   for (int r = 0; r < MR; r++) { o[r][0] = o[r][1] = o[r][2] = o[r][3] = 0.f; }
+  if constexpr (PS) {
+#pragma unroll
+    for (int r = 0; r < MR; r++) {
+      if ((deadm >> r) & 1) continue;
+#pragma unroll
+      for (int i = 0; i < RPG; i++) {
+        const float hv = hid[r][jb + i];
+        o[r][0] += hv * w2[i].x; o[r][1] += hv * w2[i].y; o[r][2] += hv * w2[i].z; o[r][3] += hv * w2[i].w;
+      }
+    }
+  } else {
 #pragma unroll
   for (int i = 0; i < RPG; i++) {
 #pragma unroll
@@ -452,6 +476,7 @@ __device__ __forceinline__ bool dec_mlp_body(const MlpFusedArgs& a, const int jb
       const float hv = hid[r][jb + i];
       o[r][0] += hv * w2[i].x; o[r][1] += hv * w2[i].y; o[r][2] += hv * w2[i].z; o[r][3] += hv * w2[i].w;
     }
+  }
   }
   if (p2 && jg > 0) {
 #pragma unroll

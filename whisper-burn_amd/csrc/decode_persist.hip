@@ -135,6 +135,7 @@ __device__ __forceinline__ bool ps_logits_role(const PersistArgs& a, const int t
   load_tile(w0, tile0);
   if constexpr (TWO) { if (n_t > 1) load_tile(w1, tile0 + 1); }
   const int use_mask = (ps.step + 1 <= a.mask_until_len) ? 1 : 0;          // transcribe.rs:271-275
+  int deadm = 0;                                    // bit r: row r takes no part (its window has ended)
   if (!ps_wait(ps)) return false;                   // pre-wake: the last layer's cross-attention blocks have finished
   // (no nap: the wake-up word reaches a few hundred pollers ~9 us after the broadcast -- the last MLP has finished by then)
   {
@@ -146,7 +147,6 @@ __device__ __forceinline__ bool ps_logits_role(const PersistArgs& a, const int t
       if (e >= MR * d) e = tid;
       off[i] = e;
     }
-    int deadm = 0;
 #pragma unroll
     for (int r = 0; r < MR; r++)
       if (r >= ps.n_rows || ld_i<true>(ps.dead + min(r, ps.n_rows - 1)) != 0) deadm |= 1 << r;
@@ -190,9 +190,10 @@ __device__ __forceinline__ bool ps_logits_role(const PersistArgs& a, const int t
 #pragma unroll
     for (int r = 0; r < MR; r++) { acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.f; }
 #pragma unroll
-    for (int i4 = 0; i4 < NR; i4 += 4) {
+    for (int r = 0; r < MR; r++) {
+      if ((deadm >> r) & 1) continue;               // (rows whose window has ended cost nothing)
 #pragma unroll
-      for (int r = 0; r < MR; r++) {
+      for (int i4 = 0; i4 < NR; i4 += 4) {
         const float4 xv = *reinterpret_cast<const float4*>(&xs[r][(2 * wave + hh) * NR + i4]);
         acc[r][0] += xv.x * w[i4].x; acc[r][1] += xv.x * w[i4].y; acc[r][2] += xv.x * w[i4].z; acc[r][3] += xv.x * w[i4].w;
         acc[r][0] += xv.y * w[i4 + 1].x; acc[r][1] += xv.y * w[i4 + 1].y; acc[r][2] += xv.y * w[i4 + 1].z; acc[r][3] += xv.y * w[i4 + 1].w;
@@ -222,7 +223,7 @@ __device__ __forceinline__ bool ps_logits_role(const PersistArgs& a, const int t
       tilev[r][c] = v;
     }
     __syncthreads();
-    if (wave < MR && wave < ps.n_rows) {
+    if (wave < MR && !((deadm >> wave) & 1)) {
       const int r = wave;
       const float v0 = tilev[r][lane], v1 = tilev[r][lane + 64];
       float bvv; int bi;
