@@ -583,6 +583,32 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
   float xfold;                                     // this thread's element of x + pending (kept for the final x_out store)
   float gv[DPL], bv[DPL];                          // LayerNorm parameters (wave 0 normalises)
   float qbias = 0.f;
+  // ---- the cached K / V rows of the first 128 positions, the coalesced way (16 lanes x 16 B = one 256-byte head row;
+  // thread (rg, pq4) holds quad pq4 of positions rg + 32 i): requested behind the first two weight rounds, so that they
+  // arrive under the QKV FMAs instead of costing two dependent round trips after them (persistent mode: BEFORE the wait --
+  // the rows were written by this same role in earlier steps).  Positions past the live range re-read slot 0 of the row
+  // (always valid; masked where consumed).
+  const int npast = len - 1;                       // cached positions; the new token attends to itself from LDS
+  const int rg = tid >> 4, pq4 = (tid & 15) * 4;
+  const int* tb = a.tabs + (size_t)step_par * a.lay.S * a.Lmax + r * a.Lmax;
+  auto slot_of = [&](int p) { if constexpr (PS) return p * a.lay.S + r; else return tb[p]; };
+  int slot_new = 0;
+  const Buf16 kbuf(a.Kc), vbuf(a.Vc);              // (persistent mode: the cache rows were written through -> sc1 loads)
+  float4 kc[PSL], vc[PSL];
+  auto load_cache_tile = [&]() {
+    int slot[PSL];
+#pragma unroll
+    for (int i = 0; i < PSL; i++) slot[i] = slot_of(rg + 32 * i < npast ? rg + 32 * i : 0);
+    slot_new = slot_of(npast);
+    if constexpr (!PS) {
+      if (npast > PT)                              // only the tail tiles of long sequences walk the table through LDS
+        for (int p = tid; p < npast; p += NT) tbs[p] = tb[p];
+    }
+#pragma unroll
+    for (int i = 0; i < PSL; i++) kc[i] = ld_f4<PS>(a.Kc, kbuf, (uint32_t)(slot[i] * d + h * 64 + pq4));
+#pragma unroll
+    for (int i = 0; i < PSL; i++) vc[i] = ld_f4<PS>(a.Vc, vbuf, (uint32_t)(slot[i] * d + h * 64 + pq4));
+  };
   {
     // x + (bias + partial planes), s ascending (mod.rs:346-348): one element per thread, all planes in flight together
     const int c = tid < d ? tid : 0;
@@ -602,6 +628,7 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
       // (the stage before the producers has finished) -- the planes themselves arrive as tagged granules, re-read until
       // every tag is the producers' (arrival and payload in one round trip)
       load_weights();
+      load_cache_tile();
       if (!ps_wait(ps)) return false;
       dead = ld_i<true>(ps.dead + r);
       if (r >= n_rows || dead) return true;
@@ -669,28 +696,7 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
     }
   }
   if constexpr (!PS) qbias = tid < 192 ? a.bqkv[(tid >> 6) * d + h * 64 + (tid & 63)] : 0.f;   // key part is zero (mod.rs:402-404)
-  // ---- the cached K / V rows of the first 128 positions, the coalesced way (16 lanes x 16 B = one 256-byte head row;
-  // thread (rg, pq4) holds quad pq4 of positions rg + 32 i): requested HERE, behind the first two weight rounds, so
-  // that they arrive under the QKV FMAs instead of costing two dependent round trips after them.  Positions past the
-  // live range re-read slot 0 of the row (always valid; masked where consumed).
-  const int npast = len - 1;                       // cached positions; the new token attends to itself from LDS
-  const int rg = tid >> 4, pq4 = (tid & 15) * 4;
-  const int* tb = a.tabs + (size_t)step_par * a.lay.S * a.Lmax + r * a.Lmax;
-  auto slot_of = [&](int p) { if constexpr (PS) return p * a.lay.S + r; else return tb[p]; };
-  int slot[PSL];
-#pragma unroll
-  for (int i = 0; i < PSL; i++) slot[i] = slot_of(rg + 32 * i < npast ? rg + 32 * i : 0);
-  const int slot_new = slot_of(npast);
-  if constexpr (!PS) {
-    if (npast > PT)                                // only the tail tiles of long sequences walk the table through LDS
-      for (int p = tid; p < npast; p += NT) tbs[p] = tb[p];
-  }
-  const Buf16 kbuf(a.Kc), vbuf(a.Vc);              // (persistent mode: the cache rows were written by other blocks -> sc1)
-  float4 kc[PSL], vc[PSL];
-#pragma unroll
-  for (int i = 0; i < PSL; i++) kc[i] = ld_f4<PS>(a.Kc, kbuf, (uint32_t)(slot[i] * d + h * 64 + pq4));
-#pragma unroll
-  for (int i = 0; i < PSL; i++) vc[i] = ld_f4<PS>(a.Vc, vbuf, (uint32_t)(slot[i] * d + h * 64 + pq4));
+  if constexpr (!PS) load_cache_tile();
   WB_STAMP(1);
   if constexpr (PS) ps_stamp(ps, 2);
   __syncthreads();
