@@ -246,7 +246,8 @@ def main() -> None:
         def pmc_bytes(cls_name):
             """HBM bytes per launch of the rocprof kernel(s) behind one profiler class (profiles/r02_pmc_*.json is keyed
             by the demangled kernel name)."""
-            want = {"dec_attn_fused": lambda n: "dec_attn_fused_kernel" in n,
+            want = {"dec_persist": lambda n: "dec_persist_kernel" in n,
+                    "dec_attn_fused": lambda n: "dec_attn_fused_kernel" in n,
                     "dec_mlp_fused": lambda n: "dec_mlp_fused_kernel" in n,
                     "dec_cross_attn": lambda n: "dec_cross_attn_kernel" in n,
                     "dec_cross_fused": lambda n: "dec_cross_fused_kernel" in n,
