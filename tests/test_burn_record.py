@@ -73,3 +73,41 @@ def test_model_from_record_equals_model_from_tensors(tmp_path, micro_weights):
     toks = np.array([[5, 17, 300, 2]], dtype=np.int32)
     assert np.array_equal(a.forward(mel, toks), b.forward(mel, toks))
     a.close(); b.close()
+
+
+def test_fixture_nesting_follows_the_reference_module_definitions(micro_weights):
+    """The record fixture's nesting -- field names AND their order, including the stored `mask` Param and the usize fields
+    that ride in the record -- is derived from the reference's own `#[derive(Module)]` structs (src/model/mod.rs:41-45,
+    :117-126, :214-225, :286-292, :330-338, :366-371, :416-424 and the cross-attention struct).  Burn's named-MessagePack
+    recorder serialises a module record field by field in declaration order; Burn itself is not vendored, so this is the
+    closest in-tree pin of the layout the reader walks."""
+    import os
+    import re
+    src = "/root/reference/src/model/mod.rs"
+    if not os.path.exists(src):
+        pytest.skip("the reference checkout is not present on this machine")
+    text = open(src).read()
+    structs = {m.group(1): re.findall(r"^\s*(\w+)\s*:", m.group(2), flags=re.M)
+               for m in re.finditer(r"#\[derive\(Module, Debug\)\]\s*pub struct (\w+)<B: Backend>\s*\{(.*?)\n\}", text, flags=re.S)}
+    rec = burnrecord.module_record(micro_weights)
+    assert list(rec) == structs["Whisper"] == ["encoder", "decoder"]
+    assert list(rec["encoder"]) == structs["AudioEncoder"]
+    assert list(rec["decoder"]) == structs["TextDecoder"] and "mask" in structs["TextDecoder"]
+    assert list(rec["encoder"]["blocks"][0]) == structs["ResidualEncoderAttentionBlock"]
+    assert list(rec["decoder"]["blocks"][0]) == structs["ResidualDecoderAttentionBlock"]
+    assert list(rec["encoder"]["blocks"][0]["attn"]) == structs["MultiHeadSelfAttention"]
+    assert list(rec["decoder"]["blocks"][0]["cross_attn"]) == structs["MultiHeadCrossAttention"]
+    assert list(rec["encoder"]["blocks"][0]["mlp"]) == structs["MLP"]
+    # the usize fields are plain integers in the record, the mask a full [n_text_ctx, n_text_ctx] Param
+    assert isinstance(rec["encoder"]["n_mels"], int) and isinstance(rec["decoder"]["n_text_ctx"], int)
+    assert rec["decoder"]["mask"]["param"]["shape"] == [rec["decoder"]["n_text_ctx"]] * 2
+
+
+def test_reader_error_names_the_layout_it_assumed(tmp_path):
+    p = str(tmp_path / "junk.mpk.gz")
+    with gzip.open(p, "wb") as f:
+        f.write(msgpack.packb({"metadata": {"float": "f32"}, "item": {"something": 1}}))
+    with pytest.raises(wb.WbError) as e:
+        wb.burn_record_tensors(p)
+    msg = str(e.value)
+    assert "Burn 0.9.0" in msg and "not vendored" in msg and "mask, n_vocab, n_text_ctx" in msg and "{id, param:" in msg

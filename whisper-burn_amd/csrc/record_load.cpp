@@ -225,7 +225,13 @@ int read_burn_record(const char* path, const char* cfg_path, TensorMap* tm) {
   }
   walk(root, "", tm);
   WB_REQUIRE(tm->count("encoder/conv1/weight") && tm->count("decoder/positional_embedding"), WB_ERR_IO,
-             "%s: no Whisper module record found (encoder.conv1.weight / decoder.positional_embedding missing)", path);
+             "%s: no Whisper module record found (encoder.conv1.weight / decoder.positional_embedding missing).  Layout "
+             "assumed (Burn 0.9.0 @ fb2a71bb is not vendored with the reference, so it could not be checked against a "
+             "converter-written file): gzip(named MessagePack) of {metadata, item}, item = the module tree of "
+             "src/model/mod.rs in field order (encoder{conv1, gelu1, conv2, gelu2, blocks[], ln_post, positional_embedding, "
+             "n_mels, n_audio_ctx}, decoder{token_embedding, positional_embedding, blocks[], ln, mask, n_vocab, n_text_ctx}), "
+             "a Param as {id, param: {value[], shape[]}} or {id, param: {data: {value[], shape[]}}}, Linear {weight, bias}, "
+             "LayerNorm {gamma, beta, epsilon}", path);
   tm->erase("decoder/mask");                               // mod.rs:125: a stored 448 x 448 mask; causality is implicit here
   if (tm->count("decoder/token_embedding")) {              // a bare Param (mod.rs:121) -> the dump's <name>/weight
     (*tm)["decoder/token_embedding/weight"] = std::move((*tm)["decoder/token_embedding"]);
