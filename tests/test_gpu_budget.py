@@ -13,7 +13,11 @@ SAME algorithm on the SAME samples, teacher-forced over the HIP path's own greed
 Asserted, at tiny.en's real shape, on the bench audio's first window AND on the reference's own audio.wav:
   |hip - o64| <= 1e-3              the HIP path is within the north star's tolerance of the EXACT result from raw audio
   |hip - o64| <  |o32 - o64|       ... and strictly closer to it than the reference-style f32 evaluation is
-  |hip - o32| <= |hip - o64| + |o32 - o64| <= BUDGET   the two f32 paths differ by no more than their own roundings
+  |hip - o32| <= |hip - o64| + |o32 - o64|             the two f32 paths differ by no more than their own roundings
+                                                       (on the bench clip that sum is < BUDGET = 3e-3; on the reference's
+                                                       audio.wav, whose upper mel bands sit at the clamp floor, the f32 oracle
+                                                       alone is ~1e-2 from the exact result -- measured 1.06e-2 -- while the
+                                                       HIP path is 1.5e-4 from it)
 """
 import numpy as np
 import pytest
@@ -82,7 +86,9 @@ def test_pcm_to_logprob_budget_tiny_en(clip):
           f"oracle_f32-exact {d_o32_exact:.3e}, hip-oracle_f32 {d_hip_o32:.3e}")
     assert d_hip_exact <= EXACT_TOL, d_hip_exact
     assert d_hip_exact < d_o32_exact, (d_hip_exact, d_o32_exact)
-    assert d_hip_o32 <= min(BUDGET, d_hip_exact + d_o32_exact + 1e-6), (d_hip_o32, d_hip_exact, d_o32_exact)
+    assert d_hip_o32 <= d_hip_exact + d_o32_exact + 1e-6, (d_hip_o32, d_hip_exact, d_o32_exact)
+    if clip == "bench_window0":
+        assert d_hip_o32 <= BUDGET, d_hip_o32
     # decisions are unaffected: the row is the argmax chain under all three evaluations
     for name, r in (("o32", r32), ("o64", r64)):
         assert [int(np.argmax(x)) for x in r] == row[4:], name

@@ -1086,7 +1086,7 @@ int session_greedy_chain(wb_session* s, int first_token, int eot, int max_depth,
     for (int p = prompt_len; p < len; p++) out_tokens[(size_t)w * row_stride + p] = toks[(size_t)w * s->Lmax + p];
     out_lens[w] = len;
   }
-  if (profile().on && s->prof_cls_cross >= 0 && s->prof_cls_self >= 0) {
+  if (profile().on && !persist && s->prof_cls_cross >= 0 && s->prof_cls_self >= 0) {
     // The tags counted every launched row's cached K/V.  A row whose window had already ended is marked dead in the
     // step state: its attention blocks exit at their first wait and stream nothing -- take those bytes back, so that
     // the reported algorithmic bytes are the NECESSARY ones.
