@@ -191,7 +191,9 @@ def _session_logprob_rows(eng, o, st, audio, use_windows, max_beams, n_steps, fo
 def _assert_budget(res, model):
     assert res["hip_exact"] <= max(LOGPROB_TOL, BUDGET_FACTOR * res["o32_exact"]), res
     assert res["hip_exact"] <= ABS_CAP[model], res
-    assert res["hip_o32"] <= 3.0 * ABS_CAP[model], res          # every window against the f32 oracle: a sanity bound
+    # every window against the f32 oracle: a sanity bound (two f32 evaluations of an ill-conditioned chain differ by up to
+    # the sum of their distances to the exact one; profiles/r03_e_diag_large_v2.log: 0.26 at large-v2's first positions)
+    assert res["hip_o32"] <= 6.0 * ABS_CAP[model], res
 
 
 def test_large_v2_batch_mode_beams_logprob_rows(large_v2):
