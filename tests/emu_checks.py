@@ -135,6 +135,20 @@ def main(which):
         got = eng.forward(mel, toks)
         ref = o.forward(torch.from_numpy(mel), torch.from_numpy(toks)).numpy()
         assert np.abs(got - ref).max() < 1e-3, np.abs(got - ref).max()
+    elif which == "geometry384":
+        # the two-pass key ring of the fused cross-attention block (a window with more keys than one pass holds: 768 on
+        # the device, 256 in this build): d = 384, doubled windows of 2 x 400 frames (C = 400 keys) + a shorter tail window,
+        # through the persistent kernel (default) or the chain of one launch per sublayer (WHISPER_HIP_PERSIST=0)
+        dims = synth.micro_dims(n_state=384, n_head=6, n_layer=2, n_vocab=2053, n_audio_ctx=400)
+        w2 = synth.synth_weights(dims, seed=57)
+        e2, o2 = wb.Whisper.from_tensors(w2), OracleWhisper(w2, frame_limit_x2=True)
+        s2 = wb.SpecialTokens.for_vocab(2053)
+        a = synth.synth_audio(16000 * 11, 43)
+        e2.set_frame_limit(True)
+        got, wins = wb.waveform_to_tokens(e2, s2, a, 16000, 1, 8)
+        ref, rw = otr.waveform_to_tokens(o2, pu.ost(s2), a, 16000, 1, 8, return_windows=True)
+        assert got == ref and wins == rw and len(wins) == 3, (got, ref, wins, rw)
+        e2.close()
     elif which == "geometry":
         # wb_model_set_frame_limit(1): windows of 2 n_audio_ctx frames.  n_audio_ctx = 400 keeps the clip short while
         # both window lengths (3.9 s and 7.9 s) stay above the 3 s overlap (below it the reference's shift is 1 sample)

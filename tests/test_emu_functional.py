@@ -69,6 +69,15 @@ def test_persistent_flag_chained_decode_under_the_functional_model(emu_lib, whic
     assert p.returncode == 0 and f"EMU_CHECK_OK {which}" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
+@pytest.mark.parametrize("env", [{}, {"WHISPER_HIP_PERSIST": "0"}])
+def test_two_pass_key_ring_of_the_fused_cross_attention(emu_lib, env):
+    """A window with more keys than one pass of the fused cross-attention block holds (the opt-in doubled window: C = 1500
+    on the device against 768 per pass; here C = 395 against 256): K and V each make two passes through the register ring,
+    in the persistent kernel and in the one-launch-per-sublayer chain.  Token-exact against the oracle."""
+    p = _run(emu_lib, "geometry384", env)
+    assert p.returncode == 0 and "EMU_CHECK_OK geometry384" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
 @pytest.mark.parametrize("d", [384, 768])
 def test_the_other_kernel_template_families(emu_lib, d):
     """d = 384 (the fused sublayer kernels of tiny.en; base.en's d = 512 instantiates the same templates) and 768

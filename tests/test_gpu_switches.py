@@ -68,6 +68,42 @@ def test_switch_reproduces_the_oracle_tokens(switch):
         assert got["tiny_beam5"] == _run({})["tiny_beam5"]
 
 
+W30_CHILD = r"""
+import json, sys
+sys.path[:0] = [%(root)r, %(pkg)r, %(tests)r]
+import whisper_burn_amd as wb
+import workloads
+wl = workloads.WORKLOADS["tiny_whisper30"]
+eng = wb.Whisper.from_tensors(wl.weights())
+eng.set_frame_limit(True)
+st = wb.SpecialTokens.for_vocab(eng.dims["n_vocab"])
+toks, wins = wb.waveform_to_tokens(eng, st, wl.audio(), 16000, wl.beam, wl.depth)
+eng.close()
+print("RESULT " + json.dumps([list(map(int, w)) for w in wins]))
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("switch", [{"WHISPER_HIP_PERSIST": "0"}, {"WHISPER_HIP_FUSE_X": "0"}],
+                         ids=lambda s: ",".join(f"{k[12:]}={v}" for k, v in s.items()))
+def test_the_30_s_window_geometry_on_the_other_decode_paths(switch):
+    """The opt-in 30 s window (C = 1500 keys per window): the default is the persistent kernel with the two-pass key ring
+    (test_gpu_workloads pins it against the committed rows); here the chain of one launch per sublayer with the same
+    two-pass block (PERSIST=0) and the chunked cross-attention pair (FUSE_X=0) reproduce the same rows."""
+    env = dict(os.environ)
+    for k in list(env):
+        if k.startswith("WHISPER_HIP_") and k not in ("WHISPER_HIP_LIB", "WHISPER_HIP_ALLOW_EMU"):
+            del env[k]
+    env.update(switch)
+    code = W30_CHILD % {"root": ROOT, "pkg": os.path.join(ROOT, "whisper-burn_amd"), "tests": os.path.join(ROOT, "tests")}
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    got = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):])
+    g = np.load(GOLD)
+    ref = [g["tiny_whisper30_tokens"][i][:int(g["tiny_whisper30_lens"][i])].tolist() for i in range(len(g["tiny_whisper30_lens"]))]
+    assert got == ref
+
+
 BATCH_CHILD = r"""
 import json, sys
 sys.path[:0] = [%(root)r, %(pkg)r, %(tests)r]

@@ -154,6 +154,7 @@ struct CrossFusedArgs {
   const float* Wq = nullptr; const float* bq = nullptr; float scale = 0.f;         // [d][d], [d]
   const float* ckv = nullptr; int ldkv = 0, koff = 0;                             // cached cross K|V rows (K pre-scaled)
   const int* win_row0 = nullptr; const int* win_C = nullptr;
+  int n_pass = 1;                                                                 // 2: some window has CROSS_FUSED_MAX_C < C <= 2 CROSS_FUSED_MAX_C keys
   const float* Wo = nullptr;                                                      // [d][d]
   float* P = nullptr;                                                             // out: planes [n_head][S][d] (out bias NOT added)
   unsigned long long* stamps = nullptr;
@@ -174,6 +175,7 @@ struct PersistArgs {
   const int* role_off = nullptr;              // [grid + 1]: block b runs roles [role_off[b], role_off[b + 1]) every step
   int n_logits_roles = 0;
   int n_layer = 0, n_rows = 0, S = 0, d = 0, n_head = 0, nb_mlp = 0;
+  int n_pass = 1;                             // key passes of the cross-attention roles (2: a window with > CROSS_FUSED_MAX_C keys)
   int* ctl = nullptr;                         // HX_* control words + arrival counters (device; set up by the host)
   int step0 = 0, n_steps = 0;                 // first decode step of the chain, most steps to run
   int mask_until_len = 0;                     // special-token mask while len <= this (transcribe.rs:271-275)
@@ -191,14 +193,21 @@ struct PersistArgs {
   unsigned long long* stamps = nullptr;       // optional timeline: [n_steps][n_roles][3] (role start, wait passed, done)
 };
 int ps_ctl_ints(int S, int n_layer);
-bool dec_persist_supported(int d, int n_rows);
+bool dec_persist_supported(int d, int n_rows, int max_keys);
 // grid: blocks of 512 threads that are co-resident on this device for (d, n_rows) -- 0 if the kernel cannot run
-int dec_persist_max_grid(int device, int d, int n_rows);
+int dec_persist_max_grid(int device, int d, int n_rows, int max_keys);
 int launch_dec_persist(hipStream_t st, const PersistArgs& a, int grid);
 // seeds the granule copy of the first step's x rows: tag = tag_base + 1 (what the first self-attention blocks expect)
 void launch_ps_seed(hipStream_t st, const float* x, int n, void* gx, unsigned tag);
 
-constexpr int CROSS_FUSED_MAX_C = 768;   // keys per window the fused cross-attention block handles (n_audio_ctx / 2 = 750)
+#ifdef HIPEMU
+// (functional-model build: micro shapes -- two tiles per pass, so that the doubled-window geometry of the micro models,
+// C = 400 keys, runs the two-pass ring)
+constexpr int CROSS_FUSED_MAX_C = 256;
+#else
+constexpr int CROSS_FUSED_MAX_C = 768;   // keys per window one pass of the fused cross-attention block holds (n_audio_ctx / 2 = 750)
+#endif
+constexpr int CROSS_FUSED_MAX_PASSES = 2;   // ... and the passes it can make (C = 1500: the opt-in 30 s window)
 void launch_dec_cross_fused(hipStream_t st, const CrossFusedArgs& a, int n_rows_hint);
 bool dec_fused_supported(int d);
 int dec_mlp_fused_planes(int d);

@@ -35,9 +35,9 @@ template <int DPL>
 __global__ __launch_bounds__(512) void dec_attn_fused_kernel(AttnFusedArgs a) {
   dec_attn_body<DPL, false>(a, blockIdx.x, blockIdx.y, PsStep());
 }
-template <int DPL>
+template <int DPL, int NP>
 __global__ __launch_bounds__(512) void dec_cross_fused_kernel(CrossFusedArgs a) {
-  dec_cross_body<DPL, false>(a, blockIdx.x, blockIdx.y, PsStep());
+  dec_cross_body<DPL, false, NP>(a, blockIdx.x, blockIdx.y, PsStep());
 }
 
 }  // namespace
@@ -62,9 +62,16 @@ void launch_dec_mlp_fused(hipStream_t st, const MlpFusedArgs& a, int n_rows_hint
 
 void launch_dec_cross_fused(hipStream_t st, const CrossFusedArgs& a, int n_rows_hint) {
   const dim3 grid(a.n_head <= 8 ? 8 : a.n_head, n_rows_hint), block(512);
-  if (a.d == 128) WB_KLAUNCH((dec_cross_fused_kernel<2>), grid, block, 0, st, a);
-  else if (a.d == 384) WB_KLAUNCH((dec_cross_fused_kernel<6>), grid, block, 0, st, a);
-  else WB_KLAUNCH((dec_cross_fused_kernel<8>), grid, block, 0, st, a);
+  // (a.n_pass = 2: some window holds more than CROSS_FUSED_MAX_C keys -- the two-pass ring)
+  if (a.n_pass <= 1) {
+    if (a.d == 128) WB_KLAUNCH((dec_cross_fused_kernel<2, 1>), grid, block, 0, st, a);
+    else if (a.d == 384) WB_KLAUNCH((dec_cross_fused_kernel<6, 1>), grid, block, 0, st, a);
+    else WB_KLAUNCH((dec_cross_fused_kernel<8, 1>), grid, block, 0, st, a);
+  } else {
+    if (a.d == 128) WB_KLAUNCH((dec_cross_fused_kernel<2, 2>), grid, block, 0, st, a);
+    else if (a.d == 384) WB_KLAUNCH((dec_cross_fused_kernel<6, 2>), grid, block, 0, st, a);
+    else WB_KLAUNCH((dec_cross_fused_kernel<8, 2>), grid, block, 0, st, a);
+  }
 }
 
 void launch_dec_attn_fused(hipStream_t st, const AttnFusedArgs& a, int n_rows_hint) {

@@ -629,6 +629,17 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
       // every tag is the producers' (arrival and payload in one round trip)
       load_weights();
       load_cache_tile();
+#ifdef WB_EXP_L2WARM
+      // the weight rounds that stream through the two register sets later: touched now, while the block would only wait,
+      // so that they come from this XCD's L2 (the logits tiles of the previous step have swept it)
+#pragma unroll 1
+      for (int it = 2; it < NIT; it++) {
+        float4 t[RK];
+        load_round(t, it);
+#pragma unroll
+        for (int j = 0; j < RK; j++) asm volatile("" : : "v"(t[j].x), "v"(t[j].w));
+      }
+#endif
       if (!ps_wait(ps)) return false;
       dead = ld_i<true>(ps.dead + r);
       if (r >= n_rows || dead) return true;
@@ -883,9 +894,16 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
 // done, so the V stream is in flight under the softmax statistics.  Scores are 4-term partial dots reduced over the
 // 16 lanes of a row by DPP (no LDS transpose); the output is a float4 of partial sums per thread, reduced over the 32
 // row groups in a fixed order.  The Wq slice arrives under the fold + LayerNorm, the Wo slice under the scores.
-template <int DPL, bool PS>
+//
+// NP = 2 (768 < C <= 1536 keys per window: the opt-in 30 s window geometry, C = 1500): the ring still holds 768 keys, so
+// FOUR streams pass through it -- K of keys [0, 768), K of keys [768, C) (a register is refilled as soon as its score
+// is done), V of keys [0, 768) (refilled under the second pass of scores), V of keys [768, C) (refilled as the first
+// pass of the output sum consumes a register).  Straight-line code: a window with C <= 768 keys (the tail window) makes
+// the same passes over clamped rows, its scores past C never stored and their probabilities zero.
+template <int DPL, bool PS, int NP = 1>
 __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const int h, const int r, const PsStep& ps) {
   constexpr int NT = 512;
+  constexpr int PASS_C = CROSS_FUSED_MAX_C, CMAX = NP * PASS_C;
   constexpr int d = 64 * DPL;
   constexpr int NWQ = d / 32;                      // Wq rows per thread
   constexpr int CF = d / 4;
@@ -896,8 +914,8 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
   __shared__ __attribute__((aligned(16))) float hs[d];
   __shared__ __attribute__((aligned(16))) float red[8][64];
   __shared__ __attribute__((aligned(16))) float qv[64];
-  __shared__ float sc[CROSS_FUSED_MAX_C];
-  __shared__ float pbuf[CROSS_FUSED_MAX_C];
+  __shared__ float sc[CMAX];
+  __shared__ float pbuf[CMAX];
   __shared__ __attribute__((aligned(16))) float part[32][64];
   __shared__ __attribute__((aligned(16))) float att[64];
   __shared__ __attribute__((aligned(16))) float obuf[(G - 1) * d];
@@ -942,7 +960,7 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
       if (ws < 8) { C_w = __builtin_amdgcn_readlane(vC8, ws); row0_w = __builtin_amdgcn_readlane(vR8, ws); }
       else { C_w = a.win_C[ws]; row0_w = a.win_row0[ws]; }
     }
-    C = min(C_w, CROSS_FUSED_MAX_C);
+    C = min(C_w, CMAX);
     // uniform base + 32-bit per-lane offsets; keys past C re-read row C - 1 (their scores are never stored and their
     // probabilities are zero), so every load is unconditional: no predicate sits between two requests
     Kh = a.ckv + (int64_t)row0_w * a.ldkv + a.koff + h * 64;                  // K pre-scaled at projection time
@@ -965,6 +983,18 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
       // arrive as tagged granules
       load_weights();
       load_keys();
+#ifdef WB_EXP_L2WARM
+      // the V rows follow the K rows through the ring only after the scores: touched now for the same reason
+#pragma unroll
+      for (int t = 0; t < NTILE; t++) {
+#pragma unroll
+        for (int i = 0; i < SL; i++) {
+          const int key = min(t * KT + rg + 32 * i, C - 1);
+          const float4 v4 = *reinterpret_cast<const float4*>(Vh + (key * a.ldkv + c4));
+          asm volatile("" : : "v"(v4.x), "v"(v4.w));
+        }
+      }
+#endif
       if (!ps_wait(ps)) return false;
       dead = ld_i<true>(ps.dead + r);
       if (r >= n_live || dead) return true;
@@ -1066,18 +1096,30 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
   {
     const float4 q4 = *reinterpret_cast<const float4*>(&qv[c4]);
 #pragma unroll
-    for (int t = 0; t < NTILE; t++)
+    for (int p = 0; p < NP; p++) {
+      // what refills a register once its score is done: the next pass's K row, after the last pass the V row of pass 0
+      const float* nxt = p + 1 < NP ? Kh + (p + 1) * PASS_C * a.ldkv : Vh;
+      int rgp = rg;
+      if constexpr (NP > 1) WB_LAUNDER_V(rgp);       // (a pass's row offsets are computed in that pass, not hoisted and spilled)
 #pragma unroll
-      for (int i = 0; i < SL; i++) {
-        const int key = t * KT + rg + 32 * i;
-        float s = q4.x * kv[t][i].x + q4.y * kv[t][i].y + q4.z * kv[t][i].z + q4.w * kv[t][i].w;
-        s += dpp_f<DPP_QUAD_XOR1, 0xF>(0.f, s);
-        s += dpp_f<DPP_QUAD_XOR2, 0xF>(0.f, s);
-        s += dpp_f<DPP_ROW_HALF_MIRROR, 0xF>(0.f, s);
-        s += dpp_f<DPP_ROW_MIRROR, 0xF>(0.f, s);
-        if ((tid & 15) == 0 && key < C) sc[key] = s;
-        kv[t][i] = *reinterpret_cast<const float4*>(Vh + (min(key, C - 1) * a.ldkv + c4));
+      for (int t = 0; t < NTILE; t++) {
+        // (two passes: the scheduler must not lift a tile's refills above the previous tile's scores -- the ring is the
+        // register file)
+        if constexpr (NP > 1) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < SL; i++) {
+          const int k0 = t * KT + rgp + 32 * i, key = p * PASS_C + k0;
+          float s = q4.x * kv[t][i].x + q4.y * kv[t][i].y + q4.z * kv[t][i].z + q4.w * kv[t][i].w;
+          s += dpp_f<DPP_QUAD_XOR1, 0xF>(0.f, s);
+          s += dpp_f<DPP_QUAD_XOR2, 0xF>(0.f, s);
+          s += dpp_f<DPP_ROW_HALF_MIRROR, 0xF>(0.f, s);
+          s += dpp_f<DPP_ROW_MIRROR, 0xF>(0.f, s);
+          if ((tid & 15) == 0 && key < C) sc[key] = s;
+          const int lim = p + 1 < NP ? max(C - 1 - (p + 1) * PASS_C, -(p + 1) * PASS_C) : C - 1;   // (clamped rows are never consumed)
+          kv[t][i] = *reinterpret_cast<const float4*>(nxt + (min(k0, lim) * a.ldkv + c4));
+        }
       }
+    }
   }
   __syncthreads();
   if constexpr (PS) ps_stamp(ps, 4);
@@ -1094,13 +1136,24 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
   {
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int t = 0; t < NTILE; t++)
+    for (int p = 0; p < NP; p++) {
+      int rgp = rg;
+      if constexpr (NP > 1) WB_LAUNDER_V(rgp);
 #pragma unroll
-      for (int i = 0; i < SL; i++) {
-        const int key = t * KT + rg + 32 * i;
-        const float pk = key < C ? pbuf[key] : 0.f;
-        o.x += pk * kv[t][i].x; o.y += pk * kv[t][i].y; o.z += pk * kv[t][i].z; o.w += pk * kv[t][i].w;
+      for (int t = 0; t < NTILE; t++) {
+        // (two passes: a tile's refills stay behind the sums that consume its registers -- the sums have no side effect,
+        // so without the pin every refill of the pass is requested first and the ring doubles)
+        if constexpr (NP > 1) WB_PIN_F4(o);
+#pragma unroll
+        for (int i = 0; i < SL; i++) {
+          const int k0 = t * KT + rgp + 32 * i, key = p * PASS_C + k0;
+          const float pk = key < C ? pbuf[key] : 0.f;
+          o.x += pk * kv[t][i].x; o.y += pk * kv[t][i].y; o.z += pk * kv[t][i].z; o.w += pk * kv[t][i].w;
+          if (p + 1 < NP)                           // the register takes the V row of the next pass's key
+            kv[t][i] = *reinterpret_cast<const float4*>(Vh + (min(key + PASS_C, C - 1) * a.ldkv + c4));
+        }
       }
+    }
     *reinterpret_cast<float4*>(&part[rg][c4]) = o;
   }
   __syncthreads();

@@ -317,7 +317,7 @@ __device__ __forceinline__ bool ps_merge_role(const PersistArgs& a, const int r,
 }
 
 // ---- the grid ---------------------------------------------------------------------------------------------------------
-template <int DPL, int MR>
+template <int DPL, int MR, int NP>
 __global__ __launch_bounds__(PS_NT) void dec_persist_kernel(PersistArgs a) {
   __shared__ int wait_flag;
   const int NL = a.n_layer, S = a.S, R = a.n_rows, H = a.n_head, NB = a.nb_mlp;
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(PS_NT) void dec_persist_kernel(PersistArgs a) {
         else { ps.ctr_index = C_MLP + role.layer - 1; ps.target = (unsigned)(e + 1) * NB; }
         ps.ctr = cptr(ps.ctr_index);
         ps.tag_out = tag_l + 1u; ps.tag_in = tag_l;
-        ok = dec_cross_body<DPL, true>(la, role.a, role.b, ps);
+        ok = dec_cross_body<DPL, true, NP>(la, role.a, role.b, ps);
         out = C_CROSS + role.layer;
       } else if (role.kind == PSR_MLP) {
         const MlpFusedArgs la = a.layers[role.layer].mlp;
@@ -403,10 +403,10 @@ __global__ void ps_seed_kernel(const float* __restrict__ x, int n, void* gx, uns
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) st_gran(b, (uint32_t)i, tag, x[i]);
 }
 
-template <int DPL, int MR>
+template <int DPL, int MR, int NP>
 int max_blocks_per_cu() {
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (dec_persist_kernel<DPL, MR>), PS_NT, 0) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (dec_persist_kernel<DPL, MR, NP>), PS_NT, 0) != hipSuccess) return 0;
   return nb;
 }
 
@@ -414,22 +414,27 @@ int max_blocks_per_cu() {
 
 int ps_ctl_ints(int S, int n_layer) { return HX_HDR + (S + n_layer * S + 2 * n_layer + 8 + PS_NGO + 1) * HX_LINE; }
 
-// d = 512 with more than 4 rows would need > 160 KB of LDS (every role's LDS is resident at once)
-bool dec_persist_supported(int d, int n_rows) {
+// d = 512 with more than 4 rows would need > 160 KB of LDS (every role's LDS is resident at once); so would the two-pass
+// cross-attention role (768 < C <= 1536 keys: the opt-in 30 s window) next to the 8-row MLP role
+bool dec_persist_supported(int d, int n_rows, int max_keys) {
   if (n_rows < 1 || n_rows > 8) return false;
+  if (max_keys > CROSS_FUSED_MAX_PASSES * CROSS_FUSED_MAX_C) return false;
+  if (max_keys > CROSS_FUSED_MAX_C && n_rows > 4) return false;
   if (d == 128 || d == 384) return true;
   return d == 512 && n_rows <= 4;
 }
 
-int dec_persist_max_grid(int device, int d, int n_rows) {
-  if (!dec_persist_supported(d, n_rows)) return 0;
+int dec_persist_max_grid(int device, int d, int n_rows, int max_keys) {
+  if (!dec_persist_supported(d, n_rows, max_keys)) return 0;
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) return 0;
   int per = 0;
   const bool big = n_rows > 4;
-  if (d == 128) per = big ? max_blocks_per_cu<2, 8>() : max_blocks_per_cu<2, 4>();
-  else if (d == 384) per = big ? max_blocks_per_cu<6, 8>() : max_blocks_per_cu<6, 4>();
-  else per = max_blocks_per_cu<8, 4>();
+  if (max_keys > CROSS_FUSED_MAX_C)
+    per = d == 128 ? max_blocks_per_cu<2, 4, 2>() : d == 384 ? max_blocks_per_cu<6, 4, 2>() : max_blocks_per_cu<8, 4, 2>();
+  else if (d == 128) per = big ? max_blocks_per_cu<2, 8, 1>() : max_blocks_per_cu<2, 4, 1>();
+  else if (d == 384) per = big ? max_blocks_per_cu<6, 8, 1>() : max_blocks_per_cu<6, 4, 1>();
+  else per = max_blocks_per_cu<8, 4, 1>();
   if (per <= 0) return 0;
   // (one block per CU is what the roles are sized for; a second resident block per CU would only share its fill path)
   return cus * 1;
@@ -443,10 +448,14 @@ int launch_dec_persist(hipStream_t st, const PersistArgs& a, int grid) {
   const dim3 g(grid), b(PS_NT);
   const bool big = a.n_rows > 4;
   hipError_t e = hipErrorInvalidValue;
-#define WB_PS(DPL_, MR_) e = WB_LAUNCH_COOP((dec_persist_kernel<DPL_, MR_>), g, b, 0, st, a)
-  if (a.d == 128) { if (big) WB_PS(2, 8); else WB_PS(2, 4); }
-  else if (a.d == 384) { if (big) WB_PS(6, 8); else WB_PS(6, 4); }
-  else if (a.d == 512 && !big) WB_PS(8, 4);
+#define WB_PS(DPL_, MR_, NP_) e = WB_LAUNCH_COOP((dec_persist_kernel<DPL_, MR_, NP_>), g, b, 0, st, a)
+  if (a.n_pass > 1) {
+    if (big) return -1;
+    if (a.d == 128) WB_PS(2, 4, 2); else if (a.d == 384) WB_PS(6, 4, 2); else if (a.d == 512) WB_PS(8, 4, 2);
+  }
+  else if (a.d == 128) { if (big) WB_PS(2, 8, 1); else WB_PS(2, 4, 1); }
+  else if (a.d == 384) { if (big) WB_PS(6, 8, 1); else WB_PS(6, 4, 1); }
+  else if (a.d == 512 && !big) WB_PS(8, 4, 1);
 #undef WB_PS
   return e == hipSuccess ? 0 : -1;
 }

@@ -28,6 +28,10 @@ namespace wb {
   [&]() { void* _args[] = {(void*)&(arg)}; return hipLaunchCooperativeKernel((const void*)(kernel), grid, block, _args, shmem, stream); }()
 #endif
 
+// an ordering point for the compiler: the float4 is computed before it, no memory operation crosses it
+#ifndef WB_PIN_F4
+#define WB_PIN_F4(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w) : : "memory")
+#endif
 // A role of the persistent kernel runs inside the step / role loops: without this, every thread-index-derived address of
 // every role is loop-invariant, gets hoisted in front of the loops and lives (spilled) across all of them.
 #ifndef WB_LAUNDER_V

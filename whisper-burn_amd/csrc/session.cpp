@@ -543,7 +543,7 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
   // (head, beam): 10.6 us against 9.5 + 5.9 us (+ a kernel boundary) for chunked cross-attention + out-projection GEMV
   // once the block keeps its head's whole K in flight (decode_fused.hip); WHISPER_HIP_FUSE_X=0 restores the chunked pair
   static const bool fuse_x_enabled = []() { const char* e = getenv("WHISPER_HIP_FUSE_X"); return !(e && e[0] == '0'); }();
-  const bool fuse_x = fuse_x_enabled && fuse_sub && s->maxC <= CROSS_FUSED_MAX_C;
+  const bool fuse_x = fuse_x_enabled && fuse_sub && s->maxC <= CROSS_FUSED_MAX_PASSES * CROSS_FUSED_MAX_C;
   // ... or (older, opt-in) the chunked cross-attention blocks apply their head's rows of the out-projection
   // (opt-in: with 128-key chunks the MLP prologue has 6 H records per row to combine and loses what the launch saves)
   static const bool fuse_co_enabled = []() { const char* e = getenv("WHISPER_HIP_FUSE_CO"); return e && e[0] == '1'; }();
@@ -589,6 +589,7 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
       ca.Wq = b.cq.w; ca.bq = b.cq.b; ca.scale = m->qk_scale;
       ca.ckv = s->ckv.as<float>(); ca.ldkv = ldkv; ca.koff = l * 2 * d; ca.win_row0 = win_row0; ca.win_C = win_C;
       ca.Wo = b.cout.w; ca.P = s->Pc.as<float>();
+      ca.n_pass = s->maxC > CROSS_FUSED_MAX_C ? 2 : 1;
       prof_tag(KC_CROSS_FUSED, ckv_bytes + 4.0 * dd * 2);
       s->prof_cls_cross = KC_CROSS_FUSED;
       launch_dec_cross_fused(st, ca, n);
@@ -772,6 +773,7 @@ static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_
     ca.ckv = s->ckv.as<float>(); ca.ldkv = ldkv; ca.koff = l * 2 * d;
     ca.win_row0 = s->win_meta.as<int>(); ca.win_C = s->win_meta.as<int>() + W;
     ca.Wo = b.cout.w; ca.P = s->Pc.as<float>();
+    ca.n_pass = s->maxC > CROSS_FUSED_MAX_C ? 2 : 1;
     ca.g_x_in = gxb[xi]; ca.g_pend = s->ps_gpa.p; ca.g_x_out = gxb[xi ^ 1]; ca.g_P = s->ps_gpc.p;
     xi ^= 1;
     MlpFusedArgs& ma = la[l].mlp;
@@ -850,6 +852,7 @@ static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_
   a.role_off = reinterpret_cast<const int*>(static_cast<char*>(s->ps_roles.p) + roles.size() * sizeof(PsRole));
   a.n_logits_roles = n_lg;
   a.n_layer = NL; a.n_rows = W; a.S = S; a.d = d; a.n_head = H; a.nb_mlp = NB;
+  a.n_pass = s->maxC > CROSS_FUSED_MAX_C ? 2 : 1;
   a.ctl = s->ps_ctl.as<int>(); a.step0 = s->step; a.n_steps = max_depth; a.mask_until_len = mask_until_len;
   a.g_xn = s->ps_gxn.p;
   a.x_fin = gxb[xi]; a.P2 = s->ps_gp2.p; a.b2_last = m->dec[NL - 1].mlp2.b; a.tag_base = tag_base;
@@ -949,9 +952,9 @@ int session_greedy_chain(wb_session* s, int first_token, int eot, int max_depth,
   }();
   bool persist = persist_enabled && fused_enabled && fuse_ln && max_depth > 0 && m->compute_dtype != WB_BF16 &&
                  dec_fused_supported(m->dims.n_text_state) && m->dims.n_text_state == 64 * m->dims.n_text_head &&
-                 s->maxC <= CROSS_FUSED_MAX_C && dec_persist_supported(m->dims.n_text_state, W);
+                 dec_persist_supported(m->dims.n_text_state, W, s->maxC);
   if (persist) {
-    if (s->ps_grid < 0) s->ps_grid = dec_persist_max_grid(m->device, m->dims.n_text_state, W);
+    if (s->ps_grid < 0) s->ps_grid = dec_persist_max_grid(m->device, m->dims.n_text_state, W, s->maxC);
     persist = s->ps_grid > 0;
   }
   ScopedTimer tm(st, 3);

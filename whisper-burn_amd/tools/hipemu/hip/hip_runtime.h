@@ -51,6 +51,7 @@ template <class T> static inline T hipemu_atomic_load(const T* p) { T v; __atomi
 // hooks of the engine's cross-block hand-off helpers (csrc/wave_ops.h defines the gfx950 forms unless these exist)
 #define WB_DRAIN_VMEM() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define WB_LAUNDER_V(x) ((void)0)
+#define WB_PIN_F4(v) ((void)0)
 #define WB_LAUNCH_COOP(kernel, grid, block, shmem, stream, arg) \
   (hipemu::launch_coop(kernel, dim3(grid), dim3(block), (size_t)(shmem), stream, arg), hipSuccess)
 
