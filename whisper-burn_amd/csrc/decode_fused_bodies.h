@@ -31,7 +31,15 @@ struct PsStep {
 };
 constexpr int PS_STAMPS = 8;     // 0 role start, 1 wait passed, 2-5 phases inside the role, 6 done, 7 arrived
 __device__ __forceinline__ void ps_stamp(const PsStep& ps, int k) {
+#ifdef WB_EXP_FINE
+  if (k == 4 || k == 5) return;                    // (developer build: slots 4 and 5 resolve the first phase instead)
+#endif
   if (ps.stamp && threadIdx.x == 0) ps.stamp[k] = wall_clock64();
+}
+__device__ __forceinline__ void ps_stamp_fine(const PsStep& ps, int k) {
+#ifdef WB_EXP_FINE
+  if (ps.stamp && threadIdx.x == 0) ps.stamp[k] = wall_clock64();
+#endif
 }
 // wait for the role's producers (all threads of the block); false: the decode was stopped -- leave the kernel
 __device__ __forceinline__ bool ps_wait(const PsStep& ps) {
@@ -629,17 +637,6 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
       // every tag is the producers' (arrival and payload in one round trip)
       load_weights();
       load_cache_tile();
-#ifdef WB_EXP_L2WARM
-      // the weight rounds that stream through the two register sets later: touched now, while the block would only wait,
-      // so that they come from this XCD's L2 (the logits tiles of the previous step have swept it)
-#pragma unroll 1
-      for (int it = 2; it < NIT; it++) {
-        float4 t[RK];
-        load_round(t, it);
-#pragma unroll
-        for (int j = 0; j < RK; j++) asm volatile("" : : "v"(t[j].x), "v"(t[j].w));
-      }
-#endif
       if (!ps_wait(ps)) return false;
       dead = ld_i<true>(ps.dead + r);
       if (r >= n_rows || dead) return true;
@@ -714,6 +711,7 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
   if constexpr (PS) { if (!ps_sweeps_ok(ps)) return false; }
   if (wave == 0) ln_row_lds<DPL>(hs, d, lane, gv, bv, a.ln_eps, a.ln_inside);
   __syncthreads();
+  if constexpr (PS) ps_stamp_fine(ps, 4);
   WB_STAMP(2);
   // ---- QKV for head h (rolled on purpose: unrolled, every round's loads are hoisted to the top and spill)
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -756,6 +754,7 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
     qkv[tid] = v;
   }
   __syncthreads();
+  if constexpr (PS) ps_stamp_fine(ps, 5);
   WB_STAMP(4);
   // ---- scores: 4-term partial dots summed over the 16 lanes of a position's row (DPP); tail tiles (sequences longer
   // than 128 cached positions) reload through the LDS copy of the table
@@ -983,18 +982,6 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
       // arrive as tagged granules
       load_weights();
       load_keys();
-#ifdef WB_EXP_L2WARM
-      // the V rows follow the K rows through the ring only after the scores: touched now for the same reason
-#pragma unroll
-      for (int t = 0; t < NTILE; t++) {
-#pragma unroll
-        for (int i = 0; i < SL; i++) {
-          const int key = min(t * KT + rg + 32 * i, C - 1);
-          const float4 v4 = *reinterpret_cast<const float4*>(Vh + (key * a.ldkv + c4));
-          asm volatile("" : : "v"(v4.x), "v"(v4.w));
-        }
-      }
-#endif
       if (!ps_wait(ps)) return false;
       dead = ld_i<true>(ps.dead + r);
       if (r >= n_live || dead) return true;
@@ -1060,6 +1047,7 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
   if constexpr (PS) { if (!ps_sweeps_ok(ps)) return false; }
   if (wave == 0) ln_row_lds<DPL>(hs, d, lane, gv, bv, a.ln_eps, a.ln_inside);
   __syncthreads();
+  if constexpr (PS) ps_stamp_fine(ps, 4);
   // ---- q = (cross_attn_ln(x) Wq + bq) * s for head h  (mod.rs:483, :506-509)
   {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1073,6 +1061,7 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
     if (lane < 16) *reinterpret_cast<float4*>(&red[wave][c4]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
   }
   __syncthreads();   // (also keeps the loads below behind the Wq registers' last use)
+  if constexpr (PS) ps_stamp_fine(ps, 5);
   // ---- requested now: the Wo slice (consumed last)
   const int cf = tid % CF, jg = tid / CF;
   const bool p5 = jg < G;
