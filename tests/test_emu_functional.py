@@ -69,6 +69,17 @@ def test_persistent_flag_chained_decode_under_the_functional_model(emu_lib, whic
     assert p.returncode == 0 and f"EMU_CHECK_OK {which}" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
+@pytest.mark.parametrize("which,env", [("beam_batch", {}), ("beam_batch", {"WHISPER_HIP_BATCH_SKINNY": "0"}),
+                                       ("chain_eot_batch", {"WHISPER_HIP_CROSS_STREAM_FUSE": "0"})])
+def test_batch_mode_skinny_gemm_and_fused_streaming_blocks(emu_lib, which, env):
+    """decode_batch.hip under the functional model: the skinny split-K GEMM on v_mfma_f32_16x16x4_f32 with 21 live rows
+    (two row tiles; 7 windows x 3 beams, chunked cross-attention) against the tiled GEMM it replaces, and the streaming
+    cross-attention blocks with and without their fused front (fold + cross_attn_ln + Wq; the default at this width is
+    fused: test_chained_greedy_windows_ending_at_different_steps runs it).  Token-exact against the oracle."""
+    p = _run(emu_lib, which, env)
+    assert p.returncode == 0 and f"EMU_CHECK_OK {which}" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
 @pytest.mark.parametrize("env", [{}, {"WHISPER_HIP_PERSIST": "0"}])
 def test_two_pass_key_ring_of_the_fused_cross_attention(emu_lib, env):
     """A window with more keys than one pass of the fused cross-attention block holds (the opt-in doubled window: C = 1500

@@ -129,10 +129,15 @@ def test_batch_mode_cross_attention_variants_agree_with_the_oracle():
     import whisper_burn_amd as wb
     code = BATCH_CHILD % {"root": ROOT, "pkg": os.path.join(ROOT, "whisper-burn_amd"), "tests": os.path.join(ROOT, "tests")}
     res = {}
-    for v in ("1", "0"):
+    # streaming cross-attention blocks that fold / normalise / project their own query (the default at this width), the
+    # same blocks behind separate fold + Wq launches, the chunked kernel + combine; and the tiled MFMA GEMM in place of the
+    # skinny weight-stream GEMM (decode_batch.hip)
+    variants = {"1": {"WHISPER_HIP_CROSS_STREAM": "1"}, "0": {"WHISPER_HIP_CROSS_STREAM": "0"},
+                "unfused": {"WHISPER_HIP_CROSS_STREAM_FUSE": "0"}, "tiled": {"WHISPER_HIP_BATCH_SKINNY": "0"}}
+    for v, extra in variants.items():
         env = {k: val for k, val in os.environ.items()
                if not k.startswith("WHISPER_HIP_") or k in ("WHISPER_HIP_LIB", "WHISPER_HIP_ALLOW_EMU")}
-        env["WHISPER_HIP_CROSS_STREAM"] = v
+        env.update(extra)
         p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
         assert p.returncode == 0, p.stderr[-2000:]
         res[v] = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
@@ -141,7 +146,7 @@ def test_batch_mode_cross_attention_variants_agree_with_the_oracle():
     st = wb.SpecialTokens.for_vocab(1031)
     ref, rw = otr.waveform_to_tokens(o, pu.ost(st), synth.synth_audio(16000 * 140, 21), 16000, 1, 10, return_windows=True)
     assert len(rw) == 12
-    for v in ("1", "0"):
+    for v in variants:
         assert res[v]["wins"] == rw and res[v]["toks"] == ref, v
 
 

@@ -92,6 +92,18 @@ void launch_dec_cross_attn(hipStream_t st, const int* state, const StepLayout& l
                            const CaFuse* fuse = nullptr);
 // batch mode, one beam per window: one block per (head, window) streams the whole cached K/V and writes the normalised
 // head outputs to att [S][d] (no chunk partials, no combine launch)
+// the streaming kernel with the front of the sublayer inside (fold of the pending planes, cross_attn_ln, Wq): see decode.hip
+constexpr int CSF_MAX_D = 1280;
+struct CaStreamFuse {
+  const float* x_in = nullptr; float* x_out = nullptr;            // residual stream in / folded stream out (head 0's blocks)
+  const float* pend = nullptr; int KSp = 0; const float* pbias = nullptr;   // the self-attention out-projection's planes + bias
+  const float* ln_g = nullptr; const float* ln_b = nullptr; float ln_eps = 0.f; int ln_inside = 0;
+  const float* Wq = nullptr;                                      // [d][d]
+};
+bool cross_stream_can_fuse(int d);
+void launch_dec_cross_attn_stream_fused(hipStream_t st, const int* state, const StepLayout& lay, int n_windows, int n_head,
+                                        const float* bq, int d, const float* ckv, int ldkv, int koff, const int* win_row0,
+                                        const int* win_C, float scale, float* att, const CaStreamFuse& fz);
 void launch_dec_cross_attn_stream(hipStream_t st, const int* state, const StepLayout& lay, int n_windows, int n_head,
                                   const float* Pq, int KS, const float* bq, int d, const float* ckv, int ldkv, int koff,
                                   const int* win_row0, const int* win_C, float scale, float* att);
@@ -160,6 +172,17 @@ struct CrossFusedArgs {
   unsigned long long* stamps = nullptr;
   const void* g_x_in = nullptr; const void* g_pend = nullptr; void* g_x_out = nullptr; void* g_P = nullptr;   // persistent mode
 };
+// ---- batch mode: skinny split-K weight-stream GEMM (decode_batch.hip) ---------------------------------------------
+struct SkinnyArgs {
+  const float* A = nullptr; int lda = 0;          // activations [M][K]
+  const float* B = nullptr; int ldb = 0;          // weight [K][N] row-major (Linear: [d_in, d_out])
+  int M = 0, N = 0, K = 0, ksplit = 1;            // M <= 64, N % 64 == 0, K % (32 ksplit) == 0
+  float* P = nullptr; int plane = 0;              // split-K planes out: P[z * plane + r * N + n]  (plane in elements)
+};
+int skinny_ksplit(int K, int N, int max_ks);      // 0: shape not served
+bool skinny_supported(int M, int K, int N);
+int launch_dec_skinny_gemm(hipStream_t st, const SkinnyArgs& a);
+
 // ---- persistent flag-chained greedy decode (decode_persist.hip) --------------------------------------------------
 // ONE co-resident grid runs every sublayer of every step of the device-chained greedy loop: a block executes the
 // roles i = blockIdx.x, + gridDim.x, ... of a per-step role list in dependency order (self-attention block (head, row),

@@ -939,14 +939,24 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const int* __restri
 // once after the loop (v_permlane16/32_swap).  Three register sets rotate so that the next chunk's K and V are in
 // flight while the current one is consumed; the normalised head output goes straight to `att` (mod.rs:518-532) and
 // the chunk-combine launch disappears.
+//
+// FUSE: the block also does what precedes the attention in the sublayer (mod.rs:345-350, :482-483) for ITS row: fold the
+// self-attention out-projection's planes into the residual stream (head 0's block writes the folded row), cross_attn_ln,
+// and the query projection of its head -- q = ln(x) . Wq[:, 64 h .. 64 h + 63] + bq, the 16 row groups of the block
+// taking every 16th K-row of the head's weight slice (327 KB at d = 1280: L2 traffic, the slice is shared by every
+// window's block of the head) and meeting in LDS in a fixed order.  The cached K/V of the first chunk are requested
+// before any of it.  Two launches (dec_resolve_ln, the Wq GEMM) and their kernel boundaries disappear.
+template <bool FUSE>
 __global__ __launch_bounds__(256) void dec_cross_attn_stream_kernel(const int* __restrict__ st, StepLayout lay,
                                                                     const float* __restrict__ Pq, int KS,
                                                                     const float* __restrict__ bq, int d,
                                                                     const float* __restrict__ ckv, int ldkv, int koff,
                                                                     const int* __restrict__ win_row0,
                                                                     const int* __restrict__ win_C, float scale,
-                                                                    float* __restrict__ att) {
+                                                                    float* __restrict__ att, CaStreamFuse fz) {
   __shared__ float red[4][66];                       // per wave: m, l, o[64]
+  __shared__ __attribute__((aligned(16))) float hs[FUSE ? CSF_MAX_D : 1];
+  __shared__ __attribute__((aligned(16))) float qred[FUSE ? 16 * 64 : 1];
   const int h = blockIdx.x, w = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nb = st[lay.win_nb + w];
   if (nb == 0 || st[ST_N] == 0) return;
@@ -974,10 +984,86 @@ __global__ __launch_bounds__(256) void dec_cross_attn_stream_kernel(const int* _
   load_v(s1, 0);
   // q = (x Wq + bq) * s  (mod.rs:483, :506-509): this lane's four head dims
   float q[4];
+  if constexpr (FUSE) {
+    // ---- x + (bias + out-projection planes), s ascending (mod.rs:346-348); LayerNorm (two passes, biased variance)
+    constexpr int VPT = CSF_MAX_D / 256;
+    float v[VPT];
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; i++) {
+      const int c = tid + i * 256;
+      v[i] = 0.f;
+      if (c < d) {
+        const float a = fz.x_in[(int64_t)slot * d + c] +
+                        fold_partials(fz.pend, fz.KSp, (int64_t)lay.S * d, (int64_t)slot * d + c, fz.pbias[c]);
+        if (h == 0) fz.x_out[(int64_t)slot * d + c] = a;
+        v[i] = a;
+        sm += a;
+      }
+    }
+    sm = wave_sum(sm);
+    if (lane == 0) red[0][wave] = sm;
+    __syncthreads();
+    const float mean = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)d;
+    float qq = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; i++) {
+      const int c = tid + i * 256;
+      if (c < d) { const float t = v[i] - mean; qq += t * t; }
+    }
+    qq = wave_sum(qq);
+    if (lane == 0) red[1][wave] = qq;
+    __syncthreads();
+    const float var = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / (float)d;
+    const float denom = fz.ln_inside ? sqrtf(var + fz.ln_eps) : (sqrtf(var) + fz.ln_eps);
+#pragma unroll
+    for (int i = 0; i < VPT; i++) {
+      const int c = tid + i * 256;
+      if (c < d) hs[c] = (v[i] - mean) / denom * fz.ln_g[c] + fz.ln_b[c];
+    }
+    __syncthreads();
+    // ---- q: row group g16 = tid / 16 takes K-rows g16, g16 + 16, ...; eight rows per round, two rounds in flight
+    const int g16 = tid >> 4;
+    const float* wp = fz.Wq + (int64_t)g16 * d + h * 64 + c16 * 4;
+    const int nk = d >> 4;                            // K-rows per group (host: d % 128 == 0)
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 wa[8], wb[8];
+    auto load_w = [&](float4 (&wr)[8], int i0) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) wr[j] = *reinterpret_cast<const float4*>(wp + (int64_t)(16 * (i0 + j)) * d);
+    };
+    auto fma_w = [&](const float4 (&wr)[8], int i0) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const float xv = hs[g16 + 16 * (i0 + j)];
+        acc[0] += xv * wr[j].x; acc[1] += xv * wr[j].y; acc[2] += xv * wr[j].z; acc[3] += xv * wr[j].w;
+      }
+    };
+    load_w(wa, 0);
+#pragma unroll 1
+    for (int i0 = 0; i0 < nk; i0 += 16) {
+      if (i0 + 8 < nk) load_w(wb, i0 + 8);
+      fma_w(wa, i0);
+      if (i0 + 16 < nk) load_w(wa, i0 + 16);
+      if (i0 + 8 < nk) fma_w(wb, i0 + 8);
+    }
+    *reinterpret_cast<float4*>(&qred[g16 * 64 + c16 * 4]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const int col = c16 * 4 + t;
+      float sq = bq[h * 64 + col];
+#pragma unroll
+      for (int g = 0; g < 16; g++) sq += qred[g * 64 + col];            // group order fixed
+      q[t] = sq * scale;
+    }
+    __syncthreads();                                  // (red is reused by the merge below)
+  } else {
 #pragma unroll
   for (int t = 0; t < 4; t++) {
     const int col = h * 64 + c16 * 4 + t;
     q[t] = fold_partials(Pq, KS, (int64_t)lay.S * d, (int64_t)slot * d + col, bq[col]) * scale;
+  }
   }
   float m = -INFINITY, l = 0.f, o[4] = {0.f, 0.f, 0.f, 0.f};
   auto step = [&](float4 (&kr)[8], float4 (&vr)[8], float4 (&fr)[8], int c) {
@@ -1247,8 +1333,17 @@ void launch_dec_cross_attn(hipStream_t st, const int* state, const StepLayout& l
 void launch_dec_cross_attn_stream(hipStream_t st, const int* state, const StepLayout& lay, int n_windows, int n_head,
                                   const float* Pq, int KS, const float* bq, int d, const float* ckv, int ldkv, int koff,
                                   const int* win_row0, const int* win_C, float scale, float* att) {
-  WB_KLAUNCH(dec_cross_attn_stream_kernel, dim3(n_head, n_windows), dim3(256), 0, st, state, lay, Pq, KS, bq, d, ckv,
-             ldkv, koff, win_row0, win_C, scale, att);
+  WB_KLAUNCH(dec_cross_attn_stream_kernel<false>, dim3(n_head, n_windows), dim3(256), 0, st, state, lay, Pq, KS, bq, d, ckv,
+             ldkv, koff, win_row0, win_C, scale, att, CaStreamFuse());
+}
+
+bool cross_stream_can_fuse(int d) { return d % 128 == 0 && d <= CSF_MAX_D; }
+
+void launch_dec_cross_attn_stream_fused(hipStream_t st, const int* state, const StepLayout& lay, int n_windows, int n_head,
+                                        const float* bq, int d, const float* ckv, int ldkv, int koff, const int* win_row0,
+                                        const int* win_C, float scale, float* att, const CaStreamFuse& fz) {
+  WB_KLAUNCH(dec_cross_attn_stream_kernel<true>, dim3(n_head, n_windows), dim3(256), 0, st, state, lay, nullptr, 0, bq, d,
+             ckv, ldkv, koff, win_row0, win_C, scale, att, fz);
 }
 
 void launch_dec_topk_merge(hipStream_t st, int* state, int n_max, const float* tstats, int n_tiles, int k,

@@ -1,0 +1,172 @@
+// Batch-mode decode (9 - 64 live rows): the skinny split-K weight-stream GEMM.
+//
+// A decode step with n rows multiplies [n x K] activations by every decoder weight once: the weights (20 MB for
+// large-v2's QKV) are the traffic, the rows are few.  The encoder's 32 x 128 LDS-staged MFMA GEMM (gemm.hip) ran these
+// at 13.9 us per launch / 0.18 of HBM peak (profiles/r03_a_bench_large_v2_450s.json): a block of it walks its K slice
+// tile by tile behind barriers, so little of the matrix is in flight at any time.
+//
+// Here  (Linear: y = x W + b, W stored [d_in, d_out]; mod.rs:377-379, :429-435, :483-489)
+//   * a wave owns a 64-column strip of W over its own K range and requests ALL of its rows before the first use
+//     (one float4 per lane = 4 K-rows x 64 columns per load instruction; <= 12 instructions in flight per wave): the
+//     whole matrix is in flight one round trip after the launch;
+//   * arithmetic stays exact f32 on the matrix cores: v_mfma_f32_16x16x4_f32, rows in tiles of 16 (15 windows of
+//     large-v2 fill one tile; 32 x 32 tiles would idle half the array).  Component c of the lane's float4 is the B
+//     operand of accumulator c, i.e. accumulator c holds columns 4 j + c: no LDS staging for W, and a lane ends up
+//     with a float4 of consecutive output columns;
+//   * the 8 waves of a block share the strip and split the block's K slice; their partial tiles meet in LDS (fixed
+//     wave order) and one split-K plane per block goes out -- the same planes the tiled GEMM wrote, folded by the same
+//     consumers in the same order;
+// 11.1 us per launch (0.20 of HBM peak) on large-v2, 450 s: 422x -> 462x; small, 10 min: 2330x -> 2481x (profiles/r03_i_*).
+//
+// Rejected, both measured on large-v2 450 s (the fold launches stay: a kernel boundary is ~7.6 us here, and every way
+// tried of moving a fold across it cost more):
+//   * "last arriver" epilogues -- the block that takes the last ticket of its strip sums the strip's planes (+ GELU), the
+//     block that takes the last ticket of the launch normalises the rows (Guideline 16 R1 hand-offs: write-through stores,
+//     drained waves, one agent-scope atomic).  Removes 4 of 12 launches per layer and still loses: every level costs three
+//     dependent fabric round trips under full load (drain, ticket, plane re-read) -- 22 us for GEMM + GELU fold, 40 us
+//     for GEMM + resolve + LayerNorm, against 11 + 4.3 and 11 + 6.7 (+ a boundary each): 374x (profiles/r03_h_*, r03_i_*);
+//   * a GELU prologue in the MLP's second product (A = GELU(b1 + the first product's planes) formed while the block
+//     stages its K slice): the planes are four times the activations and arrive in front of the weights -- that launch
+//     became 16 us slower to save 4.3 us + a boundary: 441x (profiles/r03_j_*).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "decode.h"
+#include "handoff.h"
+#include "kernels.h"
+#include "wave_ops.h"
+
+namespace wb {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SK_NT = 512;          // 8 waves: one 64-column strip, the block's K slice in 8 parts
+constexpr int SK_MAX_LD = 12;       // float4 loads a wave keeps in flight (48 K-rows)
+
+template <int MT>
+__global__ __launch_bounds__(SK_NT, MT <= 2 ? 2 : 1) void dec_skinny_gemm_kernel(SkinnyArgs a) {
+  // one region, two lives: the activations of the block's K slice, k-major in row tiles of 16 (As[mt][k][16]: the A
+  // operand of lane l for K-rows k0 .. k0 + 3 is word 16 k0 + l -- conflict-free), then the 8 waves' partial tiles
+  // (K-rows per block <= 32 SK_MAX_LD = 384: 6144 words per row tile; the partial tiles need 8 x 16 x 64 = 8192)
+  __shared__ __attribute__((aligned(16))) float smem[MT * 8192];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int strip = blockIdx.x, z = blockIdx.y;
+  const int kchunk = a.K / a.ksplit;                 // host: K % (32 ksplit) == 0
+  const int kw = kchunk >> 3;                        // K-rows per wave (multiple of 4)
+  const int kb = z * kchunk;
+  const int n0 = strip * 64;
+  const int krow = lane >> 4, cq = lane & 15;
+
+  // ---- requested first (loads return in order): the activations of the K slice (rows past M are zeros) ...
+  constexpr int AQ = (MT * 16 * (32 * SK_MAX_LD / 4) + SK_NT - 1) / SK_NT;    // float4 quads per thread, at most (3 MT)
+  const int nq = kchunk >> 2;                        // float4 quads per row
+  float4 av4[AQ];
+#pragma unroll
+  for (int i = 0; i < AQ; i++) {
+    const int idx = tid + i * SK_NT, r = idx % (MT * 16), kq = idx / (MT * 16);
+    av4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kq < nq && r < a.M) av4[i] = *reinterpret_cast<const float4*>(a.A + (int64_t)r * a.lda + kb + 4 * kq);
+  }
+  // ---- ... then the wave's weights: every row requested now
+  const int nld = kw >> 2;
+  float4 bw[SK_MAX_LD];
+  {
+    const float* bp = a.B + (int64_t)(kb + wave * kw + krow) * a.ldb + n0 + 4 * cq;
+#pragma unroll
+    for (int t = 0; t < SK_MAX_LD; t++)
+      if (t < nld) bw[t] = *reinterpret_cast<const float4*>(bp + (int64_t)(4 * t) * a.ldb);
+  }
+#pragma unroll
+  for (int i = 0; i < AQ; i++) {
+    const int idx = tid + i * SK_NT, r = idx % (MT * 16), kq = idx / (MT * 16);
+    if (kq < nq) {
+      float* dst = smem + ((r >> 4) * kchunk + 4 * kq) * 16 + (r & 15);
+      dst[0] = av4[i].x; dst[16] = av4[i].y; dst[32] = av4[i].z; dst[48] = av4[i].w;
+    }
+  }
+  __syncthreads();
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+    for (int c = 0; c < 4; c++) acc[mt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    const float* ap = smem + (wave * kw) * 16 + lane;
+#pragma unroll
+    for (int t = 0; t < SK_MAX_LD; t++) {
+      if (t < nld) {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+          const float av = ap[(mt * kchunk + 4 * t) * 16];
+          acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[t].x, acc[mt][0], 0, 0, 0);
+          acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[t].y, acc[mt][1], 0, 0, 0);
+          acc[mt][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[t].z, acc[mt][2], 0, 0, 0);
+          acc[mt][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[t].w, acc[mt][3], 0, 0, 0);
+        }
+      }
+    }
+  }
+  __syncthreads();                                   // the activations are consumed: the region takes the partial tiles
+  // red[wave][mt][i][j] as float4 (columns 4 j .. 4 j + 3): register v of lane l is row 4 (l / 16) + v, column j = l % 16
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const int i = 4 * krow + v;
+      *reinterpret_cast<float4*>(smem + (((wave * MT + mt) * 16 + i) * 16 + cq) * 4) =
+          make_float4(acc[mt][0][v], acc[mt][1][v], acc[mt][2][v], acc[mt][3][v]);
+    }
+  __syncthreads();
+  // ---- the block's plane: thread (row, column quad) sums the waves in order
+  const bool owner = tid < MT * 256;
+  const int row = tid >> 4, j4 = tid & 15;           // (owner threads: row < 16 MT)
+  const uint32_t poff = (uint32_t)((int64_t)row * a.N + n0 + 4 * j4);      // element offset inside a plane
+  if (owner && row < a.M) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+      const float4 t = *reinterpret_cast<const float4*>(smem + ((w * MT * 16 + row) * 16 + j4) * 4);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    *reinterpret_cast<float4*>(a.P + (int64_t)z * a.plane + poff) = s;
+  }
+}
+
+}  // namespace
+
+// K-splits of the skinny GEMM: slices a block's 8 waves can share in multiples of 4 rows (K % (32 ks) == 0), at most
+// SK_MAX_LD float4 rows in flight per wave, and enough blocks for the chip (~ one per CU, two where that needs no more
+// than KS_MAX planes); 0: the shape is not served (the caller keeps the tiled GEMM)
+int skinny_ksplit(int K, int N, int max_ks) {
+  if (N % 64 != 0 || K % 32 != 0) return 0;
+  const int strips = N / 64;
+  int best = 0;
+  for (int ks = 1; ks <= std::min(KS_MAX, max_ks); ks++) {
+    if (K % (32 * ks) != 0) continue;
+    const int kw = K / ks / 8;
+    if (kw / 4 > SK_MAX_LD) continue;
+    best = ks;
+    if (strips * ks >= 240) break;
+  }
+  return best;
+}
+
+bool skinny_supported(int M, int K, int N) { return M >= 1 && M <= 64 && skinny_ksplit(K, N, KS_MAX) > 0; }
+
+int launch_dec_skinny_gemm(hipStream_t st, const SkinnyArgs& a) {
+  if (a.ksplit < 1 || a.ksplit > KS_MAX || a.K % (32 * a.ksplit) != 0 || a.N % 64 != 0 || a.M < 1 || a.M > 64) return -1;
+  if (a.K / a.ksplit / 32 > SK_MAX_LD) return -1;
+  const int MT = (a.M + 15) / 16;
+  const dim3 grid(a.N / 64, a.ksplit), block(SK_NT);
+  switch (MT) {
+    case 1: WB_KLAUNCH((dec_skinny_gemm_kernel<1>), grid, block, 0, st, a); break;
+    case 2: WB_KLAUNCH((dec_skinny_gemm_kernel<2>), grid, block, 0, st, a); break;
+    case 3: WB_KLAUNCH((dec_skinny_gemm_kernel<3>), grid, block, 0, st, a); break;
+    default: WB_KLAUNCH((dec_skinny_gemm_kernel<4>), grid, block, 0, st, a); break;
+  }
+  return 0;
+}
+
+}  // namespace wb

@@ -290,11 +290,16 @@ int session_reserve(wb_session* s, int max_len) {
   WB_TRY(s->h.ensure((size_t)S * d * 4));
   WB_TRY(s->att.ensure((size_t)S * d * 4));
   WB_TRY(s->hm.ensure((size_t)S * 4 * d * 4));
-  WB_TRY(s->Pqkv.ensure((size_t)s->ks_qkv * S * 3 * d * 4));
-  WB_TRY(s->Po.ensure(((size_t)s->ks_o * S + 8) * d * 4));
-  WB_TRY(s->Pq.ensure((size_t)s->ks_o * S * d * 4));
-  WB_TRY(s->P1.ensure((size_t)s->ks_1 * S * 4 * d * 4));
-  WB_TRY(s->P2.ensure(((size_t)std::max(s->ks_2, dec_mlp_fused_planes(d)) * S + 8) * d * 4));
+  // (batch mode's skinny GEMM, decode_batch.hip, splits K its own way: the plane buffers hold the larger count)
+  s->sk_qkv = skinny_ksplit(d, 3 * d, KS_MAX); s->sk_o = skinny_ksplit(d, d, KS_MAX);
+  s->sk_1 = skinny_ksplit(d, 4 * d, KS_MAX);
+  s->sk_2 = skinny_ksplit(4 * d, d, KS_MAX);
+  WB_TRY(s->Pqkv.ensure((size_t)std::max(s->ks_qkv, s->sk_qkv) * S * 3 * d * 4));
+  WB_TRY(s->Po.ensure(((size_t)std::max(s->ks_o, s->sk_o) * S + 8) * d * 4));
+  WB_TRY(s->Pq.ensure((size_t)std::max(s->ks_o, s->sk_o) * S * d * 4));
+  WB_TRY(s->P1.ensure((size_t)std::max(s->ks_1, s->sk_1) * S * 4 * d * 4));
+  WB_TRY(s->P2.ensure(((size_t)std::max(std::max(s->ks_2, s->sk_2), dec_mlp_fused_planes(d)) * S + 8) * d * 4));
+
   WB_TRY(s->Pa.ensure(((size_t)D.n_text_head * S + 8) * d * 4));
   WB_TRY(s->Pc.ensure(((size_t)D.n_text_head * S + 8) * d * 4));
   WB_TRY(s->carec.ensure(((size_t)D.n_text_head * std::max(1, s->n_chunks) * S + 8) * (d + 2) * 4));
@@ -471,44 +476,85 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
       launch_dec_resolve_ln(st, dst, n, xb[xi], xb[xi ^ 1], pend, ks_pend, S, pbias, d, ln, m->ln_eps_inside_sqrt, h);
       xi ^= 1;
     };
+    // the skinny weight-stream GEMM (decode_batch.hip) for up to 64 rows of exact-f32 models: every weight row in flight
+    // from the start.  WHISPER_HIP_BATCH_SKINNY=0 keeps the tiled GEMM.
+    static const bool skinny_enabled = []() { const char* e = getenv("WHISPER_HIP_BATCH_SKINNY"); return !(e && e[0] == '0'); }();
+    const bool skinny = skinny_enabled && m->compute_dtype != WB_BF16 && n <= 64 && s->sk_qkv > 0 && s->sk_o > 0 &&
+                        s->sk_1 > 0 && s->sk_2 > 0;
+    auto thin = [&](const LinearW& w, int ks, const float* A, float* P) -> int {
+      SkinnyArgs g;
+      g.A = A; g.lda = w.k; g.B = w.w; g.ldb = w.n; g.M = n; g.N = w.n; g.K = w.k; g.ksplit = ks;
+      g.P = P; g.plane = S * w.n;
+      prof_tag(KC_B_GEMM, wsz * (double)w.k * w.n + 4.0 * n * ((double)w.k + (double)ks * w.n));
+      WB_REQUIRE(launch_dec_skinny_gemm(st, g) == 0, WB_ERR_SHAPE, "skinny gemm: unsupported shape M=%d N=%d K=%d ks=%d", n,
+                 w.n, w.k, ks);
+      return WB_OK;
+    };
     const float* pend = nullptr; int ks_pend = 0; const float* pbias = nullptr;
     // one beam per window (greedy over many windows): one block per (head, window) streams the whole cached K/V and
     // writes the normalised head outputs -- no 128-key chunk partials, no combine launch (WHISPER_HIP_CROSS_STREAM=0:
     // the chunked kernel + combine)
     static const bool cross_stream_enabled = []() { const char* e = getenv("WHISPER_HIP_CROSS_STREAM"); return !(e && e[0] == '0'); }();
     const bool cross_stream = cross_stream_enabled && max_nb <= 1;
+    // ... and where the head's slice of Wq is small next to the window's cached K/V (d <= 768: `small` and below) those
+    // blocks fold the pending planes, normalise and project their own query first -- two launches less per layer.
+    // Measured both ways (profiles/r03_j_*): small, 10 min 2445x -> 2517x; large-v2 (327 KB of Wq per block, 220 VGPRs)
+    // 441x -> 433x, so d = 1024 / 1280 keep the launches.  WHISPER_HIP_CROSS_STREAM_FUSE=0 / 1 forces it off / on.
+    static const int stream_fuse_mode = []() { const char* e = getenv("WHISPER_HIP_CROSS_STREAM_FUSE"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    const bool stream_fused = cross_stream && m->compute_dtype != WB_BF16 && cross_stream_can_fuse(d) &&
+                              (stream_fuse_mode < 0 ? d <= 768 : stream_fuse_mode == 1);
+    const int kq = skinny ? s->sk_qkv : s->ks_qkv, ko = skinny ? s->sk_o : s->ks_o;
     for (int l = 0; l < NL; l++) {
       const DecBlockW& b = m->dec[l];
       resolve(pend, ks_pend, pbias, b.ln1);
-      WB_TRY(big(b.qkv, s->ks_qkv, h, s->Pqkv.as<float>()));
-      prof_tag(KC_B_SELF_ATTN, self_kv_bytes + 4.0 * n * 3 * d * s->ks_qkv);
+      if (skinny) WB_TRY(thin(b.qkv, kq, h, s->Pqkv.as<float>()));
+      else WB_TRY(big(b.qkv, kq, h, s->Pqkv.as<float>()));
+      prof_tag(KC_B_SELF_ATTN, self_kv_bytes + 4.0 * n * 3 * d * kq);
       s->prof_cls_self = KC_B_SELF_ATTN;
-      launch_dec_self_attn(st, dst, L, n, H, s->Pqkv.as<float>(), s->ks_qkv, b.qkv.b, d,
+      launch_dec_self_attn(st, dst, L, n, H, s->Pqkv.as<float>(), kq, b.qkv.b, d,
                            s->kc.as<float>() + (size_t)l * pool * d, s->vc.as<float>() + (size_t)l * pool * d, tabs,
                            s->Lmax, m->qk_scale, att);
-      WB_TRY(big(b.out, s->ks_o, att, s->Po.as<float>()));
-      resolve(s->Po.as<float>(), s->ks_o, b.out.b, b.ln2);
-      WB_TRY(big(b.cq, s->ks_o, h, s->Pq.as<float>()));
-      if (cross_stream) {
-        prof_tag(KC_B_CROSS_STREAM, ckv_bytes + 4.0 * n * d * (s->ks_o + 1));
+      if (skinny) WB_TRY(thin(b.out, ko, att, s->Po.as<float>()));
+      else WB_TRY(big(b.out, ko, att, s->Po.as<float>()));
+      if (stream_fused) {
+        // fold + cross_attn_ln + Wq inside the streaming blocks: two launches less per layer
+        CaStreamFuse fz;
+        fz.x_in = xb[xi]; fz.x_out = xb[xi ^ 1]; fz.pend = s->Po.as<float>(); fz.KSp = ko; fz.pbias = b.out.b;
+        fz.ln_g = b.ln2.g; fz.ln_b = b.ln2.b; fz.ln_eps = b.ln2.eps; fz.ln_inside = m->ln_eps_inside_sqrt; fz.Wq = b.cq.w;
+        prof_tag(KC_B_CROSS_STREAM, ckv_bytes + 4.0 * dd + 4.0 * n * d * (ko + 2));
         s->prof_cls_cross = KC_B_CROSS_STREAM;
-        launch_dec_cross_attn_stream(st, dst, L, s->W, H, s->Pq.as<float>(), s->ks_o, b.cq.b, d, s->ckv.as<float>(), ldkv,
+        launch_dec_cross_attn_stream_fused(st, dst, L, s->W, H, b.cq.b, d, s->ckv.as<float>(), ldkv, l * 2 * d, win_row0,
+                                           win_C, m->qk_scale, att, fz);
+        xi ^= 1;
+      } else {
+      resolve(s->Po.as<float>(), ko, b.out.b, b.ln2);
+      if (skinny) WB_TRY(thin(b.cq, ko, h, s->Pq.as<float>()));
+      else WB_TRY(big(b.cq, ko, h, s->Pq.as<float>()));
+      if (cross_stream) {
+        prof_tag(KC_B_CROSS_STREAM, ckv_bytes + 4.0 * n * d * (ko + 1));
+        s->prof_cls_cross = KC_B_CROSS_STREAM;
+        launch_dec_cross_attn_stream(st, dst, L, s->W, H, s->Pq.as<float>(), ko, b.cq.b, d, s->ckv.as<float>(), ldkv,
                                      l * 2 * d, win_row0, win_C, m->qk_scale, att);
       } else {
-        prof_tag(KC_B_CROSS_CHUNK, ckv_bytes + 4.0 * n * d * s->ks_o);
+        prof_tag(KC_B_CROSS_CHUNK, ckv_bytes + 4.0 * n * d * ko);
         s->prof_cls_cross = KC_B_CROSS_CHUNK;
-        launch_dec_cross_attn(st, dst, L, s->W, H, s->n_chunks, s->Pq.as<float>(), s->ks_o, b.cq.b, d, s->ckv.as<float>(),
+        launch_dec_cross_attn(st, dst, L, s->W, H, s->n_chunks, s->Pq.as<float>(), ko, b.cq.b, d, s->ckv.as<float>(),
                               ldkv, l * 2 * d, win_row0, win_C, m->qk_scale, s->ca.as<float>(), max_nb);
         prof_tag(KC_B_COMBINE, 4.0 * n * H * s->n_chunks * CA_STRIDE);
         launch_dec_attn_combine(st, dst, n, s->ca.as<float>(), H, s->n_chunks, att);
       }
-      WB_TRY(big(b.cout, s->ks_o, att, s->Po.as<float>()));
-      resolve(s->Po.as<float>(), s->ks_o, b.cout.b, b.ln3);
-      WB_TRY(big(b.mlp1, s->ks_1, h, s->P1.as<float>()));
-      prof_tag(KC_B_GELU_FOLD, 4.0 * n * 4 * d * (s->ks_1 + 1));
-      launch_dec_gelu_fold(st, dst, n, s->P1.as<float>(), s->ks_1, S, 4 * d, b.mlp1.b, hm);
-      WB_TRY(big(b.mlp2, s->ks_2, hm, s->P2.as<float>()));
-      pend = s->P2.as<float>(); ks_pend = s->ks_2; pbias = b.mlp2.b;
+      }
+      const int k1 = skinny ? s->sk_1 : s->ks_1, k2 = skinny ? s->sk_2 : s->ks_2;
+      if (skinny) WB_TRY(thin(b.cout, ko, att, s->Po.as<float>()));
+      else WB_TRY(big(b.cout, ko, att, s->Po.as<float>()));
+      resolve(s->Po.as<float>(), ko, b.cout.b, b.ln3);
+      if (skinny) WB_TRY(thin(b.mlp1, k1, h, s->P1.as<float>()));
+      else WB_TRY(big(b.mlp1, k1, h, s->P1.as<float>()));
+      prof_tag(KC_B_GELU_FOLD, 4.0 * n * 4 * d * (k1 + 1));
+      launch_dec_gelu_fold(st, dst, n, s->P1.as<float>(), k1, S, 4 * d, b.mlp1.b, hm);
+      if (skinny) WB_TRY(thin(b.mlp2, k2, hm, s->P2.as<float>()));
+      else WB_TRY(big(b.mlp2, k2, hm, s->P2.as<float>()));
+      pend = s->P2.as<float>(); ks_pend = k2; pbias = b.mlp2.b;
     }
     if (k > 0) {
       resolve(pend, ks_pend, pbias, m->ln_dec);

@@ -31,6 +31,7 @@ struct wb_session {
   int32_t* topk_id_host = nullptr;      // [S][TOPK_MAX]
   float* topk_lp_host = nullptr;
   wb::DevMem x, h, att, Pqkv, Po, Pq, P1, P2, Pa, Pc, carec, ca, logits, tstats, row_stats, mask, lp_tmp, gctl, gtok, hm;
+  int sk_qkv = 0, sk_o = 0, sk_1 = 0, sk_2 = 0;                             // its K-splits per weight shape (0: shape not served)
   wb::DevMem ps_layers, ps_roles, ps_ctl, ps_dead, ps_tstats, ps_stamps;   // persistent flag-chained decode (decode_persist.hip)
   wb::DevMem ps_gx, ps_gpa, ps_gpc, ps_gp2, ps_gxn;     // ... its residual streams / planes as 8-byte {tag, value} granules
   unsigned ps_launches = 0;                     // launches so far: the high half of the granule tags

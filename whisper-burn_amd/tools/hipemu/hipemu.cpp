@@ -257,6 +257,26 @@ static void run_collective(Fiber** lane, int n_lanes) {
         }
       }
     } break;
+    case OP_MFMA_F32_16X16X4: {
+      // v_mfma_f32_16x16x4_f32: A: lane l holds A[i = l % 16][k = l / 16]; B: B[k = l / 16][j = l % 16];
+      // D: register v of lane l is D[i = 4 (l / 16) + v][j = l % 16]
+      float A[16][4], B[4][16];
+      for (int l = 0; l < 64; l++) {
+        if (!active[l]) die("MFMA with inactive lanes");
+        A[l & 15][l >> 4] = *(const float*)lane[l]->in0;
+        B[l >> 4][l & 15] = *(const float*)lane[l]->in1;
+      }
+      for (int l = 0; l < 64; l++) {
+        const float* c = (const float*)lane[l]->in2; float* d = (float*)lane[l]->out;
+        const int j = l & 15;
+        for (int v = 0; v < 4; v++) {
+          const int i = 4 * (l >> 4) + v;
+          float acc = c[v];
+          for (int k = 0; k < 4; k++) acc = fmaf(A[i][k], B[k][j], acc);
+          d[v] = acc;
+        }
+      }
+    } break;
     default: die("unknown wave collective");
   }
   for (int l = 0; l < n_lanes && l < 64; l++) if (lane[l]->state == AT_WAVE) lane[l]->state = RUNNABLE;
