@@ -179,7 +179,7 @@ struct SkinnyArgs {
   int M = 0, N = 0, K = 0, ksplit = 1;            // M <= 64, N % 64 == 0, K % (32 ksplit) == 0
   float* P = nullptr; int plane = 0;              // split-K planes out: P[z * plane + r * N + n]  (plane in elements)
 };
-int skinny_ksplit(int K, int N, int max_ks);      // 0: shape not served
+int skinny_ksplit(int K, int N, int max_ks, int max_rows);   // 0: shape not served
 bool skinny_supported(int M, int K, int N);
 int launch_dec_skinny_gemm(hipStream_t st, const SkinnyArgs& a);
 

@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "decode.h"
 #include "handoff.h"
@@ -43,14 +44,16 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SK_NT = 512;          // 8 waves: one 64-column strip, the block's K slice in 8 parts
-constexpr int SK_MAX_LD = 12;       // float4 loads a wave keeps in flight (48 K-rows)
+constexpr int SK_MAX_LD = 20;       // float4 loads a wave keeps in flight (80 K-rows); 12 with more than two row tiles
 
 template <int MT>
 __global__ __launch_bounds__(SK_NT, MT <= 2 ? 2 : 1) void dec_skinny_gemm_kernel(SkinnyArgs a) {
   // one region, two lives: the activations of the block's K slice, k-major in row tiles of 16 (As[mt][k][16]: the A
   // operand of lane l for K-rows k0 .. k0 + 3 is word 16 k0 + l -- conflict-free), then the 8 waves' partial tiles
-  // (K-rows per block <= 32 SK_MAX_LD = 384: 6144 words per row tile; the partial tiles need 8 x 16 x 64 = 8192)
-  __shared__ __attribute__((aligned(16))) float smem[MT * 8192];
+  // (K-rows per block <= 32 x 20 = 640: 10240 words per row tile -- 32 x 12 = 384 rows with three or four row tiles;
+  // the partial tiles need 8 x 16 x 64 = 8192)
+  constexpr int LDW = MT <= 2 ? SK_MAX_LD : 12;
+  __shared__ __attribute__((aligned(16))) float smem[MT * (MT <= 2 ? 10240 : 8192)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int strip = blockIdx.x, z = blockIdx.y;
   const int kchunk = a.K / a.ksplit;                 // host: K % (32 ksplit) == 0
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(SK_NT, MT <= 2 ? 2 : 1) void dec_skinny_gemm_kernel
   const int krow = lane >> 4, cq = lane & 15;
 
   // ---- requested first (loads return in order): the activations of the K slice (rows past M are zeros) ...
-  constexpr int AQ = (MT * 16 * (32 * SK_MAX_LD / 4) + SK_NT - 1) / SK_NT;    // float4 quads per thread, at most (3 MT)
+  constexpr int AQ = (MT * 16 * (32 * LDW / 4) + SK_NT - 1) / SK_NT;    // float4 quads per thread, at most
   const int nq = kchunk >> 2;                        // float4 quads per row
   float4 av4[AQ];
 #pragma unroll
@@ -71,11 +74,11 @@ __global__ __launch_bounds__(SK_NT, MT <= 2 ? 2 : 1) void dec_skinny_gemm_kernel
   }
   // ---- ... then the wave's weights: every row requested now
   const int nld = kw >> 2;
-  float4 bw[SK_MAX_LD];
+  float4 bw[LDW];
   {
     const float* bp = a.B + (int64_t)(kb + wave * kw + krow) * a.ldb + n0 + 4 * cq;
 #pragma unroll
-    for (int t = 0; t < SK_MAX_LD; t++)
+    for (int t = 0; t < LDW; t++)
       if (t < nld) bw[t] = *reinterpret_cast<const float4*>(bp + (int64_t)(4 * t) * a.ldb);
   }
 #pragma unroll
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(SK_NT, MT <= 2 ? 2 : 1) void dec_skinny_gemm_kernel
   {
     const float* ap = smem + (wave * kw) * 16 + lane;
 #pragma unroll
-    for (int t = 0; t < SK_MAX_LD; t++) {
+    for (int t = 0; t < LDW; t++) {
       if (t < nld) {
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
@@ -137,27 +140,28 @@ __global__ __launch_bounds__(SK_NT, MT <= 2 ? 2 : 1) void dec_skinny_gemm_kernel
 }  // namespace
 
 // K-splits of the skinny GEMM: slices a block's 8 waves can share in multiples of 4 rows (K % (32 ks) == 0), at most
-// SK_MAX_LD float4 rows in flight per wave, and enough blocks for the chip (~ one per CU, two where that needs no more
-// than KS_MAX planes); 0: the shape is not served (the caller keeps the tiled GEMM)
-int skinny_ksplit(int K, int N, int max_ks) {
+// SK_MAX_LD float4 rows in flight per wave, and as many blocks as fit ONE round of the chip: with 320 blocks on 256 CUs the
+// MLP products took 19.5 us against 11.2 us for the QKV product's 240 blocks of the same size
+// (profiles/r03_l_layer_cycle_large_v2.txt).  0: the shape is not served (the caller keeps the tiled GEMM)
+int skinny_ksplit(int K, int N, int max_ks, int max_rows) {
   if (N % 64 != 0 || K % 32 != 0) return 0;
+  static const int max_blocks = []() { const char* e = getenv("WHISPER_HIP_SK_MAX_BLOCKS"); return e ? atoi(e) : 256; }();
   const int strips = N / 64;
   int best = 0;
   for (int ks = 1; ks <= std::min(KS_MAX, max_ks); ks++) {
     if (K % (32 * ks) != 0) continue;
-    const int kw = K / ks / 8;
-    if (kw / 4 > SK_MAX_LD) continue;
+    if (K / ks / 32 > (max_rows <= 32 ? SK_MAX_LD : 12)) continue;
+    if (best > 0 && strips * ks > max_blocks) break;
     best = ks;
-    if (strips * ks >= 240) break;
   }
   return best;
 }
 
-bool skinny_supported(int M, int K, int N) { return M >= 1 && M <= 64 && skinny_ksplit(K, N, KS_MAX) > 0; }
+bool skinny_supported(int M, int K, int N) { return M >= 1 && M <= 64 && skinny_ksplit(K, N, KS_MAX, M) > 0; }
 
 int launch_dec_skinny_gemm(hipStream_t st, const SkinnyArgs& a) {
   if (a.ksplit < 1 || a.ksplit > KS_MAX || a.K % (32 * a.ksplit) != 0 || a.N % 64 != 0 || a.M < 1 || a.M > 64) return -1;
-  if (a.K / a.ksplit / 32 > SK_MAX_LD) return -1;
+  if (a.K / a.ksplit / 32 > (a.M <= 32 ? SK_MAX_LD : 12)) return -1;
   const int MT = (a.M + 15) / 16;
   const dim3 grid(a.N / 64, a.ksplit), block(SK_NT);
   switch (MT) {

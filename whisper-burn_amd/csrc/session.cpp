@@ -291,9 +291,8 @@ int session_reserve(wb_session* s, int max_len) {
   WB_TRY(s->att.ensure((size_t)S * d * 4));
   WB_TRY(s->hm.ensure((size_t)S * 4 * d * 4));
   // (batch mode's skinny GEMM, decode_batch.hip, splits K its own way: the plane buffers hold the larger count)
-  s->sk_qkv = skinny_ksplit(d, 3 * d, KS_MAX); s->sk_o = skinny_ksplit(d, d, KS_MAX);
-  s->sk_1 = skinny_ksplit(d, 4 * d, KS_MAX);
-  s->sk_2 = skinny_ksplit(4 * d, d, KS_MAX);
+  s->sk_qkv = skinny_ksplit(d, 3 * d, KS_MAX, S); s->sk_o = skinny_ksplit(d, d, KS_MAX, S);
+  s->sk_1 = skinny_ksplit(d, 4 * d, KS_MAX, S); s->sk_2 = skinny_ksplit(4 * d, d, KS_MAX, S);
   WB_TRY(s->Pqkv.ensure((size_t)std::max(s->ks_qkv, s->sk_qkv) * S * 3 * d * 4));
   WB_TRY(s->Po.ensure(((size_t)std::max(s->ks_o, s->sk_o) * S + 8) * d * 4));
   WB_TRY(s->Pq.ensure((size_t)std::max(s->ks_o, s->sk_o) * S * d * 4));
