@@ -146,7 +146,7 @@ def main(which):
         assert np.abs(got - ref).max() < 1e-3, np.abs(got - ref).max()
     elif which == "geometry384":
         # the two-pass key ring of the fused cross-attention block (a window with more keys than one pass holds: 768 on
-        # the device, 256 in this build): d = 384, doubled windows of 2 x 400 frames (C = 400 keys) + a shorter tail window,
+        # the device, 384 in this build): d = 384, doubled windows of 2 x 400 frames (C = 400 keys) + a shorter tail window,
         # through the persistent kernel (default) or the chain of one launch per sublayer (WHISPER_HIP_PERSIST=0)
         dims = synth.micro_dims(n_state=384, n_head=6, n_layer=2, n_vocab=2053, n_audio_ctx=400)
         w2 = synth.synth_weights(dims, seed=57)

@@ -83,7 +83,7 @@ def test_batch_mode_skinny_gemm_and_fused_streaming_blocks(emu_lib, which, env):
 @pytest.mark.parametrize("env", [{}, {"WHISPER_HIP_PERSIST": "0"}])
 def test_two_pass_key_ring_of_the_fused_cross_attention(emu_lib, env):
     """A window with more keys than one pass of the fused cross-attention block holds (the opt-in doubled window: C = 1500
-    on the device against 768 per pass; here C = 395 against 256): K and V each make two passes through the register ring,
+    on the device against 768 per pass; here C = 395 against 384): K and V each make two passes through the register ring,
     in the persistent kernel and in the one-launch-per-sublayer chain.  Token-exact against the oracle."""
     p = _run(emu_lib, "geometry384", env)
     assert p.returncode == 0 and "EMU_CHECK_OK geometry384" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]

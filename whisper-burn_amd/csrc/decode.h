@@ -224,9 +224,9 @@ int launch_dec_persist(hipStream_t st, const PersistArgs& a, int grid);
 void launch_ps_seed(hipStream_t st, const float* x, int n, void* gx, unsigned tag);
 
 #ifdef HIPEMU
-// (functional-model build: micro shapes -- two tiles per pass, so that the doubled-window geometry of the micro models,
-// C = 400 keys, runs the two-pass ring)
-constexpr int CROSS_FUSED_MAX_C = 256;
+// (functional-model build: three tiles per pass, so that micro models run both rings -- one pass at n_audio_ctx = 400
+// (C = 200 keys), two passes for its doubled windows (C = 395) and for reference-length windows (C = 745))
+constexpr int CROSS_FUSED_MAX_C = 384;
 #else
 constexpr int CROSS_FUSED_MAX_C = 768;   // keys per window one pass of the fused cross-attention block holds (n_audio_ctx / 2 = 750)
 #endif
