@@ -124,13 +124,14 @@ def main(which):
         assert len(wins) == (7 if which.endswith("x7") else 4)
         e2.close()
     elif which == "beam_batch":
-        # batch mode with MORE than 16 live rows: 7 windows x 3 beams = 21 rows -> two 16-row tiles of the skinny
-        # weight-stream GEMM (decode_batch.hip: v_mfma_f32_16x16x4_f32, split-K planes, last-arriver fold + LayerNorm /
-        # GELU epilogues), chunked cross-attention + combine (beams share a window's cached K/V)
-        a = synth.synth_audio(16000 * 75, 33)
-        got, wins = wb.waveform_to_tokens(eng, st, a, 16000, 3, 6)
-        ref, rw = otr.waveform_to_tokens(o, pu.ost(st), a, 16000, 3, 6, return_windows=True)
-        assert len(rw) == 7, len(rw)
+        # batch mode with MORE than 32 live rows: 9 windows x 4 beams = 36 rows -> three 16-row tiles of the skinny
+        # weight-stream GEMM (decode_batch.hip: v_mfma_f32_16x16x4_f32, split-K planes; with three or four tiles a thread
+        # stores two (row, column quad) items of the block's plane), chunked cross-attention + combine (beams share a
+        # window's cached K/V)
+        a = synth.synth_audio(16000 * 100, 33)
+        got, wins = wb.waveform_to_tokens(eng, st, a, 16000, 4, 5)
+        ref, rw = otr.waveform_to_tokens(o, pu.ost(st), a, 16000, 4, 5, return_windows=True)
+        assert len(rw) == 9, len(rw)
         assert wins == rw and got == ref, (wins, rw)
     elif which == "beam":
         a = synth.synth_audio(16000 * 2, 9)

@@ -122,18 +122,20 @@ __global__ __launch_bounds__(SK_NT, MT <= 2 ? 2 : 1) void dec_skinny_gemm_kernel
           make_float4(acc[mt][0][v], acc[mt][1][v], acc[mt][2][v], acc[mt][3][v]);
     }
   __syncthreads();
-  // ---- the block's plane: thread (row, column quad) sums the waves in order
-  const bool owner = tid < MT * 256;
-  const int row = tid >> 4, j4 = tid & 15;           // (owner threads: row < 16 MT)
-  const uint32_t poff = (uint32_t)((int64_t)row * a.N + n0 + 4 * j4);      // element offset inside a plane
-  if (owner && row < a.M) {
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  // ---- the block's plane: (row, column quad) items over the block's 512 threads -- 16 MT rows x 16 quads, i.e. up to two
+  // items per thread with three or four row tiles -- each sums the waves in order
 #pragma unroll
-    for (int w = 0; w < 8; w++) {
-      const float4 t = *reinterpret_cast<const float4*>(smem + ((w * MT * 16 + row) * 16 + j4) * 4);
-      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+  for (int e0 = 0; e0 < MT * 256; e0 += SK_NT) {
+    const int e = e0 + tid, row = e >> 4, j4 = e & 15;
+    if (e < MT * 256 && row < a.M) {
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int w = 0; w < 8; w++) {
+        const float4 t = *reinterpret_cast<const float4*>(smem + ((w * MT * 16 + row) * 16 + j4) * 4);
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+      }
+      *reinterpret_cast<float4*>(a.P + (int64_t)z * a.plane + (int64_t)row * a.N + n0 + 4 * j4) = s;
     }
-    *reinterpret_cast<float4*>(a.P + (int64_t)z * a.plane + poff) = s;
   }
 }
 

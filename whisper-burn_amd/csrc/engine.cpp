@@ -34,7 +34,14 @@ static int upload(hipStream_t st, DevMem& dst, const void* src, size_t bytes) {
 
 // Dispatch on the model's compute dtype: exact-f32 MFMA (parity path) or bf16 MFMA (speed path) when the
 // weight has a bf16 copy and the shape fits that kernel (the conv1 gather stays on the f32 kernel).
-int gemm_dispatch(const wb_model* m, hipStream_t st, const GemmArgs& a, const uint16_t* wt, int ldwt) {
+int gemm_dispatch(const wb_model* m, hipStream_t st, const GemmArgs& a, const uint16_t* wt, int ldwt, const uint16_t* sh,
+                  const uint16_t* sl) {
+  // exact-f32 models: encoder-side weights that carry a split copy go through the three-product fp16 kernel
+  if (m->compute_dtype != WB_BF16 && sh && sl && a.conv1_tstride == 0 && a.K % 32 == 0 && ldwt % 8 == 0 && a.ksplit <= 1) {
+    WB_REQUIRE(launch_gemm_f16x3(st, a, sh, sl, ldwt) == 0, WB_ERR_SHAPE, "split gemm: unsupported shape M=%d N=%d K=%d", a.M,
+               a.N, a.K);
+    return WB_OK;
+  }
   if (m->compute_dtype == WB_BF16 && wt && a.conv1_tstride == 0 && a.K % 32 == 0 && ldwt % 8 == 0) {
     WB_REQUIRE(launch_gemm_bf16(st, a, wt, ldwt) == 0, WB_ERR_SHAPE, "bf16 gemm: unsupported shape M=%d N=%d K=%d", a.M,
                a.N, a.K);
@@ -47,7 +54,7 @@ int gemm_dispatch(const wb_model* m, hipStream_t st, const GemmArgs& a, const ui
 
 // GEMM against a model weight: `w` supplies the bf16 copy for the speed path (null: f32 kernel only).
 static int gemm(const wb_model* m, hipStream_t st, const GemmArgs& a, const LinearW* w) {
-  return gemm_dispatch(m, st, a, w ? w->wt : nullptr, w ? w->k : 0);
+  return gemm_dispatch(m, st, a, w ? w->wt : nullptr, w ? w->k : 0, w ? w->sh : nullptr, w ? w->sl : nullptr);
 }
 
 // y = x + (h W + b) for a long contraction (the MLP's second matrix, K = 4 d): K in blocks of GEMM_KBLOCK rows, each block's
@@ -65,7 +72,7 @@ static int gemm_residual_kblocked(const wb_model* m, hipStream_t st, const float
     g.bias = k0 == 0 ? w.b : nullptr;              // first block: + bias + the residual stream; later blocks: + the running sum
     g.residual = x; g.ldr = w.n;
     g.M = M; g.N = w.n; g.K = kb;
-    WB_TRY(gemm_dispatch(m, st, g, blocked ? nullptr : w.wt, w.k));
+    WB_TRY(gemm_dispatch(m, st, g, blocked ? nullptr : w.wt, w.k, w.sh ? w.sh + k0 : nullptr, w.sl ? w.sl + k0 : nullptr));
   }
   return WB_OK;
 }

@@ -11,6 +11,7 @@
 #include <fstream>
 
 #include "wb_internal.h"
+#include "kernels.h"
 
 namespace wb { void session_pool_register(wb_model* m); }
 
@@ -415,6 +416,26 @@ int build_model(TensorMap& tm, int device, int compute_dtype, wb_model** out) {
     uint16_t* b16 = m->arena_bf16.as<uint16_t>();
     for (auto& f : fixes) { f.l->wt = b16 + f.wt; if (f.wkn != SIZE_MAX) f.l->wkn = b16 + f.wkn; }
     m->tok_emb_bf = b16 + e_bf; m->tok_emb_t_bf = b16 + et_bf;
+  }
+  // ---- exact-f32 models, opt-in (WHISPER_HIP_ENCODER_SPLIT=1): fp16 hi / lo copies of the encoder-side GEMM weights for
+  // the three-product kernel (gemm_f16x3.hip); made on the device, once
+  static const bool split_enabled = []() { const char* e = getenv("WHISPER_HIP_ENCODER_SPLIT"); return e && e[0] == '1'; }();
+  if (compute_dtype != WB_BF16 && split_enabled) {
+    std::vector<LinearW*> ws;
+    for (int i = 0; i < D.n_audio_layer; i++) {
+      ws.push_back(&m->enc[i].qkv); ws.push_back(&m->enc[i].out); ws.push_back(&m->enc[i].mlp1); ws.push_back(&m->enc[i].mlp2);
+    }
+    ws.push_back(&m->ckv_all);
+    size_t total = 0;
+    for (LinearW* l : ws) total += ((size_t)l->k * l->n + 127) & ~size_t(127);
+    WB_TRY(m->arena_split.alloc(total * 2 * 2));
+    uint16_t* p = m->arena_split.as<uint16_t>();
+    for (LinearW* l : ws) {
+      const size_t n = ((size_t)l->k * l->n + 127) & ~size_t(127);
+      l->sh = p; l->sl = p + n; p += 2 * n;
+      launch_split_weight_f16(nullptr, l->w, l->k, l->n, l->sh, l->sl);
+    }
+    WB_HIP(hipDeviceSynchronize());
   }
   *out = m.release();
   session_pool_register(*out);

@@ -178,7 +178,7 @@ static int session_finish_encode(wb_session* s, const MelBatch& mb) {
     g.A = s->enc_out.as<float>(); g.lda = d; g.B = m->ckv_all.w; g.ldb = ldkv; g.C = s->ckv.as<float>(); g.ldc = ldkv;
     g.bias = m->ckv_all.b; g.M = rows; g.N = ldkv; g.K = d;
     g.col_scale = m->qk_scale; g.col_scale_period = 2 * d; g.col_scale_width = d;   // K * s (mod.rs:510-514)
-    WB_TRY(gemm_dispatch(m, s->st, g, m->ckv_all.wt, m->ckv_all.k));
+    WB_TRY(gemm_dispatch(m, s->st, g, m->ckv_all.wt, m->ckv_all.k, m->ckv_all.sh, m->ckv_all.sl));
     tm.stop();
     if (tm.on) { WB_HIP(hipStreamSynchronize(s->st)); tm.collect(); }
   }

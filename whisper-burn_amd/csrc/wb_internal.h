@@ -88,6 +88,7 @@ struct LinearW {
   float* w = nullptr; float* b = nullptr; int k = 0, n = 0;   // w: [k][n] row-major f32
   uint16_t* wt = nullptr;    // speed path: bf16 [n][k] (K-contiguous, MFMA GEMM operand)
   uint16_t* wkn = nullptr;   // speed path: bf16 [k][n] (decode GEMV streams N contiguously); decoder weights only
+  uint16_t* sh = nullptr; uint16_t* sl = nullptr;   // split-precision path: fp16 hi / lo * 2^11, [n][k] (encoder-side weights)
 };
 
 struct EncBlockW {
@@ -129,6 +130,7 @@ struct wb_model {
   // all weights live in one arena allocation
   wb::DevMem arena;
   wb::DevMem arena_bf16;      // WB_BF16: bf16 copies of the GEMM weights
+  wb::DevMem arena_split;     // exact-f32 models with the split-precision encoder: fp16 hi / lo copies of the encoder-side weights
   uint16_t* tok_emb_bf = nullptr;     // E   [V][d] bf16 (already K-contiguous for logits = x E^T)
   uint16_t* tok_emb_t_bf = nullptr;   // E^T [d][vocab_ld] bf16
   // encoder

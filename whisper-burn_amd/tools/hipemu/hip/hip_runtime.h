@@ -282,6 +282,16 @@ static inline hipemu_f32x4 hipemu_mfma_f32_16x16x4f32(float a, float b, hipemu_f
   for (int i = 0; i < 4; i++) d[i] = co[i];
   return d;
 }
+typedef _Float16 hipemu_f16x8 __attribute__((ext_vector_type(8)));
+static inline hipemu_f32x16 hipemu_mfma_f32_32x32x16_f16(hipemu_f16x8 a, hipemu_f16x8 b, hipemu_f32x16 c, int, int, int) {
+  float ai[8], bi[8], ci[16], co[16];                      // (same register layout as the bf16 variant)
+  for (int i = 0; i < 8; i++) { ai[i] = (float)a[i]; bi[i] = (float)b[i]; }
+  for (int i = 0; i < 16; i++) ci[i] = c[i];
+  hipemu::wave_op(hipemu::OP_MFMA_BF16_32X32X16, ai, bi, ci, co, 0, 0, 0, 0);
+  hipemu_f32x16 d;
+  for (int i = 0; i < 16; i++) d[i] = co[i];
+  return d;
+}
 static inline hipemu_f32x16 hipemu_mfma_f32_32x32x16_bf16(hipemu_bf16x8 a, hipemu_bf16x8 b, hipemu_f32x16 c, int, int, int) {
   float ai[8], bi[8], ci[16], co[16];
   for (int i = 0; i < 8; i++) { ai[i] = (float)a[i]; bi[i] = (float)b[i]; }
@@ -315,3 +325,4 @@ static inline unsigned long long __ballot(int pred) {
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu_mfma_f32_32x32x2f32
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_f32_16x16x4f32
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 hipemu_mfma_f32_32x32x16_bf16
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16 hipemu_mfma_f32_32x32x16_f16
