@@ -16,7 +16,8 @@
 //   * the 8 waves of a block share the strip and split the block's K slice; their partial tiles meet in LDS (fixed
 //     wave order) and one split-K plane per block goes out -- the same planes the tiled GEMM wrote, folded by the same
 //     consumers in the same order;
-// 11.1 us per launch (0.20 of HBM peak) on large-v2, 450 s: 422x -> 462x; small, 10 min: 2330x -> 2481x (profiles/r03_i_*).
+// 11.1 us per launch (0.20 of HBM peak) on large-v2, 450 s: 422x -> 462x (profiles/r03_i_*); small, 10 min: 2330x -> 2525x
+// (profiles/r03_p_*).
 //
 // Rejected, both measured on large-v2 450 s (the fold launches stay: a kernel boundary is ~7.6 us here, and every way
 // tried of moving a fold across it cost more):

@@ -497,7 +497,7 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
     const bool cross_stream = cross_stream_enabled && max_nb <= 1;
     // ... and where the head's slice of Wq is small next to the window's cached K/V (d <= 768: `small` and below) those
     // blocks fold the pending planes, normalise and project their own query first -- two launches less per layer.
-    // Measured both ways (profiles/r03_j_*): small, 10 min 2445x -> 2517x; large-v2 (327 KB of Wq per block, 220 VGPRs)
+    // Measured both ways (profiles/r03_j_*): small, 10 min +3 %; large-v2 (327 KB of Wq per block, 220 VGPRs)
     // 441x -> 433x, so d = 1024 / 1280 keep the launches.  WHISPER_HIP_CROSS_STREAM_FUSE=0 / 1 forces it off / on.
     static const int stream_fuse_mode = []() { const char* e = getenv("WHISPER_HIP_CROSS_STREAM_FUSE"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
     const bool stream_fused = cross_stream && m->compute_dtype != WB_BF16 && cross_stream_can_fuse(d) &&
