@@ -89,6 +89,21 @@ def test_two_pass_key_ring_of_the_fused_cross_attention(emu_lib, env):
     assert p.returncode == 0 and "EMU_CHECK_OK geometry384" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
+def test_split_precision_encoder_gemm_under_the_functional_model(emu_lib):
+    """gemm_f16x3.hip (opt-in, WHISPER_HIP_ENCODER_SPLIT=1): weights pre-split into fp16 hi / lo pieces at load, activations
+    split on their way into LDS, three v_mfma_f32_32x32x16_f16 per product: logits of wb_forward within 1e-3 of the oracle,
+    greedy tokens exact -- and the bits differ from the f32 path's (the kernel really ran)."""
+    for which in ("forward", "greedy"):
+        p = _run(emu_lib, which, {"WHISPER_HIP_ENCODER_SPLIT": "1"})
+        assert p.returncode == 0 and f"EMU_CHECK_OK {which}" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+    digests = []
+    for v in ("0", "1"):
+        p = _run(emu_lib, "bitwise", {"WHISPER_HIP_ENCODER_SPLIT": v})
+        assert p.returncode == 0, p.stderr[-2000:]
+        digests.append([l for l in p.stdout.splitlines() if l.startswith("DIGEST ")][-1])
+    assert digests[0] != digests[1]
+
+
 @pytest.mark.parametrize("d", [384, 768])
 def test_the_other_kernel_template_families(emu_lib, d):
     """d = 384 (the fused sublayer kernels of tiny.en; base.en's d = 512 instantiates the same templates) and 768

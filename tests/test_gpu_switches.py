@@ -104,6 +104,17 @@ def test_the_30_s_window_geometry_on_the_other_decode_paths(switch):
     assert got == ref
 
 
+@pytest.mark.gpu
+def test_split_precision_encoder_reproduces_the_oracle_tokens():
+    """WHISPER_HIP_ENCODER_SPLIT=1 (gemm_f16x3.hip: every encoder-side Linear as three fp16 MFMAs per product, f32
+    accumulation; opt-in): the benchmarked workload decodes to the committed oracle rows.  The tolerance tests at real shapes
+    were run with it once (profiles/r03_o_pytest_split.log); the numerics study is tests/study_split_precision.py."""
+    g = np.load(GOLD)
+    got = _run({"WHISPER_HIP_ENCODER_SPLIT": "1"})
+    ref = [g["tiny_bench_tokens"][i][:int(g["tiny_bench_lens"][i])].tolist() for i in range(len(g["tiny_bench_lens"]))]
+    assert got["tiny_bench"] == ref
+
+
 BATCH_CHILD = r"""
 import json, sys
 sys.path[:0] = [%(root)r, %(pkg)r, %(tests)r]
