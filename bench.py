@@ -414,6 +414,9 @@ def main() -> None:
                                    f"KV-cached decode, {'greedy (beam_size 1)' if args.beam == 1 else 'beam ' + str(args.beam)}, "
                                    f"max_depth {args.max_depth}",
                        "windows": n_win, "beam_size": args.beam, "max_depth": args.max_depth,
+                       "encoder_gemm": ("split precision: three fp16 MFMAs per product, f32 accumulate (WHISPER_HIP_ENCODER_SPLIT=1)"
+                                        if os.environ.get("WHISPER_HIP_ENCODER_SPLIT", "") == "1" and args.dtype != "bf16"
+                                        else ("bf16 MFMA" if args.dtype == "bf16" else "exact-f32 MFMA")),
                        "tokens_out": len(tokens) if tokens is not None else 0,
                        "parallelism": f"windows sharded over {world} GPU(s), 1 token all-gather"},
             "roofline": roofline,

@@ -89,16 +89,19 @@ print("RESULT " + json.dumps(res))
 
 
 def draw_many(rng):
-    """Batch mode: 9-16 short windows (n_audio_ctx = 400: 3.9 s windows, 0.9 s apart), greedy or beams -- more than 8 live rows,
-    i.e. split-K MFMA GEMMs, resolve-LN, the streaming (one beam) or chunked (beams) cross-attention, dec_topk_rows."""
-    d = int(rng.choice([128, 128, 384, 768]))
+    """Batch mode: 9-16 short windows (n_audio_ctx = 400: 3.9 s windows, 0.9 s apart), greedy or beams -- more than 8 live rows
+    (up to 64: one to four 16-row tiles of the skinny GEMM), i.e. the skinny / tiled split-K MFMA GEMMs, resolve-LN, the
+    streaming (one beam; with or without its fused front) or chunked (beams) cross-attention, dec_topk_rows."""
+    d = int(rng.choice([128, 128, 384, 512, 768]))
     n_win = int(rng.integers(9, 17)) if d == 128 else int(rng.integers(9, 12))
     secs = 3.9 + 0.9 * (n_win - 1) - float(rng.random()) * 0.8
     return dict(d=d, layers=int(rng.integers(1, 3)) if d == 128 else 1, vocab=int(rng.choice([515, 1031, 2053])),
                 audio_ctx=400, text_ctx=int(rng.choice([16, 64, 448])), x2=0, ln_inside=int(rng.random() < 0.3),
                 samples=int(secs * 16000), aseed=int(rng.integers(0, 1 << 30)), wseed=int(rng.integers(0, 1 << 30)),
-                beam=int(rng.choice([1, 1, 1, 2, 3])), depth=int(rng.integers(1, 11)),
-                switches=str(rng.choice(["", "", "WHISPER_HIP_CROSS_STREAM=0", "WHISPER_HIP_CHAIN=0", "WHISPER_HIP_GRAPH=0"])))
+                beam=int(rng.choice([1, 1, 1, 2, 3, 4])), depth=int(rng.integers(1, 11)),
+                switches=str(rng.choice(["", "", "", "WHISPER_HIP_CROSS_STREAM=0", "WHISPER_HIP_CHAIN=0", "WHISPER_HIP_GRAPH=0",
+                                         "WHISPER_HIP_BATCH_SKINNY=0", "WHISPER_HIP_CROSS_STREAM_FUSE=0",
+                                         "WHISPER_HIP_ENCODER_SPLIT=1"])))
 
 
 def draw(rng):
@@ -113,8 +116,9 @@ def draw(rng):
                 audio_ctx=audio_ctx, text_ctx=int(rng.choice([16, 64, 448])), x2=x2, ln_inside=int(rng.random() < 0.3),
                 samples=int(secs * 16000) + int(rng.integers(0, 160)), aseed=int(rng.integers(0, 1 << 30)),
                 wseed=int(rng.integers(0, 1 << 30)), beam=int(rng.choice([1, 1, 2, 3, 5])), depth=int(rng.integers(0, 13)),
-                switches=str(rng.choice(["", "", "WHISPER_HIP_FUSE_SUB=0", "WHISPER_HIP_FUSE_X=0", "WHISPER_HIP_CHAIN=0",
-                                         "WHISPER_HIP_GRAPH=0", "WHISPER_HIP_CROSS_STREAM=0", "WHISPER_HIP_FUSE_Q=0"])))
+                switches=str(rng.choice(["", "", "", "WHISPER_HIP_FUSE_SUB=0", "WHISPER_HIP_FUSE_X=0", "WHISPER_HIP_CHAIN=0",
+                                         "WHISPER_HIP_GRAPH=0", "WHISPER_HIP_CROSS_STREAM=0", "WHISPER_HIP_FUSE_Q=0",
+                                         "WHISPER_HIP_PERSIST=0", "WHISPER_HIP_ENCODER_SPLIT=1"])))
 
 
 def main():
