@@ -3,6 +3,7 @@
 by their ISA semantics), compared with the oracle at micro shapes -- plus the guard that keeps that build out of
 the product path.  Not a substitute for the `-m gpu` parity tests (no timing, no memory model, micro shapes only);
 it catches indexing / layout / launch-logic defects before a GPU minute is spent."""
+import concurrent.futures
 import os
 import shutil
 import subprocess
@@ -26,16 +27,81 @@ def emu_lib():
     return EMU_LIB
 
 
-def _run(emu_lib, which, extra_env=None, allow=True):
+def _spawn(emu_lib, which, extra_env=None, allow=True):
     env = dict(os.environ)
     env["WHISPER_HIP_LIB"] = emu_lib
     env.pop("WHISPER_HIP_ALLOW_EMU", None)
     if allow:
         env["WHISPER_HIP_ALLOW_EMU"] = "1"
     env["PYTHONPATH"] = os.pathsep.join([ROOT, PKG, os.path.join(ROOT, "tests"), env.get("PYTHONPATH", "")])
+    env.setdefault("OMP_NUM_THREADS", "2")             # (several checks run side by side: the oracle half of each stays small)
     env.update(extra_env or {})
     return subprocess.run([sys.executable, os.path.join(ROOT, "tests", "emu_checks.py"), which], env=env,
-                          capture_output=True, text=True, timeout=300)
+                          capture_output=True, text=True, timeout=900)
+
+
+# The checks are independent processes, mostly single-threaded (the functional model runs one fiber at a time): the ones the
+# selected tests will ask for are started ahead of time, a few side by side, and a test picks up its finished process.
+_JOBS = {}
+_POOL = concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(6, (os.cpu_count() or 2) - 2)))
+
+
+def _key(which, extra_env, allow=True):
+    return (which, tuple(sorted((extra_env or {}).items())), allow)
+
+
+def _run(emu_lib, which, extra_env=None, allow=True):
+    fut = _JOBS.pop(_key(which, extra_env, allow), None)
+    return fut.result() if fut is not None else _spawn(emu_lib, which, extra_env, allow)
+
+
+def _stamps_path(which, env):
+    tag = "_".join([which] + [f"{k[-6:]}{v}" for k, v in sorted(env.items())])
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"ps_stamps_test_{tag}.bin")
+
+
+def _persist_env(which, env):
+    return dict(env, WHISPER_HIP_PS_STAMPS=_stamps_path(which, env))
+
+
+# test function -> the (check, environment) jobs one parametrisation of it runs
+_PLAN = {
+    "test_kernel_sources_reproduce_the_oracle_under_the_functional_model": lambda p: [(p["which"], {})],
+    "test_chained_greedy_windows_ending_at_different_steps": lambda p: [(p["which"], p["env"])],
+    "test_persistent_flag_chained_decode_under_the_functional_model": lambda p: [(p["which"], _persist_env(p["which"], p["env"]))],
+    "test_batch_mode_skinny_gemm_and_fused_streaming_blocks": lambda p: [(p["which"], p["env"])],
+    "test_two_pass_key_ring_of_the_fused_cross_attention": lambda p: [("geometry384", p["env"])],
+    "test_split_precision_encoder_gemm_under_the_functional_model": lambda p: [
+        ("forward", {"WHISPER_HIP_ENCODER_SPLIT": "1"}), ("greedy", {"WHISPER_HIP_ENCODER_SPLIT": "1"}),
+        ("bitwise", {"WHISPER_HIP_ENCODER_SPLIT": "0"}), ("bitwise", {"WHISPER_HIP_ENCODER_SPLIT": "1"})],
+    "test_the_other_kernel_template_families": lambda p: [(f"shape{p['d']}", {})],
+    "test_unfused_decode_paths_under_the_functional_model": lambda p: [("greedy", {p["switch"]: "0"})],
+    "test_sanitizer_and_reversed_schedule": lambda p: [(p["which"], {"HIPEMU_GUARD": "1", "HIPEMU_SEGV_TRACE": "1",
+                                                                     "HIPEMU_ORDER": "reverse"})],
+    "test_outputs_are_bitwise_independent_of_the_schedule": lambda p: [("bitwise", {}), ("bitwise", {"HIPEMU_ORDER": "reverse"})],
+}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _prefetch(request, emu_lib):
+    for item in request.session.items:
+        if getattr(item, "module", None) is not request.module:
+            continue
+        plan = _PLAN.get(getattr(item, "originalname", None) or item.name)
+        if plan is None:
+            continue
+        cs = getattr(item, "callspec", None)
+        for which, env in plan(dict(cs.params) if cs is not None else {}):
+            k = _key(which, env)
+            if k not in _JOBS:
+                stamps = env.get("WHISPER_HIP_PS_STAMPS")
+                if stamps and os.path.exists(stamps):
+                    os.remove(stamps)
+                _JOBS[k] = _POOL.submit(_spawn, emu_lib, which, env)
+    yield
+    for fut in _JOBS.values():
+        fut.cancel()
+    _JOBS.clear()
 
 
 @pytest.mark.parametrize("which", ["mel", "greedy", "beam", "forward", "geometry", "prompted", "pool", "bigpad"])
@@ -62,9 +128,7 @@ def test_persistent_flag_chained_decode_under_the_functional_model(emu_lib, whic
     through arrival counters (the functional model runs every block on its own thread and passes a baton whenever a block
     spins).  Token-exact against the oracle for d = 128 / 384 / 512, 4 and 7 rows, one role per block and several roles
     per block (HIPEMU_CUS shrinks the grid), both block orders.  It is the default greedy path of the models it supports."""
-    env = dict(env, WHISPER_HIP_PS_STAMPS=os.path.join(os.environ.get("TMPDIR", "/tmp"), "ps_stamps_test.bin"))
-    if os.path.exists(env["WHISPER_HIP_PS_STAMPS"]):
-        os.remove(env["WHISPER_HIP_PS_STAMPS"])
+    env = _persist_env(which, env)
     p = _run(emu_lib, which, env)
     assert os.path.exists(env["WHISPER_HIP_PS_STAMPS"]), "the persistent kernel did not run"
     assert p.returncode == 0 and f"EMU_CHECK_OK {which}" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
