@@ -16,6 +16,8 @@
 // times the instructions: the ceiling is 5.3x the f32 kernel's.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace wb {
@@ -251,8 +253,9 @@ int launch_gemm_f16x3(hipStream_t st, const GemmArgs& a, const uint16_t* Wh, con
   if (a.K % BK != 0 || ldwt % 8 != 0 || a.conv1_tstride > 0) return -1;
   if (a.ksplit > 1 && (a.bias || a.residual || a.aux || a.act != ACT_NONE || a.col_scale_period > 0)) return -1;
   auto blocks = [&](int bm, int bn) { return (int64_t)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
+  static const int force_tile = []() { const char* e = getenv("WHISPER_HIP_SPLIT_TILE"); return e ? atoi(e) : 0; }();   // developer A/B
   if (a.M <= 32) launch_cfg<32, 128, 1, 4>(st, a, Wh, Wl, ldwt);
-  else if (a.ksplit > 1 || blocks(128, 128) < 384) launch_cfg<64, 64, 2, 2>(st, a, Wh, Wl, ldwt);
+  else if (force_tile == 64 || (force_tile != 128 && (a.ksplit > 1 || blocks(128, 128) < 384))) launch_cfg<64, 64, 2, 2>(st, a, Wh, Wl, ldwt);
   else launch_cfg<128, 128, 2, 2>(st, a, Wh, Wl, ldwt);
   return 0;
 }
