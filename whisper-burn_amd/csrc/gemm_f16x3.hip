@@ -53,8 +53,14 @@ __device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& 
                   (unsigned)l[4] | ((unsigned)l[5] << 16), (unsigned)l[6] | ((unsigned)l[7] << 16));
 }
 
+// Two waves per SIMD: bounded to 256 registers the 128 x 128 tile fits two blocks per CU (246 VGPRs, no scratch; unbounded the
+// compiler took 198 + 128 accumulator registers = one block) -- large-v2 encoder 249.7 -> 196.5 ms on the same box
+// (profiles/r03_r_*).
+#ifndef WB_F16X3_MIN_WAVES
+#define WB_F16X3_MIN_WAVES 2
+#endif
 template <int BM, int BN, int WGM, int WGN>
-__global__ __launch_bounds__(NT) void gemm_f16x3_kernel(GemmArgs g, const u16* __restrict__ Wh, const u16* __restrict__ Wl, int ldwt) {
+__global__ __launch_bounds__(NT, WB_F16X3_MIN_WAVES) void gemm_f16x3_kernel(GemmArgs g, const u16* __restrict__ Wh, const u16* __restrict__ Wl, int ldwt) {
   constexpr int TM = BM / WGM, TN = BN / WGN;
   constexpr int RM = TM / 32, RN = TN / 32;
   static_assert(WGM * WGN == 4 && TM % 32 == 0 && TN % 32 == 0, "bad tiling");
