@@ -135,7 +135,12 @@ def main() -> None:
                     help="audio per GPU of the large-v2 leg (450 s = 38 windows = one GPU's share of the 8-GPU hour)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 = exact-f32 MFMA parity path (the judged configuration); bf16 = speed path")
+    ap.add_argument("--encoder", default=None, choices=["f32", "split"],
+                    help="encoder-side GEMMs of the f32 path: f32 = exact-f32 MFMA (default), split = three fp16 MFMAs per "
+                         "product (WHISPER_HIP_ENCODER_SPLIT=1: f32-grade results, ~1.9x the rate; opt-in)")
     args = ap.parse_args()
+    if args.encoder is not None:                     # (read once per process by the library, at model load)
+        os.environ["WHISPER_HIP_ENCODER_SPLIT"] = "1" if args.encoder == "split" else "0"
     if args.seconds is None:
         args.seconds = 478559 / 16000.0 if args.geometry == "whisper30" else 30.0
 

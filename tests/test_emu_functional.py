@@ -198,8 +198,9 @@ def test_two_ranks_shard_the_windows_of_the_real_engine(emu_lib):
     assert p.returncode == 0 and "EMU_CHECK_OK sharded" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
-@pytest.mark.parametrize("extra", [["--large-v2-leg", "on", "--large-v2-seconds", "4"], ["--geometry", "whisper30", "--beam", "2"]],
-                         ids=["default+large-v2-leg", "whisper30-beam2"])
+@pytest.mark.parametrize("extra", [["--large-v2-leg", "on", "--large-v2-seconds", "4"], ["--geometry", "whisper30", "--beam", "2"],
+                                   ["--encoder", "split"]],
+                         ids=["default+large-v2-leg", "whisper30-beam2", "split-encoder"])
 def test_bench_main_runs_to_its_json_line(emu_lib, extra):
     """bench.py cannot start without cuda:0, and a broken bench line cannot be repaired after a round: tools/
     bench_dry_run.py stubs the torch.cuda calls and runs the script UNCHANGED over the functional model with a micro
@@ -222,6 +223,7 @@ def test_bench_main_runs_to_its_json_line(emu_lib, extra):
     assert cb["kind"] == "port" and cb["cores"] >= 1 and set(cb["stages_s"]) == {"mel", "encoder", "decode", "total"}
     assert out["mel_frontend"]["windows"] >= 2 and out["stages"]["decode_kernels_per_token"] > 0
     assert len(cb["runs_s"]) == 3
+    assert out["config"]["encoder_gemm"].startswith("split precision" if "--encoder" in extra else "exact-f32")
     if "--large-v2-leg" in extra:
         lv = out["large_v2"]
         assert lv["n_gpus"] == 1 and lv["value"] > 0 and lv["steps"] == 3 and "large-v2" in lv["config"]["workload"]
