@@ -9,15 +9,15 @@
 //   * a wave owns a 64-column strip of W over its own K range and requests ALL of its rows before the first use
 //     (one float4 per lane = 4 K-rows x 64 columns per load instruction; <= 12 instructions in flight per wave): the
 //     whole matrix is in flight one round trip after the launch;
-//   * arithmetic stays exact f32 on the matrix cores: v_mfma_f32_16x16x4_f32, rows in tiles of 16 (15 windows of
+//   * arithmetic stays exact f32 on the matrix cores: v_mfma_f32_16x16x4_f32, rows in tiles of 16 (e.g. 15 windows of
 //     large-v2 fill one tile; 32 x 32 tiles would idle half the array).  Component c of the lane's float4 is the B
 //     operand of accumulator c, i.e. accumulator c holds columns 4 j + c: no LDS staging for W, and a lane ends up
 //     with a float4 of consecutive output columns;
 //   * the 8 waves of a block share the strip and split the block's K slice; their partial tiles meet in LDS (fixed
 //     wave order) and one split-K plane per block goes out -- the same planes the tiled GEMM wrote, folded by the same
 //     consumers in the same order;
-// 11.1 us per launch (0.20 of HBM peak) on large-v2, 450 s: 422x -> 462x (profiles/r03_i_*); small, 10 min: 2330x -> 2525x
-// (profiles/r03_p_*).
+// 11.4 us per launch (0.20 of HBM peak) against 13.8 us on large-v2, 450 s (38 rows): 424x -> 450x on one box
+// (profiles/r03_t_*); small, 10 min: 2330x -> 2525x (profiles/r03_p_*).
 //
 // Rejected, both measured on large-v2 450 s (the fold launches stay: a kernel boundary is ~7.6 us here, and every way
 // tried of moving a fold across it cost more):
