@@ -7,7 +7,8 @@
 //
 // Here  (Linear: y = x W + b, W stored [d_in, d_out]; mod.rs:377-379, :429-435, :483-489)
 //   * a wave owns a 64-column strip of W over its own K range and requests ALL of its rows before the first use
-//     (one float4 per lane = 4 K-rows x 64 columns per load instruction; <= 12 instructions in flight per wave): the
+//     (one float4 per lane = 4 K-rows x 64 columns per load instruction; <= 20 instructions in flight per wave, 12 with
+//     three or four row tiles): the
 //     whole matrix is in flight one round trip after the launch;
 //   * arithmetic stays exact f32 on the matrix cores: v_mfma_f32_16x16x4_f32, rows in tiles of 16 (e.g. 15 windows of
 //     large-v2 fill one tile; 32 x 32 tiles would idle half the array).  Component c of the lane's float4 is the B
