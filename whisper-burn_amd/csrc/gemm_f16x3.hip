@@ -60,7 +60,8 @@ __device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& 
 #define WB_F16X3_MIN_WAVES 2
 #endif
 template <int BM, int BN, int WGM, int WGN>
-__global__ __launch_bounds__(NT, WB_F16X3_MIN_WAVES) void gemm_f16x3_kernel(GemmArgs g, const u16* __restrict__ Wh, const u16* __restrict__ Wl, int ldwt) {
+__global__ __launch_bounds__(NT, WB_F16X3_MIN_WAVES) void gemm_f16x3_kernel(GemmArgs g, const u16* __restrict__ Wh,
+                                                                            const u16* __restrict__ Wl, int ldwt) {
   constexpr int TM = BM / WGM, TN = BN / WGN;
   constexpr int RM = TM / 32, RN = TN / 32;
   static_assert(WGM * WGN == 4 && TM % 32 == 0 && TN % 32 == 0, "bad tiling");
