@@ -26,10 +26,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "whisper-burn_amd")]
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # dense peaks, same guide
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0,   # dense peaks, same guide
+                    "f16x3": 2500.0 / 3.0}           # split precision: three fp16 MFMAs per f32-grade product
 
 
-def e2e_roofline_ms(dims, lens, n_steps, dtype, clip=1490, gen_lens=None, prompt_steps=3):
+def e2e_roofline_ms(dims, lens, n_steps, dtype, clip=1490, gen_lens=None, prompt_steps=3, encoder_peak=None):
     """Roofline time of one bench step from the algorithmic work of every stage: mel = 960 B
     per frame over HBM, encoder + cross-K/V projection = dense FLOPs over the MFMA peak of the path's dtype,
     decode = weights + cached cross-K/V streamed once per step over HBM.  `gen_lens` (tokens each window generated):
@@ -44,7 +45,7 @@ def e2e_roofline_ms(dims, lens, n_steps, dtype, clip=1490, gen_lens=None, prompt
     enc_flops = sum(2 * 80 * d * 3 * t + 2 * d * d * 3 * c + L * (8 * c * d * d + 4 * c * c * d + 16 * c * d * d)
                     for t, c in zip(T, C))
     ckv_flops = sum(L * 4 * c * d * d for c in C)
-    enc_ms = (enc_flops + ckv_flops) / (MFMA_PEAK_TFLOPS[dtype] * 1e12) * 1e3
+    enc_ms = (enc_flops + ckv_flops) / (MFMA_PEAK_TFLOPS[encoder_peak or dtype] * 1e12) * 1e3
     w_bytes = s * (V * d + L * 14 * d * d)                                    # decoder weights + E^T, once per step
     if gen_lens is None:
         dec_bytes = n_steps * (w_bytes + 4.0 * L * 2 * d * sum(C))           # cached K/V stay f32
@@ -377,8 +378,10 @@ def main() -> None:
         audio_s = args.seconds * world * args.steps
         lo, hi = shard.partition_windows(n_win, rank, world)
         gen_lens = [max(0, len(r) - 4) for r in per_window[lo:hi]] if args.beam == 1 else None
+        # (split-precision encoder: its MFMA peak is a third of the fp16 dense peak -- three instructions per product)
+        enc_peak = "f16x3" if (os.environ.get("WHISPER_HIP_ENCODER_SPLIT", "") == "1" and args.dtype != "bf16") else args.dtype
         rl = e2e_roofline_ms(eng.dims, lens[lo:hi], 3 + args.max_depth, args.dtype,
-                             eng.max_mel_frames() - params.padding, gen_lens=gen_lens)   # per rank (weak scaling)
+                             eng.max_mel_frames() - params.padding, gen_lens=gen_lens, encoder_peak=enc_peak)   # per rank (weak scaling)
         work = rl.pop("_work")
         if stages:
             # achieved rates of the two big stages from their algorithmic work: encoder + cross-K/V from the profiled
@@ -386,7 +389,7 @@ def main() -> None:
             enc_ms = stages["encoder_ms_per_step"] + stages["cross_kv_ms_per_step"]
             dec_ms = dt / args.steps * 1e3 - enc_ms - stages["mel_ms_per_step"]
             stages["encoder_TFLOPs_algorithmic"] = round(work["encoder_flops"] / (enc_ms * 1e-3) / 1e12, 2) if enc_ms > 0 else None
-            stages["encoder_frac_of_mfma_peak"] = round(work["encoder_flops"] / (enc_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[args.dtype], 4) if enc_ms > 0 else None
+            stages["encoder_frac_of_mfma_peak"] = round(work["encoder_flops"] / (enc_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[enc_peak], 4) if enc_ms > 0 else None
             stages["decode_GBps_algorithmic"] = round(work["decode_bytes"] / (dec_ms * 1e-3) / 1e9, 1) if dec_ms > 0 else None
             stages["decode_frac_of_hbm_peak"] = round(work["decode_bytes"] / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dec_ms > 0 else None
         rtf = audio_s / dt
