@@ -134,10 +134,12 @@ def test_persistent_flag_chained_decode_under_the_functional_model(emu_lib, whic
     assert p.returncode == 0 and f"EMU_CHECK_OK {which}" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
-@pytest.mark.parametrize("which,env", [("beam_batch", {}), ("chain_eot_batch", {"WHISPER_HIP_CROSS_STREAM_FUSE": "0"})])
+@pytest.mark.parametrize("which,env", [("beam_batch", {}), ("beam_batch", {"WHISPER_HIP_SK_PAIR": "1"}),
+                                       ("chain_eot_batch", {"WHISPER_HIP_CROSS_STREAM_FUSE": "0"})])
 def test_batch_mode_skinny_gemm_and_fused_streaming_blocks(emu_lib, which, env):
     """decode_batch.hip under the functional model: the skinny split-K GEMM on v_mfma_f32_16x16x4_f32 with 36 live rows
-    (three row tiles; 9 windows x 4 beams, chunked cross-attention), and the streaming cross-attention blocks without
+    (three row tiles; 9 windows x 4 beams, chunked cross-attention; also with the opt-in pairwise meeting of the waves'
+    partial tiles), and the streaming cross-attention blocks without
     their fused front (fold + cross_attn_ln + Wq; the default at this width is fused, and the tiled GEMM the skinny one
     replaces runs too: test_chained_greedy_windows_ending_at_different_steps).  Token-exact against the oracle."""
     p = _run(emu_lib, which, env)

@@ -48,14 +48,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int SK_NT = 512;          // 8 waves: one 64-column strip, the block's K slice in 8 parts
 constexpr int SK_MAX_LD = 20;       // float4 loads a wave keeps in flight (80 K-rows); 12 with more than two row tiles
 
-template <int MT>
+// PAIR (opt-in, WHISPER_HIP_SK_PAIR=1; to be measured): the partial tiles meet pairwise -- waves 4-7 park theirs, waves 0-3 add
+// their own and park the sums, the plane items sum those four: half the LDS (16 KB per row tile instead of 32), so that a
+// block of THREE row tiles is 74 KB and two of them share a CU.  Today's 96 KB admit one, and the 320 blocks of large-v2's
+// MLP products (the smallest K-split 12 loads in flight allow) take two rounds of the chip: 19.5 us against 8.8 us for a bare
+// read of the matrix (profiles/r03_m_layer_cycle_large_v2.txt, r03_v_stream_probe.txt).  The summation order becomes
+// (w0 + w4) + (w1 + w5) + (w2 + w6) + (w3 + w7): fixed, but other bits than the sequential order's -- which is why it waits
+// for a whole `-m gpu` run.
+template <int MT, bool PAIR>
 __global__ __launch_bounds__(SK_NT, MT <= 2 ? 2 : 1) void dec_skinny_gemm_kernel(SkinnyArgs a) {
   // one region, two lives: the activations of the block's K slice, k-major in row tiles of 16 (As[mt][k][16]: the A
   // operand of lane l for K-rows k0 .. k0 + 3 is word 16 k0 + l -- conflict-free), then the 8 waves' partial tiles
   // (K-rows per block <= 32 x 20 = 640: 10240 words per row tile -- 32 x 12 = 384 rows with three or four row tiles;
   // the partial tiles need 8 x 16 x 64 = 8192)
   constexpr int LDW = MT <= 2 ? SK_MAX_LD : 12;
-  __shared__ __attribute__((aligned(16))) float smem[MT * (MT <= 2 ? 10240 : 8192)];
+  __shared__ __attribute__((aligned(16))) float smem[MT * (MT <= 2 ? 10240 : (PAIR ? 6144 : 8192))];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int strip = blockIdx.x, z = blockIdx.y;
   const int kchunk = a.K / a.ksplit;                 // host: K % (32 ksplit) == 0
@@ -115,14 +122,34 @@ __global__ __launch_bounds__(SK_NT, MT <= 2 ? 2 : 1) void dec_skinny_gemm_kernel
   }
   __syncthreads();                                   // the activations are consumed: the region takes the partial tiles
   // red[wave][mt][i][j] as float4 (columns 4 j .. 4 j + 3): register v of lane l is row 4 (l / 16) + v, column j = l % 16
+  constexpr int NSLOT = PAIR ? 4 : 8;
+  auto park = [&](int slot) {
 #pragma unroll
-  for (int mt = 0; mt < MT; mt++)
+    for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-    for (int v = 0; v < 4; v++) {
-      const int i = 4 * krow + v;
-      *reinterpret_cast<float4*>(smem + (((wave * MT + mt) * 16 + i) * 16 + cq) * 4) =
-          make_float4(acc[mt][0][v], acc[mt][1][v], acc[mt][2][v], acc[mt][3][v]);
+      for (int v = 0; v < 4; v++) {
+        const int i = 4 * krow + v;
+        *reinterpret_cast<float4*>(smem + (((slot * MT + mt) * 16 + i) * 16 + cq) * 4) =
+            make_float4(acc[mt][0][v], acc[mt][1][v], acc[mt][2][v], acc[mt][3][v]);
+      }
+  };
+  if constexpr (PAIR) {
+    if (wave >= 4) park(wave - 4);
+    __syncthreads();
+    if (wave < 4) {                                    // (a wave reads and rewrites its OWN slot: no barrier in between)
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+          const int i = 4 * krow + v;
+          const float4 t = *reinterpret_cast<const float4*>(smem + (((wave * MT + mt) * 16 + i) * 16 + cq) * 4);
+          acc[mt][0][v] += t.x; acc[mt][1][v] += t.y; acc[mt][2][v] += t.z; acc[mt][3][v] += t.w;
+        }
+      park(wave);
     }
+  } else {
+    park(wave);
+  }
   __syncthreads();
   // ---- the block's plane: (row, column quad) items over the block's 512 threads -- 16 MT rows x 16 quads, i.e. up to two
   // items per thread with three or four row tiles -- each sums the waves in order
@@ -132,7 +159,7 @@ __global__ __launch_bounds__(SK_NT, MT <= 2 ? 2 : 1) void dec_skinny_gemm_kernel
     if (e < MT * 256 && row < a.M) {
       float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int w = 0; w < 8; w++) {
+      for (int w = 0; w < NSLOT; w++) {
         const float4 t = *reinterpret_cast<const float4*>(smem + ((w * MT * 16 + row) * 16 + j4) * 4);
         s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
       }
@@ -168,12 +195,19 @@ int launch_dec_skinny_gemm(hipStream_t st, const SkinnyArgs& a) {
   if (a.K / a.ksplit / 32 > (a.M <= 32 ? SK_MAX_LD : 12)) return -1;
   const int MT = (a.M + 15) / 16;
   const dim3 grid(a.N / 64, a.ksplit), block(SK_NT);
+  static const bool pair = []() { const char* e = getenv("WHISPER_HIP_SK_PAIR"); return e && e[0] == '1'; }();
+#define WB_SK(MT_)                                                                              \
+  do {                                                                                          \
+    if (pair) WB_KLAUNCH((dec_skinny_gemm_kernel<MT_, true>), grid, block, 0, st, a);            \
+    else WB_KLAUNCH((dec_skinny_gemm_kernel<MT_, false>), grid, block, 0, st, a);                \
+  } while (0)
   switch (MT) {
-    case 1: WB_KLAUNCH((dec_skinny_gemm_kernel<1>), grid, block, 0, st, a); break;
-    case 2: WB_KLAUNCH((dec_skinny_gemm_kernel<2>), grid, block, 0, st, a); break;
-    case 3: WB_KLAUNCH((dec_skinny_gemm_kernel<3>), grid, block, 0, st, a); break;
-    default: WB_KLAUNCH((dec_skinny_gemm_kernel<4>), grid, block, 0, st, a); break;
+    case 1: WB_SK(1); break;
+    case 2: WB_SK(2); break;
+    case 3: WB_SK(3); break;
+    default: WB_SK(4); break;
   }
+#undef WB_SK
   return 0;
 }
 

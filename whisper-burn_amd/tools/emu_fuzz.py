@@ -101,7 +101,7 @@ def draw_many(rng):
                 beam=int(rng.choice([1, 1, 1, 2, 3, 4])), depth=int(rng.integers(1, 11)),
                 switches=str(rng.choice(["", "", "", "WHISPER_HIP_CROSS_STREAM=0", "WHISPER_HIP_CHAIN=0", "WHISPER_HIP_GRAPH=0",
                                          "WHISPER_HIP_BATCH_SKINNY=0", "WHISPER_HIP_CROSS_STREAM_FUSE=0",
-                                         "WHISPER_HIP_ENCODER_SPLIT=1"])))
+                                         "WHISPER_HIP_ENCODER_SPLIT=1", "WHISPER_HIP_SK_PAIR=1"])))
 
 
 def draw(rng):
