@@ -57,17 +57,19 @@ def e2e_roofline_ms(dims, lens, n_steps, dtype, clip=1490, gen_lens=None, prompt
             "_work": {"encoder_flops": float(enc_flops + ckv_flops), "decode_bytes": float(dec_bytes)}}
 
 
-CPU_BASELINE_DEPTH = 32     # decode depth of the CPU leg's bounded sample (the reference re-runs the whole prefix per token:
-                            # its cost per token GROWS with the depth, so a shallower sample flatters the CPU figure)
+CPU_BASELINE_DEPTH = 32     # decode depth of the CPU leg's REPEATED sample (second field); `value` is one run at the GPU's depth
 
 
-def run_cpu_baseline(weights, st, audio, sr, wlen, beam, depth, geometry, model_name, reps=3):
+def run_cpu_baseline(weights, st, audio, sr, wlen, beam, depth, geometry, model_name, reps=3, full_depth=True):
     """The `cpu_baseline` leg: the oracle (kind "port": the PyTorch-CPU fp32 restatement of the reference algorithm as
     written -- dense-DFT mel, no KV cache, full-prefix decoder re-run per step) on a BOUNDED sample of the workload: ONE
-    window, decode depth min(depth, CPU_BASELINE_DEPTH), on the host cores PyTorch uses.  BASELINE.md section 3: one
-    warm-up run, then `reps` (>= 3) timed runs, the MEDIAN is reported (every run is listed); the mel and encoder stages
-    are timed on their own as well, the decode time is the rest.  Runs without a GPU (tests call it on a
-    micro model)."""
+    window on the host cores PyTorch uses.
+
+    `value` is LIKE-FOR-LIKE with the GPU figure: one timed run at the GPU run's own decode depth (the reference re-runs
+    the whole prefix per token, transcribe.rs:253-307, so its cost per token grows with the depth and a shallower sample
+    would flatter it).  `depth32` keeps the cheaper repeated sample of the earlier rounds (one
+    warm-up, `reps` runs, median; every run listed) with the mel / encoder stages timed on their own.
+    Runs without a GPU (tests call it on a micro model)."""
     import statistics
 
     import torch
@@ -84,9 +86,14 @@ def run_cpu_baseline(weights, st, audio, sr, wlen, beam, depth, geometry, model_
     runs = []
     for _ in range(max(1, reps)):
         t0 = time.perf_counter()
-        otr.waveform_to_tokens(ow, ost, clip, sr, beam, cpu_depth)        # the baseline figure: the whole path, as it comes
+        otr.waveform_to_tokens(ow, ost, clip, sr, beam, cpu_depth)        # the whole path, as it comes
         runs.append(time.perf_counter() - t0)
     cpu_dt = statistics.median(runs)
+    full_dt = cpu_dt
+    if full_depth and cpu_depth != int(depth):
+        t0 = time.perf_counter()
+        otr.waveform_to_tokens(ow, ost, clip, sr, beam, int(depth))       # ONE run at the GPU run's depth: the like-for-like figure
+        full_dt = time.perf_counter() - t0
     t_mels, t_encs = [], []
     for _ in range(max(1, reps)):                                        # ... then the two front stages on their own
         t0 = time.perf_counter()
@@ -99,16 +106,68 @@ def run_cpu_baseline(weights, st, audio, sr, wlen, beam, depth, geometry, model_
         t_encs.append(time.perf_counter() - t0)
     t_mel, t_enc = statistics.median(t_mels), statistics.median(t_encs)
     t_mel, t_enc = min(t_mel, cpu_dt), min(t_enc, max(cpu_dt - min(t_mel, cpu_dt), 0.0))
-    return {"value": round((n_cpu / sr) / cpu_dt, 3), "unit": "x real-time", "cores": torch.get_num_threads(),
+    like = full_depth or cpu_depth == int(depth)
+    return {"value": round((n_cpu / sr) / full_dt, 3), "unit": "x real-time", "cores": torch.get_num_threads(),
             "kind": "port",
             "sample": f"1 window ({n_cpu / sr:.1f} s, {geometry} geometry), {model_name}, beam {beam}, "
-                      f"depth {cpu_depth}" + (f" (GPU run: {depth})" if cpu_depth != depth else "") +
+                      f"depth {int(depth) if like else cpu_depth}" + ("" if like else f" (GPU run: {depth})") +
                       f", PyTorch-CPU fp32 restatement of the reference algorithm as "
-                      f"written (dense-DFT mel, no KV cache); 1 warm-up + {len(runs)} runs, median {cpu_dt:.2f} s wall",
-            "runs_s": [round(r, 3) for r in runs],
+                      f"written (dense-DFT mel, no KV cache); " +
+                      (f"ONE run at the GPU run's depth: {full_dt:.2f} s wall" if like and cpu_depth != int(depth)
+                       else f"1 warm-up + {len(runs)} runs, median {cpu_dt:.2f} s wall"),
+            "depth": int(depth) if like else cpu_depth,
+            "depth32": {"value": round((n_cpu / sr) / cpu_dt, 3), "depth": cpu_depth,
+                        "note": f"same window at depth {cpu_depth}: 1 warm-up + {len(runs)} runs, median {cpu_dt:.2f} s wall; "
+                                f"NOT like-for-like with the GPU figure (shallower decode)",
+                        "runs_s": [round(r, 3) for r in runs],
+                        "stages_s": {"mel": round(t_mel, 3), "encoder": round(t_enc, 3),
+                                     "decode": round(cpu_dt - t_mel - t_enc, 3), "total": round(cpu_dt, 3)}},
+            "runs_s": [round(full_dt, 3)] if like and cpu_depth != int(depth) else [round(r, 3) for r in runs],
             "stages_s": {"mel": round(t_mel, 3), "encoder": round(t_enc, 3),
-                         "decode": round(cpu_dt - t_mel - t_enc, 3), "total": round(cpu_dt, 3)},
+                         "decode": round(full_dt - t_mel - t_enc, 3), "total": round(full_dt, 3)},
             "host_cpus": os.cpu_count()}
+
+
+def kernel_table(kstats, pmc_bytes=lambda name: None):
+    """Per-kernel-class rows of the profiled passes (attached HIP events per launch + algorithmic bytes): sorted by total
+    time; the first row is the dominant kernel."""
+    tot_ms = sum(k["total_ms"] for k in kstats) or 1.0
+    rows = []
+    for k in sorted(kstats, key=lambda k: -k["total_ms"]):
+        avg_s = k["total_ms"] / k["calls"] * 1e-3
+        per_launch = k["algo_bytes"] / k["calls"]
+        ach = per_launch / avg_s / 1e9
+        rows.append({"kernel": k["name"], "share_of_decode_kernel_time": round(k["total_ms"] / tot_ms, 4),
+                     "launches_timed": k["calls"], "avg_launch_us": round(avg_s * 1e6, 2),
+                     "algorithmic_bytes_per_launch": int(per_launch), "achieved_GBps": round(ach, 1),
+                     "frac_of_hbm_peak": round(ach / HBM_PEAK_GBS, 4),
+                     "traffic": pmc_bytes(k["name"])})
+    return rows
+
+
+def roofline_of(k0, traffic_source=None):
+    return {"kernel": k0["kernel"], "bound": "hbm", "achieved": k0["achieved_GBps"], "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": k0["frac_of_hbm_peak"], "traffic": k0["traffic"],
+            "traffic_source": traffic_source if k0["traffic"] is not None else None,
+            "algorithmic_bytes_per_launch": k0["algorithmic_bytes_per_launch"],
+            "avg_launch_us": k0["avg_launch_us"], "launches_timed": k0["launches_timed"],
+            "share_of_decode_kernel_time": k0["share_of_decode_kernel_time"],
+            "note": "dominant decode-step kernel by total duration; `kernels` lists every class"}
+
+
+def profiled_passes(lib, _lib, decode_fn, n_prof):
+    """`n_prof` extra passes with every decode-step launch carrying its own start / stop HIP events on the engine's stream
+    (the dispatch's begin -> end, what `rocprofv3 --kernel-trace` reports).  Returns (stage milliseconds + counters, per-class stats)."""
+    lib.wb_profile_enable(1)
+    buf = np.zeros(8, dtype=np.float64)
+    lib.wb_profile_read(buf.ctypes.data_as(_lib.c_double_p), 1)
+    _lib.profile_kernels(reset=True)
+    for _ in range(n_prof):
+        decode_fn()
+    lib.wb_profile_read(buf.ctypes.data_as(_lib.c_double_p), 1)
+    kstats = _lib.profile_kernels(reset=True)
+    lib.wb_profile_enable(0)
+    return [float(x) for x in buf], kstats
 
 
 def main() -> None:
@@ -138,7 +197,7 @@ def main() -> None:
                     help="f32 = exact-f32 MFMA parity path (the judged configuration); bf16 = speed path")
     ap.add_argument("--encoder", default=None, choices=["f32", "split"],
                     help="encoder-side GEMMs of the f32 path: f32 = exact-f32 MFMA (default), split = three fp16 MFMAs per "
-                         "product (WHISPER_HIP_ENCODER_SPLIT=1: f32-grade results, ~1.9x the rate; opt-in)")
+                         "product (f32-grade results, ~1.9x the rate); default: the library's (WHISPER_HIP_ENCODER_SPLIT)")
     args = ap.parse_args()
     if args.encoder is not None:                     # (read once per process by the library, at model load)
         os.environ["WHISPER_HIP_ENCODER_SPLIT"] = "1" if args.encoder == "split" else "0"
@@ -182,22 +241,29 @@ def main() -> None:
     if args.geometry == "whisper30":
         eng.set_frame_limit(True)
     V = eng.dims["n_vocab"]
+    enc_gemm = eng.encoder_gemm()
     st = wb.SpecialTokens.for_vocab(V)
     params = wb.decode_params(st, beam_size=args.beam, max_depth=args.max_depth)
 
     sr = 16000
     n_total = int(round(args.seconds * sr)) * world
     audio = synth.synth_audio(n_total, synth.BENCH_AUDIO_SEED)         # seed 1234 + config#
-    pcm_dev = torch.from_numpy(audio).to(dev)                           # resident in HBM before the timed region
     wlen = wb.max_waveform_samples(eng.max_mel_frames() - params.padding)
     starts, lens = wb.window_extents(n_total, sr, wlen, params.overlap_seconds)
     n_win = len(starts)
     row_stride = 4 + args.max_depth + 4
-    n_frames_local = int(sum(int(l) // 160 for l in lens[slice(*shard.partition_windows(n_win, rank, world))]))
+    local_win = shard.partition_windows(n_win, rank, world)
+    n_frames_local = int(sum(int(l) // 160 for l in lens[slice(*local_win)]))
+    # a rank holds only the PCM span its own windows cover (resident in HBM before the timed region)
+    span = shard.rank_pcm_span(starts, lens, *local_win)
+    pcm_dev = torch.from_numpy(np.ascontiguousarray(audio[span[0]:span[1]])).to(dev)
+    n_local = span[1] - span[0]
 
     def decode_local(lo, hi):
-        return wb.waveform_to_tokens(eng, st, None, sr, params=params, win_begin=lo, win_end=hi,
-                                     device_ptr=pcm_dev.data_ptr(), n_samples=n_total)[1]
+        # (lo, hi) are this rank's GLOBAL window indices; inside the span they are windows 0 .. hi - lo
+        assert (lo, hi) == local_win
+        return wb.waveform_to_tokens(eng, st, None, sr, params=params, win_begin=0, win_end=hi - lo,
+                                     device_ptr=pcm_dev.data_ptr(), n_samples=n_local)[1]
 
     def step():
         return shard.transcribe_sharded(decode_local, wb.stitch_windows, n_win, rank, world, row_stride,
@@ -228,17 +294,9 @@ def main() -> None:
     kernels = None
     stages = None
     if rank == 0:
-        lib.wb_profile_enable(1)
-        buf = (np.zeros(8, dtype=np.float64))
-        lib.wb_profile_read(buf.ctypes.data_as(_lib.c_double_p), 1)
-        _lib.profile_kernels(reset=True)
         n_prof = 3
-        for _ in range(n_prof):
-            decode_local(*shard.partition_windows(n_win, rank, world))
-        lib.wb_profile_read(buf.ctypes.data_as(_lib.c_double_p), 1)
-        kstats = _lib.profile_kernels(reset=True)
-        lib.wb_profile_enable(0)
-        mel_ms, enc_ms, ckv_ms, dec_ms, n_steps, n_mel, logit_ms, n_logit = [float(x) for x in buf]
+        buf, kstats = profiled_passes(lib, _lib, lambda: decode_local(*local_win), n_prof)
+        mel_ms, enc_ms, ckv_ms, dec_ms, n_steps, n_mel, logit_ms, n_logit = buf
         # measured HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command,
         # corrected per MI355X_MICROARCH.md (profiles/summarize_pmc.py), keyed by kernel class; only used when the
         # file was collected on this workload (it records the command line)
@@ -266,26 +324,9 @@ def main() -> None:
                     return int(max(vals)) if vals else None
             return None
 
-        tot_ms = sum(k["total_ms"] for k in kstats) or 1.0
-        kernels = []
-        for k in sorted(kstats, key=lambda k: -k["total_ms"]):
-            avg_s = k["total_ms"] / k["calls"] * 1e-3
-            per_launch = k["algo_bytes"] / k["calls"]
-            ach = per_launch / avg_s / 1e9
-            kernels.append({"kernel": k["name"], "share_of_decode_kernel_time": round(k["total_ms"] / tot_ms, 4),
-                            "launches_timed": k["calls"], "avg_launch_us": round(avg_s * 1e6, 2),
-                            "algorithmic_bytes_per_launch": int(per_launch), "achieved_GBps": round(ach, 1),
-                            "frac_of_hbm_peak": round(ach / HBM_PEAK_GBS, 4),
-                            "traffic": pmc_bytes(k["name"])})
+        kernels = kernel_table(kstats, pmc_bytes)
         if kernels:
-            k0 = kernels[0]                                   # the dominant kernel by total time
-            roofline = {"kernel": k0["kernel"], "bound": "hbm", "achieved": k0["achieved_GBps"], "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": k0["frac_of_hbm_peak"], "traffic": k0["traffic"],
-                        "traffic_source": os.path.relpath(pmc_json, ROOT) if k0["traffic"] is not None else None,
-                        "algorithmic_bytes_per_launch": k0["algorithmic_bytes_per_launch"],
-                        "avg_launch_us": k0["avg_launch_us"], "launches_timed": k0["launches_timed"],
-                        "share_of_decode_kernel_time": k0["share_of_decode_kernel_time"],
-                        "note": "dominant decode-step kernel by total duration; `kernels` lists every class"}
+            roofline = roofline_of(kernels[0], os.path.relpath(pmc_json, ROOT))
         stages = {"mel_ms_per_step": round(mel_ms / n_prof, 4), "encoder_ms_per_step": round(enc_ms / n_prof, 4),
                   "cross_kv_ms_per_step": round(ckv_ms / n_prof, 4), "decode_ms_per_step": round(dec_ms / n_prof, 4),
                   "decode_steps_per_step": n_steps / n_prof,
@@ -299,7 +340,7 @@ def main() -> None:
         n_mw = max(1, args.mel_windows)
         shift = int(wlen) - int(params.overlap_seconds * sr)
         n_mel = shift * (n_mw - 1) + int(wlen)
-        big = pcm_dev.repeat((n_mel + n_total - 1) // n_total)[:n_mel].contiguous()
+        big = pcm_dev.repeat((n_mel + n_local - 1) // n_local)[:n_mel].contiguous()
         m_starts, m_lens = wb.window_extents(n_mel, sr, wlen, params.overlap_seconds)
         Ts = eng.max_mel_frames()
         mel_out = torch.empty((len(m_starts), 80, Ts), dtype=torch.float32, device=dev)
@@ -326,24 +367,30 @@ def main() -> None:
 
     # ---- large-v2 leg (BASELINE.json's multi-GPU headline config): every rank decodes --large-v2-seconds of audio ----
     large_v2 = None
-    if args.large_v2_leg == "on" or (args.large_v2_leg == "auto" and world > 1):
+    if args.large_v2_leg == "on" or (args.large_v2_leg == "auto" and args.model in ("tiny.en", "tiny_en")
+                                     and args.geometry == "reference" and args.beam == 1):
         eng.close()
         del pcm_dev
         lw = synth.synth_preset("large-v2")
         leng = wb.Whisper.from_tensors(lw, device=local_rank,
                                        compute_dtype=wb.WB_BF16 if args.dtype == "bf16" else wb.WB_F32)
         del lw
+        leng_split = leng.encoder_gemm() == "f16x3"
         lst = wb.SpecialTokens.for_vocab(leng.dims["n_vocab"])
         lparams = wb.decode_params(lst, beam_size=1, max_depth=args.max_depth)
         ln_total = int(round(args.large_v2_seconds * sr)) * world
         laudio = synth.synth_audio(ln_total, synth.BENCH_AUDIO_SEED + 5)
-        lpcm = torch.from_numpy(laudio).to(dev)
         lstarts, llens = wb.window_extents(ln_total, sr, wlen, lparams.overlap_seconds)
         ln_win = len(lstarts)
+        lwin = shard.partition_windows(ln_win, rank, world)
+        lspan = shard.rank_pcm_span(lstarts, llens, *lwin)
+        lpcm = torch.from_numpy(np.ascontiguousarray(laudio[lspan[0]:lspan[1]])).to(dev)
+        del laudio
 
         def ldecode(lo_, hi_):
-            return wb.waveform_to_tokens(leng, lst, None, sr, params=lparams, win_begin=lo_, win_end=hi_,
-                                         device_ptr=lpcm.data_ptr(), n_samples=ln_total)[1]
+            assert (lo_, hi_) == lwin
+            return wb.waveform_to_tokens(leng, lst, None, sr, params=lparams, win_begin=0, win_end=hi_ - lo_,
+                                         device_ptr=lpcm.data_ptr(), n_samples=lspan[1] - lspan[0])[1]
 
         def lstep():
             return shard.transcribe_sharded(ldecode, wb.stitch_windows, ln_win, rank, world, row_stride,
@@ -363,6 +410,17 @@ def main() -> None:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ldt = float(t.item())
         if rank == 0:
+            # the leg's own roofline: dominant batch-mode decode kernel of ONE profiled pass (attached HIP events per launch)
+            lbuf, lkstats = profiled_passes(lib, _lib, lambda: ldecode(*lwin), 1)
+            lkern = kernel_table(lkstats)
+            l_enc_ms, l_ckv_ms, l_dec_ms, l_nsteps = lbuf[1], lbuf[2], lbuf[3], lbuf[4]
+            lgen = [max(0, len(r) - 4) for r in lrows[lwin[0]:lwin[1]]]
+            lenc_peak = "f16x3" if (leng_split and args.dtype != "bf16") else args.dtype
+            lrl = e2e_roofline_ms(leng.dims, llens[lwin[0]:lwin[1]], 3 + args.max_depth, args.dtype,
+                                  leng.max_mel_frames() - lparams.padding, gen_lens=lgen, encoder_peak=lenc_peak)
+            lwork = lrl.pop("_work")
+            l_step_ms = ldt / l_steps * 1e3
+            l_dec_untraced = l_step_ms - l_enc_ms - l_ckv_ms - lbuf[0]
             large_v2 = {"metric": "real-time factor (audio-sec/wall-sec)",
                         "value": round(args.large_v2_seconds * world * l_steps / ldt, 2), "unit": "x real-time",
                         "n_gpus": world, "steps": l_steps, "warmup": l_warm, "ms_per_step": round(ldt / l_steps * 1e3, 2),
@@ -371,6 +429,20 @@ def main() -> None:
                                                f"reference windowing ({ln_win} windows), greedy, max_depth {args.max_depth}",
                                    "windows": ln_win, "tokens_out": len(ltok),
                                    "generated_tokens_per_window_mean": round(float(np.mean([len(r) - 4 for r in lrows])), 1)},
+                        "roofline": roofline_of(lkern[0]) if lkern else None,
+                        "kernels": lkern,
+                        "stages": {"encoder_ms_per_step": round(l_enc_ms, 2), "cross_kv_ms_per_step": round(l_ckv_ms, 2),
+                                   "decode_ms_per_step_untraced": round(l_dec_untraced, 2),
+                                   "decode_ms_per_step_profiled_pass": round(l_dec_ms, 2),
+                                   "decode_kernel_ms_sum_profiled_pass": round(sum(k["total_ms"] for k in lkstats), 2),
+                                   "decode_steps": l_nsteps,
+                                   "encoder_TFLOPs_algorithmic": round(lwork["encoder_flops"] / ((l_enc_ms + l_ckv_ms) * 1e-3) / 1e12, 2) if l_enc_ms > 0 else None,
+                                   "encoder_frac_of_mfma_peak": round(lwork["encoder_flops"] / ((l_enc_ms + l_ckv_ms) * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[lenc_peak], 4) if l_enc_ms > 0 else None,
+                                   "decode_frac_of_hbm_peak": round(lwork["decode_bytes"] / (l_dec_untraced * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if l_dec_untraced > 0 else None,
+                                   "note": "decode_ms_per_step_untraced = timed step - encoder - cross-K/V - mel (no events attached); the "
+                                           "profiled pass attaches events to every launch, which inflates its wall time -- only its per-kernel "
+                                           "durations are used"},
+                        "e2e_roofline_ms_per_step": {k: round(v, 3) for k, v in lrl.items()},
                         "target": ">= 50x real-time on 8 GPUs (BASELINE.json north_star)"}
         leng.close()
 
@@ -379,7 +451,7 @@ def main() -> None:
         lo, hi = shard.partition_windows(n_win, rank, world)
         gen_lens = [max(0, len(r) - 4) for r in per_window[lo:hi]] if args.beam == 1 else None
         # (split-precision encoder: its MFMA peak is a third of the fp16 dense peak -- three instructions per product)
-        enc_peak = "f16x3" if (os.environ.get("WHISPER_HIP_ENCODER_SPLIT", "") == "1" and args.dtype != "bf16") else args.dtype
+        enc_peak = enc_gemm if enc_gemm == "f16x3" else args.dtype
         rl = e2e_roofline_ms(eng.dims, lens[lo:hi], 3 + args.max_depth, args.dtype,
                              eng.max_mel_frames() - params.padding, gen_lens=gen_lens, encoder_peak=enc_peak)   # per rank (weak scaling)
         work = rl.pop("_work")
@@ -422,9 +494,9 @@ def main() -> None:
                                    f"KV-cached decode, {'greedy (beam_size 1)' if args.beam == 1 else 'beam ' + str(args.beam)}, "
                                    f"max_depth {args.max_depth}",
                        "windows": n_win, "beam_size": args.beam, "max_depth": args.max_depth,
-                       "encoder_gemm": ("split precision: three fp16 MFMAs per product, f32 accumulate (WHISPER_HIP_ENCODER_SPLIT=1)"
-                                        if os.environ.get("WHISPER_HIP_ENCODER_SPLIT", "") == "1" and args.dtype != "bf16"
-                                        else ("bf16 MFMA" if args.dtype == "bf16" else "exact-f32 MFMA")),
+                       "encoder_gemm": {"f16x3": "split precision: three fp16 MFMAs per product on fp16 hi / lo pieces, f32 "
+                                                 "accumulate (f32-grade results; WHISPER_HIP_ENCODER_SPLIT=0 selects exact-f32 MFMA)",
+                                        "bf16": "bf16 MFMA", "f32": "exact-f32 MFMA"}[enc_gemm],
                        "tokens_out": len(tokens) if tokens is not None else 0,
                        "parallelism": f"windows sharded over {world} GPU(s), 1 token all-gather"},
             "roofline": roofline,

@@ -95,6 +95,14 @@ int wb_model_set_ln_variant(wb_model* m, int eps_inside_sqrt);
  *                            formulas (transcribe.rs:32-34, :171-177) with the larger bound. */
 int wb_model_set_frame_limit(wb_model* m, int whisper_geometry);
 
+/* Arithmetic of the encoder-side Linear layers of this model (fixed at load time):
+ *   0 = exact-f32 MFMA (v_mfma_f32_32x32x2_f32)
+ *   1 = split precision: three fp16 MFMAs per product on fp16 hi / lo pieces, f32 accumulation -- f32-grade results
+ *       (default for f32 models; WHISPER_HIP_ENCODER_SPLIT=0 at load time selects 0)
+ *   2 = bf16 MFMA (compute_dtype WB_BF16: the speed path)
+ * Replaces nothing in the reference (its Linear is Burn's, mod.rs:377-379); a caller reports it next to its timings. */
+int wb_model_encoder_gemm(const wb_model* m);
+
 /* ---- stateless, reference-shaped entry points (the parity surface) -------------- */
 
 /* max_waveform_samples(n_frame_max), src/audio.rs:12-17 */

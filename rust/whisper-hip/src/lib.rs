@@ -117,6 +117,10 @@ impl Whisper {
         check(unsafe { ffi::wb_model_set_frame_limit(self.raw, whisper_geometry as c_int) })
     }
 
+    /// Arithmetic of the encoder-side Linear layers: 0 = exact-f32 MFMA, 1 = split precision (three fp16 MFMAs per
+    /// product, f32-grade; the default), 2 = bf16 MFMA.
+    pub fn encoder_gemm(&self) -> i32 { unsafe { ffi::wb_model_encoder_gemm(self.raw) as i32 } }
+
     /// mod.rs:52-54: `[B, 80, T]` -> `[B, C, d]`, `C = (T - 1) / 2 + 1`; T > n_audio_ctx is the reference's panic.
     pub fn forward_encoder(&self, mel: &Tensor) -> Result<Tensor> {
         let (b, t) = (mel.shape[0], mel.shape[2]);

@@ -201,7 +201,7 @@ def test_two_ranks_shard_the_windows_of_the_real_engine(emu_lib):
 
 
 @pytest.mark.parametrize("extra", [["--large-v2-leg", "on", "--large-v2-seconds", "4"], ["--geometry", "whisper30", "--beam", "2"],
-                                   ["--encoder", "split"]],
+                                   ["--encoder", "split", "--large-v2-seconds", "4"]],
                          ids=["default+large-v2-leg", "whisper30-beam2", "split-encoder"])
 def test_bench_main_runs_to_its_json_line(emu_lib, extra):
     """bench.py cannot start without cuda:0, and a broken bench line cannot be repaired after a round: tools/
@@ -226,10 +226,13 @@ def test_bench_main_runs_to_its_json_line(emu_lib, extra):
     assert out["mel_frontend"]["windows"] >= 2 and out["stages"]["decode_kernels_per_token"] > 0
     assert len(cb["runs_s"]) == 3
     assert out["config"]["encoder_gemm"].startswith("split precision" if "--encoder" in extra else "exact-f32")
-    if "--large-v2-leg" in extra:
+    assert cb["depth"] == 4 and cb["depth32"]["depth"] == 4 and cb["depth32"]["value"] > 0
+    if "--large-v2-seconds" in extra:      # the default tiny.en line carries the large-v2 leg at ONE GPU too (auto = on)
         lv = out["large_v2"]
         assert lv["n_gpus"] == 1 and lv["value"] > 0 and lv["steps"] == 3 and "large-v2" in lv["config"]["workload"]
         assert out["e2e_roofline"]["generated_tokens_per_window"] is not None
+        assert lv["roofline"]["bound"] == "hbm" and lv["roofline"]["kernel"] == lv["kernels"][0]["kernel"]
+        assert lv["stages"]["decode_ms_per_step_untraced"] > 0 and lv["stages"]["encoder_ms_per_step"] > 0
     else:
         assert out["large_v2"] is None
 

@@ -220,6 +220,25 @@ def test_partition_windows_is_a_contiguous_cover(n, world):
     assert max(b - a for a, b in blocks) <= shard.rows_per_rank(n, world)
 
 
+@given(st_.integers(1, 6_000_000), st_.integers(1, 9))
+@settings(max_examples=200, deadline=None)
+def test_rank_pcm_span_reproduces_the_rank_windows(n, world):
+    """a rank keeps only the PCM span of its own windows; inside the span they are windows 0 .. hi - lo - 1 of
+    the same window_extents() with the same lengths (the span may yield one extra overlap-tail window: the next rank's)."""
+    wlen = 238559
+    starts, lens = wb.window_extents(n, 16000, wlen)
+    for r in range(world):
+        lo, hi = shard.partition_windows(len(starts), r, world)
+        b, e = shard.rank_pcm_span(starts, lens, lo, hi)
+        if hi == lo:
+            assert (b, e) == (0, 0)
+            continue
+        s2, l2 = wb.window_extents(e - b, 16000, wlen)
+        assert hi - lo <= len(s2) <= hi - lo + 1
+        assert [int(x) + b for x in s2[:hi - lo]] == [int(x) for x in starts[lo:hi]]
+        assert [int(x) for x in l2[:hi - lo]] == [int(x) for x in lens[lo:hi]]
+
+
 def test_frontend_entry_validates_its_arguments_before_touching_a_device():
     """wb_waveform_to_mels_dev: window / stride errors are reported without a GPU (pointers are never read)."""
     starts = np.array([0, 190559], dtype=np.int64)

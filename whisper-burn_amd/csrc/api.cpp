@@ -106,6 +106,12 @@ int wb_model_set_frame_limit(wb_model* m, int whisper_geometry) {
   return WB_OK;
 }
 
+int wb_model_encoder_gemm(const wb_model* m) {
+  if (!m) return WB_ERR_ARG;
+  if (m->compute_dtype == WB_BF16) return 2;
+  return m->arena_split.p ? 1 : 0;
+}
+
 void wb_model_free(wb_model* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);

@@ -24,6 +24,17 @@ def partition_windows(n_windows: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, min(hi, n_windows)
 
 
+def rank_pcm_span(starts: Sequence[int], lens: Sequence[int], lo: int, hi: int) -> Tuple[int, int]:
+    """Sample range [begin, end) of the waveform that windows [lo, hi) cover: the only PCM a rank needs resident
+    (SURVEY.md section 8e).  Window i of the reference starts at i * shift (transcribe.rs:120-128), so inside the span the
+    rank's windows are windows 0 .. hi - lo - 1 of `window_extents(end - begin)` with the same lengths -- the span may
+    yield ONE more window than the rank owns (the 3 s overlap tail of its last window, which belongs to the next rank),
+    hence callers pass win_end = hi - lo explicitly."""
+    if hi <= lo:
+        return 0, 0
+    return int(starts[lo]), int(starts[hi - 1]) + int(lens[hi - 1])
+
+
 def rows_per_rank(n_windows: int, world: int) -> int:
     return max(1, -(-n_windows // world))
 
