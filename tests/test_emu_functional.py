@@ -70,6 +70,7 @@ _PLAN = {
     "test_chained_greedy_windows_ending_at_different_steps": lambda p: [(p["which"], p["env"])],
     "test_persistent_flag_chained_decode_under_the_functional_model": lambda p: [(p["which"], _persist_env(p["which"], p["env"]))],
     "test_batch_mode_skinny_gemm_and_fused_streaming_blocks": lambda p: [(p["which"], p["env"])],
+    "test_persistent_decode_falls_back_to_the_chain": lambda p: [("chain_eot", _persist_env("chain_eot_fb", p["env"]))],
     "test_two_pass_key_ring_of_the_fused_cross_attention": lambda p: [("geometry384", p["env"])],
     "test_split_precision_encoder_gemm_under_the_functional_model": lambda p: [
         ("forward", {"WHISPER_HIP_ENCODER_SPLIT": "1"}), ("greedy", {"WHISPER_HIP_ENCODER_SPLIT": "1"}),
@@ -132,6 +133,20 @@ def test_persistent_flag_chained_decode_under_the_functional_model(emu_lib, whic
     p = _run(emu_lib, which, env)
     assert os.path.exists(env["WHISPER_HIP_PS_STAMPS"]), "the persistent kernel did not run"
     assert p.returncode == 0 and f"EMU_CHECK_OK {which}" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
+@pytest.mark.parametrize("env", [{"WHISPER_HIP_PERSIST_INJECT_FAIL": "launch"}, {"HIPEMU_NO_COOP": "1"}],
+                         ids=["launch-refused", "no-cooperative-launch"])
+def test_persistent_decode_falls_back_to_the_chain(emu_lib, env):
+    """The persistent kernel is the default greedy path; when it cannot run -- the cooperative launch is refused (CU masking,
+    a partition, a second cooperative client) or the device reports no cooperative launches at all (a wait that gives up
+    before any step is committed takes the same exit) -- the session re-seeds the control block and decodes through the graph-replayed chain of
+    one launch per sublayer instead of failing: same tokens (windows ending at different steps), no error."""
+    env = _persist_env("chain_eot_fb", env)
+    p = _run(emu_lib, "chain_eot", env)
+    assert p.returncode == 0 and "EMU_CHECK_OK chain_eot" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+    # the role timeline is written only by a persistent launch that ran
+    assert not os.path.exists(env["WHISPER_HIP_PS_STAMPS"]), "the persistent kernel ran although it was made to fail"
 
 
 @pytest.mark.parametrize("which,env", [("beam_batch", {}), ("beam_batch", {"WHISPER_HIP_SK_PAIR": "1"}),

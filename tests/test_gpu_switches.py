@@ -32,7 +32,10 @@ SWITCHES = [{}, {"WHISPER_HIP_FUSE_X": "0"}, {"WHISPER_HIP_FUSE_SUB": "0"}, {"WH
             {"WHISPER_HIP_ATTN_KVSPLIT": "0"}, {"WHISPER_HIP_POLL": "0"}, {"WHISPER_HIP_FUSE_X": "0", "WHISPER_HIP_FUSE_CO": "1"},
             # the graph-replayed chain of one launch per sublayer instead of the persistent flag-chained decode kernel
             # (decode_persist.hip: every sublayer of every greedy step in ONE co-resident launch -- the default)
-            {"WHISPER_HIP_PERSIST": "0"}]
+            {"WHISPER_HIP_PERSIST": "0"},
+            # the cooperative launch of the persistent kernel is refused (CU masking, a partition, a second cooperative
+            # client): the session falls back to the chain instead of failing
+            {"WHISPER_HIP_PERSIST_INJECT_FAIL": "launch"}]
 
 
 _CACHE = {}

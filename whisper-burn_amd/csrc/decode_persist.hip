@@ -426,7 +426,8 @@ bool dec_persist_supported(int d, int n_rows, int max_keys) {
 
 int dec_persist_max_grid(int device, int d, int n_rows, int max_keys) {
   if (!dec_persist_supported(d, n_rows, max_keys)) return 0;
-  int cus = 0;
+  int cus = 0, coop = 0;
+  if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device) != hipSuccess || !coop) return 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) return 0;
   int per = 0;
   const bool big = n_rows > 4;

@@ -770,7 +770,15 @@ namespace wb {
 // The whole chained greedy decode as ONE persistent launch (decode_persist.hip): every sublayer of every step runs in a
 // co-resident grid whose blocks hand their output planes to each other through arrival counters.  Enqueues the first
 // step's prepare kernel, the control block and the launch, then waits for the stream.  *steps_done = steps executed.
-static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_until_len, int* steps_done) {
+//
+// *fell_back: the launch was refused (no cooperative launch on this device / partition, the grid not co-resident, a
+// second cooperative client) or a wait gave up before ANY step was committed -- the caller re-seeds the control block and
+// runs the graph-replayed chain of one launch per sublayer instead (it derives everything from gctl), and the session
+// stops trying the persistent kernel.  A wait that gives up after steps were committed stays an error.
+static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_until_len, int* steps_done, bool* fell_back) {
+  *fell_back = false;
+  // test hook (tests/test_emu_functional.py, tests/test_gpu_switches.py): "launch" = behave as if the cooperative launch was refused
+  static const char* inject = getenv("WHISPER_HIP_PERSIST_INJECT_FAIL");
   wb_model* m = s->m;
   const wb_dims& D = m->dims;
   const int d = D.n_text_state, H = D.n_text_head, NL = D.n_text_layer, V = D.n_vocab, S = s->S, W = s->W;
@@ -914,6 +922,8 @@ static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_
     WB_HIP(hipMemsetAsync(s->ps_stamps.p, 0, n_stamps * 8, st));
     a.stamps = s->ps_stamps.as<unsigned long long>();
   }
+  WB_REQUIRE(3 * NL * (max_depth + 1) + 4 < 0x10000, WB_ERR_SHAPE,
+             "persistent decode: %d layers x %d steps do not fit the 16-bit granule tags", NL, max_depth);
   // first step of the chain: token + position embedding of the last prompt token (every later step: the merge role)
   launch_dec_prepare(st, reinterpret_cast<const int*>(s->host_block_dev), s->state.as<int>(), L, W, s->tabs.as<int>(),
                      s->Lmax, m->tok_emb, m->dec_pos, d, s->x.as<float>(), s->gctl.as<int>());
@@ -923,14 +933,26 @@ static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_
   prof_tag(KC_PERSIST, 0.0);                   // (its necessary bytes are known when the rows' lengths are: added by the caller)
   const bool timed = prof_take_events(&e0, &e1);
   if (timed) WB_HIP(hipEventRecord(e0, st));
-  WB_REQUIRE(launch_dec_persist(st, a, grid) == 0, WB_ERR_HIP, "persistent decode launch failed (grid %d): %s", grid,
-             hipGetErrorString(hipGetLastError()));
+  const bool refused = (inject && !strcmp(inject, "launch")) || launch_dec_persist(st, a, grid) != 0;
   if (timed) WB_HIP(hipEventRecord(e1, st));
+  if (refused) {
+    (void)hipGetLastError();                   // (clears the sticky launch error)
+    s->ps_grid = 0;
+    *fell_back = true;
+    *steps_done = 0;
+    return WB_OK;
+  }
   std::vector<int> ctl(n_ctl);
   WB_HIP(hipMemcpyAsync(ctl.data(), s->ps_ctl.p, (size_t)n_ctl * 4, hipMemcpyDeviceToHost, st));
   int gstep = 0;
   WB_HIP(hipMemcpyAsync(&gstep, s->gctl.as<int>() + GC_STEP, 4, hipMemcpyDeviceToHost, st));
   WB_HIP(hipStreamSynchronize(st));
+  if (ctl[HX_ERR] != 0 && gstep == s->step) {  // nothing committed: the chain can take over from the same control block
+    s->ps_grid = 0;
+    *fell_back = true;
+    *steps_done = 0;
+    return WB_OK;
+  }
   WB_REQUIRE(ctl[HX_ERR] == 0, WB_ERR_HIP, "persistent decode: a wait gave up (counter %d) at step %d", ctl[HX_ERR] - 1, gstep);
   if (n_stamps) {
     std::vector<unsigned long long> hs(n_stamps);
@@ -1004,9 +1026,17 @@ int session_greedy_chain(wb_session* s, int first_token, int eot, int max_depth,
   }
   ScopedTimer tm(st, 3);
   if (persist) {
-    WB_TRY(run_persistent_chain(s, eot, max_depth, mask_until_len, &depth));
-    if (profile().on) profile().ms[4] += depth;
-  } else {
+    bool fell_back = false;
+    WB_TRY(run_persistent_chain(s, eot, max_depth, mask_until_len, &depth, &fell_back));
+    if (fell_back) {
+      // rows whose merge role ran before the give-up have moved their control words: start over from the seed
+      persist = false;
+      depth = 0;
+      WB_HIP(hipMemcpyAsync(s->gctl.p, ctl.data(), ctl_ints * 4, hipMemcpyHostToDevice, st));
+      WB_HIP(hipStreamSynchronize(st));
+    } else if (profile().on) profile().ms[4] += depth;
+  }
+  if (!persist) {
   if (fuse_ln)   // first step of the chain; every later one is prepared by its predecessor's merge kernel
     launch_dec_prepare(st, reinterpret_cast<const int*>(s->host_block_dev), s->state.as<int>(), s->lay, n_launch,
                        s->tabs.as<int>(), s->Lmax, m->tok_emb, m->dec_pos, m->dims.n_text_state, s->x.as<float>(),

@@ -127,7 +127,7 @@ hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t);
 hipError_t hipGraphDestroy(hipGraph_t);
 hipError_t hipGraphExecDestroy(hipGraphExec_t);
 hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int);
-enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 16 };
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 16, hipDeviceAttributeCooperativeLaunch = 95 };
 hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t attr, int device);   // CU count: HIPEMU_CUS (default 256)
 // resident blocks per CU of a kernel: the model has no registers or LDS budget -- HIPEMU_BLOCKS_PER_CU (default 1)
 hipError_t hipemu_occupancy(int* blocks_per_cu);

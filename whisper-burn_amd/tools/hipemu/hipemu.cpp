@@ -574,6 +574,11 @@ hipError_t hipGraphDestroy(hipGraph_t g) { delete g; return hipSuccess; }
 hipError_t hipGraphExecDestroy(hipGraphExec_t g) { delete g; return hipSuccess; }
 hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t attr, int) {
+  if (attr == hipDeviceAttributeCooperativeLaunch) {        // HIPEMU_NO_COOP=1: a device / partition without cooperative launches
+    const char* c = getenv("HIPEMU_NO_COOP");
+    *v = (c && c[0] == '1') ? 0 : 1;
+    return hipSuccess;
+  }
   if (attr != hipDeviceAttributeMultiprocessorCount) return hipErrorInvalidValue;
   const char* e = getenv("HIPEMU_CUS");
   *v = e ? atoi(e) : 256;
