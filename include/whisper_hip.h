@@ -98,7 +98,8 @@ int wb_model_set_frame_limit(wb_model* m, int whisper_geometry);
 /* Arithmetic of the encoder-side Linear layers of this model (fixed at load time):
  *   0 = exact-f32 MFMA (v_mfma_f32_32x32x2_f32)
  *   1 = split precision: three fp16 MFMAs per product on fp16 hi / lo pieces, f32 accumulation -- f32-grade results
- *       (default for f32 models; WHISPER_HIP_ENCODER_SPLIT=0 at load time selects 0)
+ *       (default for f32 models; WHISPER_HIP_ENCODER_SPLIT=0 at load time selects 0, and a model whose activations leave
+ *       fp16's range, |x| >= 65504, falls back to 0 by itself: the pass is repeated, the answer changes from then on)
  *   2 = bf16 MFMA (compute_dtype WB_BF16: the speed path)
  * Replaces nothing in the reference (its Linear is Burn's, mod.rs:377-379); a caller reports it next to its timings. */
 int wb_model_encoder_gemm(const wb_model* m);

@@ -123,6 +123,28 @@ def main(which):
         assert wins == rw and got == ref, (which, wins, rw)
         assert len(wins) == (7 if which.endswith("x7") else 4)
         e2.close()
+    elif which == "split_range":
+        # range guard of the split-precision encoder GEMM (gemm_f16x3.hip): an activation outside fp16's range (here the
+        # GELU output that feeds the first block's second MLP matrix, pushed to ~1e5 by its bias) makes an fp16 piece inf;
+        # the kernel raises its flag, the pass is repeated on the exact-f32 kernel and the model stays there
+        w2 = dict(w)
+        w2["encoder/block_0/mlp/mlp1/bias"] = np.asarray(w["encoder/block_0/mlp/mlp1/bias"], np.float32) + np.float32(1.0e5)
+        e2, o2 = wb.Whisper.from_tensors(w2), OracleWhisper(w2)
+        assert e2.encoder_gemm() == "f16x3", e2.encoder_gemm()
+        a = synth.synth_audio(16000, 5)
+        mel = np.concatenate([wb.prep_audio(a[None]), np.zeros((1, 80, 10), np.float32)], 2)
+        got = e2.forward_encoder(mel)
+        assert e2.encoder_gemm() == "f32", e2.encoder_gemm()
+        # the repeated pass IS the exact-f32 pass: a second call (now on the f32 kernel from the start) gives the same bits;
+        # against the oracle only loosely -- activations of 1e5 in f32 leave ~1e-2 of the normalised output to cancellation
+        assert np.isfinite(got).all() and np.array_equal(got, e2.forward_encoder(mel))
+        ref = o2.forward_encoder(torch.from_numpy(mel)).numpy()
+        assert np.abs(got - ref).max() < 0.3, np.abs(got - ref).max()
+        # an ordinary model is untouched by the guard
+        assert eng.encoder_gemm() == "f16x3"
+        eng.forward_encoder(mel)
+        assert eng.encoder_gemm() == "f16x3"
+        e2.close()
     elif which == "beam_batch":
         # batch mode with MORE than 32 live rows: 9 windows x 4 beams = 36 rows -> three 16-row tiles of the skinny
         # weight-stream GEMM (decode_batch.hip: v_mfma_f32_16x16x4_f32, split-K planes; with three or four tiles a thread

@@ -73,7 +73,8 @@ _PLAN = {
     "test_persistent_decode_falls_back_to_the_chain": lambda p: [("chain_eot", _persist_env("chain_eot_fb", p["env"]))],
     "test_two_pass_key_ring_of_the_fused_cross_attention": lambda p: [("geometry384", p["env"])],
     "test_split_precision_encoder_gemm_under_the_functional_model": lambda p: [
-        ("forward", {"WHISPER_HIP_ENCODER_SPLIT": "1"}), ("greedy", {"WHISPER_HIP_ENCODER_SPLIT": "1"}),
+        ("forward", {"WHISPER_HIP_ENCODER_SPLIT": "1"}), ("greedy", {"WHISPER_HIP_ENCODER_SPLIT": "1"}), ("split_range", {}),
+        ("forward", {"WHISPER_HIP_ENCODER_SPLIT": "0"}), ("greedy", {"WHISPER_HIP_ENCODER_SPLIT": "0"}),
         ("bitwise", {"WHISPER_HIP_ENCODER_SPLIT": "0"}), ("bitwise", {"WHISPER_HIP_ENCODER_SPLIT": "1"})],
     "test_the_other_kernel_template_families": lambda p: [(f"shape{p['d']}", {})],
     "test_unfused_decode_paths_under_the_functional_model": lambda p: [("greedy", {p["switch"]: "0"})],
@@ -171,12 +172,16 @@ def test_two_pass_key_ring_of_the_fused_cross_attention(emu_lib, env):
 
 
 def test_split_precision_encoder_gemm_under_the_functional_model(emu_lib):
-    """gemm_f16x3.hip (opt-in, WHISPER_HIP_ENCODER_SPLIT=1): weights pre-split into fp16 hi / lo pieces at load, activations
-    split on their way into LDS, three v_mfma_f32_32x32x16_f16 per product: logits of wb_forward within 1e-3 of the oracle,
-    greedy tokens exact -- and the bits differ from the f32 path's (the kernel really ran)."""
-    for which in ("forward", "greedy"):
-        p = _run(emu_lib, which, {"WHISPER_HIP_ENCODER_SPLIT": "1"})
+    """gemm_f16x3.hip (the default arithmetic of the encoder-side Linear layers since round 4; WHISPER_HIP_ENCODER_SPLIT=0
+    selects the exact-f32 MFMA kernel): weights pre-split into fp16 hi / lo pieces at load, activations split on their way
+    into LDS, three v_mfma_f32_32x32x16_f16 per product: logits of wb_forward within 1e-3 of the oracle, greedy tokens exact
+    with EITHER kernel -- and the bits differ between the two (each kernel really ran).  `split_range`: an activation
+    outside fp16's range trips the kernel's guard, the pass is repeated on the f32 kernel and the model stays there."""
+    for which, v in (("forward", "1"), ("greedy", "1"), ("forward", "0"), ("greedy", "0")):
+        p = _run(emu_lib, which, {"WHISPER_HIP_ENCODER_SPLIT": v})
         assert p.returncode == 0 and f"EMU_CHECK_OK {which}" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+    p = _run(emu_lib, "split_range", {})
+    assert p.returncode == 0 and "EMU_CHECK_OK split_range" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
     digests = []
     for v in ("0", "1"):
         p = _run(emu_lib, "bitwise", {"WHISPER_HIP_ENCODER_SPLIT": v})
@@ -216,8 +221,8 @@ def test_two_ranks_shard_the_windows_of_the_real_engine(emu_lib):
 
 
 @pytest.mark.parametrize("extra", [["--large-v2-leg", "on", "--large-v2-seconds", "4"], ["--geometry", "whisper30", "--beam", "2"],
-                                   ["--encoder", "split", "--large-v2-seconds", "4"]],
-                         ids=["default+large-v2-leg", "whisper30-beam2", "split-encoder"])
+                                   ["--encoder", "f32", "--large-v2-seconds", "4"]],
+                         ids=["default+large-v2-leg", "whisper30-beam2", "f32-encoder"])
 def test_bench_main_runs_to_its_json_line(emu_lib, extra):
     """bench.py cannot start without cuda:0, and a broken bench line cannot be repaired after a round: tools/
     bench_dry_run.py stubs the torch.cuda calls and runs the script UNCHANGED over the functional model with a micro
@@ -240,7 +245,7 @@ def test_bench_main_runs_to_its_json_line(emu_lib, extra):
     assert cb["kind"] == "port" and cb["cores"] >= 1 and set(cb["stages_s"]) == {"mel", "encoder", "decode", "total"}
     assert out["mel_frontend"]["windows"] >= 2 and out["stages"]["decode_kernels_per_token"] > 0
     assert len(cb["runs_s"]) == 3
-    assert out["config"]["encoder_gemm"].startswith("split precision" if "--encoder" in extra else "exact-f32")
+    assert out["config"]["encoder_gemm"].startswith("exact-f32" if "--encoder" in extra else "split precision")
     assert cb["depth"] == 4 and cb["depth32"]["depth"] == 4 and cb["depth32"]["value"] > 0
     if "--large-v2-seconds" in extra:      # the default tiny.en line carries the large-v2 leg at ONE GPU too (auto = on)
         lv = out["large_v2"]

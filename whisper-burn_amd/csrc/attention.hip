@@ -135,17 +135,19 @@ __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(const float* __r
     }
     l_run = l_run * alpha + psum;
     m_run = m_new;
+    // ---- O^T = alpha O^T + V_tile^T * P^T: the tile's product is summed on its own (a chain of 32 keys) and joins the running
+    // sum with one fma per element -- a single chain over all keys (750 per window) is ~4x less accurate
 #pragma unroll
-    for (int tt = 0; tt < 2; tt++)
+    for (int tt = 0; tt < 2; tt++) {
+      f32x16 pt;
 #pragma unroll
-      for (int r = 0; r < 16; r++) oacc[tt][r] *= alpha;
-    // ---- O^T += V_tile^T * P^T ----
-#pragma unroll
-    for (int tt = 0; tt < 2; tt++)
+      for (int r = 0; r < 16; r++) pt[r] = 0.f;
 #pragma unroll
       for (int s = 0; s < 16; s++)
-        oacc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[buf][(s & 3) + 8 * (s >> 2) + 4 * hh][32 * tt + li],
-                                                         sacc[s], oacc[tt], 0, 0, 0);
+        pt = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[buf][(s & 3) + 8 * (s >> 2) + 4 * hh][32 * tt + li], sacc[s], pt, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; r++) oacc[tt][r] = fmaf(oacc[tt][r], alpha, pt[r]);
+    }
     if (t + 1 < n_tiles) store_tile(buf ^ 1);
     __syncthreads();
   }
@@ -277,6 +279,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_f32_kvsplit_kernel(const
     }
     l_run = l_run * alpha + psum;
     m_run = m_new;
+    // (one chain per wave: the waves split the key tiles, so a chain covers a quarter of the keys and the four partial sums
+    // meet below -- already a two-level sum; a separate tile accumulator as in the kernel above would not fit 256 registers)
 #pragma unroll
     for (int tt = 0; tt < 2; tt++)
 #pragma unroll

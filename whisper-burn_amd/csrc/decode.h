@@ -223,9 +223,11 @@ int launch_dec_persist(hipStream_t st, const PersistArgs& a, int grid);
 // seeds the granule copy of the first step's x rows: tag = tag_base + 1 (what the first self-attention blocks expect)
 void launch_ps_seed(hipStream_t st, const float* x, int n, void* gx, unsigned tag);
 
-#ifdef HIPEMU
+#if defined(HIPEMU) && !defined(HIPEMU_PROD_GEOMETRY)
 // (functional-model build: three tiles per pass, so that micro models run both rings -- one pass at n_audio_ctx = 400
-// (C = 200 keys), two passes for its doubled windows (C = 395) and for reference-length windows (C = 745))
+// (C = 200 keys), two passes for its doubled windows (C = 395) and for reference-length windows (C = 745).  The second
+// functional-model library, `make prod` in tools/hipemu, compiles the PRODUCT's ring of 768 keys: tests/test_emu_functional.py
+// runs the real window lengths through it)
 constexpr int CROSS_FUSED_MAX_C = 384;
 #else
 constexpr int CROSS_FUSED_MAX_C = 768;   // keys per window one pass of the fused cross-attention block holds (n_audio_ctx / 2 = 750)

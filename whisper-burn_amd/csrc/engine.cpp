@@ -2,6 +2,7 @@
 // short sequence of fused gfx950 launches over packed, ragged window batches.
 #include "engine.h"
 
+#include <functional>
 #include <map>
 #include <mutex>
 
@@ -37,8 +38,10 @@ static int upload(hipStream_t st, DevMem& dst, const void* src, size_t bytes) {
 int gemm_dispatch(const wb_model* m, hipStream_t st, const GemmArgs& a, const uint16_t* wt, int ldwt, const uint16_t* sh,
                   const uint16_t* sl) {
   // exact-f32 models: encoder-side weights that carry a split copy go through the three-product fp16 kernel
-  if (m->compute_dtype != WB_BF16 && sh && sl && a.conv1_tstride == 0 && a.K % 32 == 0 && ldwt % 8 == 0 && a.ksplit <= 1) {
-    WB_REQUIRE(launch_gemm_f16x3(st, a, sh, sl, ldwt) == 0, WB_ERR_SHAPE, "split gemm: unsupported shape M=%d N=%d K=%d", a.M,
+  if (m->split_active() && sh && sl && a.conv1_tstride == 0 && a.K % 32 == 0 && ldwt % 8 == 0 && a.ksplit <= 1) {
+    GemmArgs g = a;
+    g.range_flag = m->split_flag_dev;
+    WB_REQUIRE(launch_gemm_f16x3(st, g, sh, sl, ldwt) == 0, WB_ERR_SHAPE, "split gemm: unsupported shape M=%d N=%d K=%d", a.M,
                a.N, a.K);
     return WB_OK;
   }
@@ -50,6 +53,19 @@ int gemm_dispatch(const wb_model* m, hipStream_t st, const GemmArgs& a, const ui
   WB_REQUIRE(launch_gemm_f32(st, a) == 0, WB_ERR_SHAPE, "gemm: unsupported shape M=%d N=%d K=%d ldb=%d", a.M,
              a.N, a.K, a.ldb);
   return WB_OK;
+}
+
+// Run `body` (a pass that may use the split-precision kernel); if that kernel raised its range flag -- an activation left
+// fp16's range, so some outputs are inf / NaN -- switch the model to the exact-f32 kernel for good and run the pass again.
+// Costs one stream synchronisation per pass while the split kernel is in use.
+int split_guarded(wb_model* m, hipStream_t st, const std::function<int()>& body) {
+  if (!m->split_active()) return body();
+  WB_TRY(body());
+  WB_HIP(hipStreamSynchronize(st));
+  if (__atomic_load_n(m->split_flag_host, __ATOMIC_ACQUIRE) == 0) return WB_OK;
+  __atomic_store_n(m->split_flag_host, 0, __ATOMIC_RELEASE);
+  m->split_off = 1;
+  return body();
 }
 
 // GEMM against a model weight: `w` supplies the bf16 copy for the speed path (null: f32 kernel only).
@@ -85,6 +101,10 @@ static GemmArgs linear_args(const float* A, int M, const LinearW& w, float* C) {
 }
 
 int run_encoder(wb_model* m, hipStream_t st, Workspace& ws, const MelBatch& mb, float* out_dev, EncoderOut* eo) {
+  return split_guarded(m, st, [&]() { return run_encoder_unguarded(m, st, ws, mb, out_dev, eo); });
+}
+
+int run_encoder_unguarded(wb_model* m, hipStream_t st, Workspace& ws, const MelBatch& mb, float* out_dev, EncoderOut* eo) {
   const wb_dims& D = m->dims;
   const int d = D.n_audio_state, H = D.n_audio_head, nw = (int)mb.T.size();
   WB_REQUIRE(nw > 0, WB_ERR_ARG, "encoder: empty batch");
@@ -181,8 +201,15 @@ int run_encoder(wb_model* m, hipStream_t st, Workspace& ws, const MelBatch& mb, 
   return WB_OK;
 }
 
+static int run_decoder_stateless_body(wb_model* m, hipStream_t st, Workspace& ws, const int32_t* tokens_dev, int n, int L,
+                                      const float* enc_dev, int C, float* logits_dev);
 int run_decoder_stateless(wb_model* m, hipStream_t st, Workspace& ws, const int32_t* tokens_dev, int n, int L,
                           const float* enc_dev, int C, float* logits_dev) {
+  return split_guarded(m, st, [&]() { return run_decoder_stateless_body(m, st, ws, tokens_dev, n, L, enc_dev, C, logits_dev); });
+}
+
+static int run_decoder_stateless_body(wb_model* m, hipStream_t st, Workspace& ws, const int32_t* tokens_dev, int n, int L,
+                                      const float* enc_dev, int C, float* logits_dev) {
   const wb_dims& D = m->dims;
   const int d = D.n_text_state, H = D.n_text_head, NL = D.n_text_layer, V = D.n_vocab;
   const int rows = n * L, krows = n * C, ldkv = NL * 2 * d;

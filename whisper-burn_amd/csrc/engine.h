@@ -1,5 +1,6 @@
 // Encoder / decoder orchestration over the gfx950 kernels (host side).
 #pragma once
+#include <functional>
 #include <vector>
 
 #include "kernels.h"
@@ -22,7 +23,13 @@ struct EncoderOut {
 };
 
 // AudioEncoder::forward (mod.rs:228-260) for a packed batch of ragged windows -> out[rows][d].
+// (guarded: see split_guarded)
 int run_encoder(wb_model* m, hipStream_t st, Workspace& ws, const MelBatch& mb, float* out_dev, EncoderOut* eo);
+int run_encoder_unguarded(wb_model* m, hipStream_t st, Workspace& ws, const MelBatch& mb, float* out_dev, EncoderOut* eo);
+
+// Run `body` (a pass that may use the split-precision GEMM, gemm_f16x3.hip); if that kernel raised its range flag -- an
+// activation outside fp16's range -- the model switches to the exact-f32 kernel for good and the pass runs again.
+int split_guarded(wb_model* m, hipStream_t st, const std::function<int()>& body);
 
 // TextDecoder::forward (mod.rs:131-157), stateless: tokens_dev [n*L], enc_dev [n*C][d] -> logits_dev [n*L][V].
 int run_decoder_stateless(wb_model* m, hipStream_t st, Workspace& ws, const int32_t* tokens_dev, int n, int L,

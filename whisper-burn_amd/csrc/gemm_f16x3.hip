@@ -9,7 +9,10 @@
 // residual of the split itself.  Measured with the oracle as the model (tests/study_split_precision.py): encoder output
 // and decoder log-probs as close to the f64 evaluation as plain f32 is (tiny.en 6.2e-5 vs 6.8e-5, small 4.6e-4 vs 3.3e-4;
 // a bf16 split loses a decade, plain bf16 three).  Range: |x| < 65504 for every operand (encoder activations and weights
-// stay below 10 on every fixture; the scaled low parts stay below the high parts' magnitude).
+// stay below 10 on every fixture; the scaled low parts stay below the high parts' magnitude).  An operand outside that
+// range turns its fp16 piece into inf and the affected outputs into inf / NaN: the epilogue raises GemmArgs::range_flag
+// and the host repeats the pass with the exact-f32 kernel (engine.cpp: split_guarded); weights outside the range never
+// get a split copy (model_load.cpp).
 //
 // The weight comes pre-split and K-contiguous ([N][K] fp16 x 2, made once at model load by split_weight_f16); the
 // activations stay f32 in HBM and are split on their way into LDS.  16x the MFMA rate of the exact-f32 path for three
@@ -104,9 +107,15 @@ __global__ __launch_bounds__(NT, WB_F16X3_MIN_WAVES) void gemm_f16x3_kernel(Gemm
     for (int i = 0; i < A_IT; i++) {
       const int idx = tid + i * NT, k = k0 + (idx % (BK / 8)) * 8;
       float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
-      if (a_row[i] != nullptr && k >= a_klo[i] && k + 7 < a_khi[i]) {   // masks are multiples of 8 for every caller
+      if (a_row[i] != nullptr && k >= a_klo[i] && k + 7 < a_khi[i]) {   // (every caller's masks are multiples of 8)
         lo = *reinterpret_cast<const float4*>(a_row[i] + k);
         hi = *reinterpret_cast<const float4*>(a_row[i] + k + 4);
+      } else if (a_row[i] != nullptr && k + 7 >= a_klo[i] && k < a_khi[i]) {   // an octet that straddles a mask edge: by element
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = (k + e >= a_klo[i] && k + e < a_khi[i]) ? a_row[i][k + e] : 0.f;
+        lo = make_float4(v[0], v[1], v[2], v[3]);
+        hi = make_float4(v[4], v[5], v[6], v[7]);
       }
       ra_lo[i] = lo; ra_hi[i] = hi;
     }
@@ -184,6 +193,7 @@ __global__ __launch_bounds__(NT, WB_F16X3_MIN_WAVES) void gemm_f16x3_kernel(Gemm
 
   // epilogue: batched residual / positional reads from clamped addresses, then arithmetic, then predicated stores
   // (same structure as gemm.hip)
+  bool bad = false;
 #pragma unroll
   for (int i = 0; i < RM; i++)
 #pragma unroll
@@ -214,6 +224,7 @@ __global__ __launch_bounds__(NT, WB_F16X3_MIN_WAVES) void gemm_f16x3_kernel(Gemm
       for (int r = 0; r < 16; r++) {
         const int row = rbase + (r & 3) + 8 * (r >> 2);
         float v = (acc[i][j][r] + acl[i][j][r] * LO_UNSCALE) + bias;
+        bad |= !(fabsf(v) < 3.0e38f);               // inf / NaN: an fp16 piece overflowed (|operand| >= 65504)
         if (g.act == ACT_GELU) v = gelu_erf(v);
         if (g.col_scale_period > 0) v *= cs;
         if (g.residual) v = res[r] + v;
@@ -221,6 +232,8 @@ __global__ __launch_bounds__(NT, WB_F16X3_MIN_WAVES) void gemm_f16x3_kernel(Gemm
         if (col_ok && row < M) Cout[(int64_t)row * g.ldc + col] = v;
       }
     }
+  // range guard: the host re-runs the pass on the exact-f32 kernel and stops using this one (engine.cpp: split_guarded)
+  if (bad && g.range_flag) __hip_atomic_fetch_or(g.range_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 template <int BM, int BN, int WGM, int WGN>

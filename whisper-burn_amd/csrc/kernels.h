@@ -85,6 +85,8 @@ struct GemmArgs {
   int M = 0, N = 0, K = 0;                       // K % 16 == 0
   int act = ACT_NONE;
   int ksplit = 1; int64_t c_split_stride = 0;    // split-K: raw partials of K-slice z go to C + z * c_split_stride
+  int* range_flag = nullptr;                     // split-precision kernel only: set to 1 (system scope) when a result is not
+                                                 // finite, i.e. an operand left fp16's range (|x| >= 65504)
 };
 int launch_gemm_f32(hipStream_t st, const GemmArgs& a);   // exact-f32 MFMA (v_mfma_f32_32x32x2_f32)
 // speed path (gemm_bf16.hip): same contract, weight given as Wt [N][ldwt] bf16 (K-contiguous); a.B ignored

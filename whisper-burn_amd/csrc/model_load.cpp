@@ -417,15 +417,28 @@ int build_model(TensorMap& tm, int device, int compute_dtype, wb_model** out) {
     for (auto& f : fixes) { f.l->wt = b16 + f.wt; if (f.wkn != SIZE_MAX) f.l->wkn = b16 + f.wkn; }
     m->tok_emb_bf = b16 + e_bf; m->tok_emb_t_bf = b16 + et_bf;
   }
-  // ---- exact-f32 models, opt-in (WHISPER_HIP_ENCODER_SPLIT=1): fp16 hi / lo copies of the encoder-side GEMM weights for
-  // the three-product kernel (gemm_f16x3.hip); made on the device, once
-  static const bool split_enabled = []() { const char* e = getenv("WHISPER_HIP_ENCODER_SPLIT"); return e && e[0] == '1'; }();
+  // ---- exact-f32 models: fp16 hi / lo copies of the encoder-side GEMM weights for the three-product kernel
+  // (gemm_f16x3.hip: f32-grade results at ~2x the rate of the exact-f32 MFMA); made on the device, once.
+  // WHISPER_HIP_ENCODER_SPLIT=0 keeps the exact-f32 MFMA kernel for everything.
+  static const bool split_enabled = []() { const char* e = getenv("WHISPER_HIP_ENCODER_SPLIT"); return e ? e[0] == '1' : WB_ENCODER_SPLIT_DEFAULT; }();
   if (compute_dtype != WB_BF16 && split_enabled) {
-    std::vector<LinearW*> ws;
+    std::vector<LinearW*> cand, ws;
     for (int i = 0; i < D.n_audio_layer; i++) {
-      ws.push_back(&m->enc[i].qkv); ws.push_back(&m->enc[i].out); ws.push_back(&m->enc[i].mlp1); ws.push_back(&m->enc[i].mlp2);
+      cand.push_back(&m->enc[i].qkv); cand.push_back(&m->enc[i].out); cand.push_back(&m->enc[i].mlp1); cand.push_back(&m->enc[i].mlp2);
     }
-    ws.push_back(&m->ckv_all);
+    cand.push_back(&m->ckv_all);
+    cand.push_back(&m->conv2);            // K = 3 d: the longest f32 chain of the encoder otherwise (masks are multiples of d)
+    // a weight outside fp16's range keeps the exact-f32 kernel (its hi piece would be inf); weights live in the host image
+    const float* arena_dev = m->arena.as<float>();
+    for (LinearW* l : cand) {
+      const float* hw = B.host.data() + (l->w - arena_dev);
+      bool ok = true;
+      for (size_t i = 0, n = (size_t)l->k * l->n; i < n && ok; i++) ok = std::fabs(hw[i]) < 65000.f;
+      if (ok) ws.push_back(l);
+    }
+    WB_HIP(hipHostMalloc((void**)&m->split_flag_host, 64, hipHostMallocMapped));
+    *m->split_flag_host = 0;
+    WB_HIP(hipHostGetDevicePointer((void**)&m->split_flag_dev, m->split_flag_host, 0));
     size_t total = 0;
     for (LinearW* l : ws) total += ((size_t)l->k * l->n + 127) & ~size_t(127);
     WB_TRY(m->arena_split.alloc(total * 2 * 2));
@@ -434,6 +447,7 @@ int build_model(TensorMap& tm, int device, int compute_dtype, wb_model** out) {
       const size_t n = ((size_t)l->k * l->n + 127) & ~size_t(127);
       l->sh = p; l->sl = p + n; p += 2 * n;
       launch_split_weight_f16(nullptr, l->w, l->k, l->n, l->sh, l->sl);
+      WB_HIP(hipGetLastError());
     }
     WB_HIP(hipDeviceSynchronize());
   }

@@ -158,30 +158,36 @@ static int session_finish_encode(wb_session* s, const MelBatch& mb) {
   for (int t : mb.T) rows += (t - 1) / 2 + 1;
   WB_TRY(s->enc_out.ensure((size_t)rows * d * 4));
   EncoderOut eo;
+  const int rows_all = rows;
+  const int ldkv_all = NL * 2 * d;
+  WB_TRY(s->ckv.ensure((size_t)rows_all * ldkv_all * 4));
+  // encoder + cross-K/V projection under ONE range guard of the split-precision kernel (engine.cpp: split_guarded)
+  WB_TRY(split_guarded(m, s->st, [&]() -> int {
   {
     ScopedTimer tm(s->st, 1);
-    WB_TRY(run_encoder(m, s->st, s->ws, mb, s->enc_out.as<float>(), &eo));
+    WB_TRY(run_encoder_unguarded(m, s->st, s->ws, mb, s->enc_out.as<float>(), &eo));
     tm.stop();
     if (tm.on) { WB_HIP(hipStreamSynchronize(s->st)); tm.collect(); }
   }
-  s->C = eo.C; s->row0 = eo.row0; s->enc_rows = eo.rows;
-  s->maxC = 0;
-  for (int c : s->C) s->maxC = std::max(s->maxC, c);
-  s->n_chunks = (s->maxC + cross_attn_chunk() - 1) / cross_attn_chunk();
-  WB_REQUIRE(s->n_chunks <= CA_NCH_MAX, WB_ERR_SHAPE, "encoder context %d too long for the decode kernels", s->maxC);
-  // cross-attention K|V of every decoder layer, once per window (mod.rs:484-485 does it per layer/beam/step)
-  const int ldkv = NL * 2 * d;
-  WB_TRY(s->ckv.ensure((size_t)rows * ldkv * 4));
   {
     ScopedTimer tm(s->st, 2);
     GemmArgs g;
-    g.A = s->enc_out.as<float>(); g.lda = d; g.B = m->ckv_all.w; g.ldb = ldkv; g.C = s->ckv.as<float>(); g.ldc = ldkv;
-    g.bias = m->ckv_all.b; g.M = rows; g.N = ldkv; g.K = d;
+    g.A = s->enc_out.as<float>(); g.lda = d; g.B = m->ckv_all.w; g.ldb = ldkv_all; g.C = s->ckv.as<float>(); g.ldc = ldkv_all;
+    g.bias = m->ckv_all.b; g.M = rows_all; g.N = ldkv_all; g.K = d;
     g.col_scale = m->qk_scale; g.col_scale_period = 2 * d; g.col_scale_width = d;   // K * s (mod.rs:510-514)
     WB_TRY(gemm_dispatch(m, s->st, g, m->ckv_all.wt, m->ckv_all.k, m->ckv_all.sh, m->ckv_all.sl));
     tm.stop();
     if (tm.on) { WB_HIP(hipStreamSynchronize(s->st)); tm.collect(); }
   }
+  return WB_OK;
+  }));
+  s->C = eo.C; s->row0 = eo.row0; s->enc_rows = eo.rows;
+  s->maxC = 0;
+  for (int c : s->C) s->maxC = std::max(s->maxC, c);
+  s->n_chunks = (s->maxC + cross_attn_chunk() - 1) / cross_attn_chunk();
+  WB_REQUIRE(s->n_chunks <= CA_NCH_MAX, WB_ERR_SHAPE, "encoder context %d too long for the decode kernels", s->maxC);
+  // (cross-attention K|V of every decoder layer, once per window -- mod.rs:484-485 does it per layer / beam / step -- ran
+  // above, under the encoder's range guard)
   std::vector<int> meta(2 * s->W);
   for (int w = 0; w < s->W; w++) { meta[w] = s->row0[w]; meta[s->W + w] = s->C[w]; }
   WB_TRY(s->win_meta.ensure(meta.size() * 4));

@@ -115,6 +115,11 @@ struct Workspace {
 
 }  // namespace wb
 
+// Encoder-side Linear layers of exact-f32 models run on the split-precision kernel (gemm_f16x3.hip) unless
+// WHISPER_HIP_ENCODER_SPLIT=0: as close to the exact result as the f32 MFMA kernel or closer (its K chain is 16 x shorter:
+// profiles/r04_a_diag_*), at about twice the rate.
+constexpr bool WB_ENCODER_SPLIT_DEFAULT = true;
+
 struct wb_model {
   // process-unique, never reused (build_model): the session pool and the captured decode graphs are keyed by it, not by
   // the handle's address -- glibc hands a freed model's address to the next model of the same size
@@ -131,6 +136,10 @@ struct wb_model {
   wb::DevMem arena;
   wb::DevMem arena_bf16;      // WB_BF16: bf16 copies of the GEMM weights
   wb::DevMem arena_split;     // exact-f32 models with the split-precision encoder: fp16 hi / lo copies of the encoder-side weights
+  // range guard of the split-precision kernel: a mapped host word the kernel raises when a result is not finite; once it
+  // has tripped the model stays on the exact-f32 kernel (split_off)
+  int* split_flag_host = nullptr; int* split_flag_dev = nullptr; int split_off = 0;
+  bool split_active() const { return compute_dtype != WB_BF16 && arena_split.p && !split_off; }
   uint16_t* tok_emb_bf = nullptr;     // E   [V][d] bf16 (already K-contiguous for logits = x E^T)
   uint16_t* tok_emb_t_bf = nullptr;   // E^T [d][vocab_ld] bf16
   // encoder
