@@ -123,6 +123,33 @@ def main(which):
         assert wins == rw and got == ref, (which, wins, rw)
         assert len(wins) == (7 if which.endswith("x7") else 4)
         e2.close()
+    elif which == "prodring":
+        # run with lib/libwhisper_hip_emu_prod.so (the product's key ring: CROSS_FUSED_MAX_C = 768): reference-length
+        # windows (C = 745 keys: ONE pass through the ring, the bench's geometry) at d = 384 with two heads' worth of blocks
+        # per row, through the persistent kernel and -- WHISPER_HIP_PERSIST=0 -- the one-launch-per-sublayer chain
+        assert b"prod" in _lib.load().wb_version(), _lib.load().wb_version()
+        dims = synth.micro_dims(n_state=384, n_head=6, n_layer=1, n_vocab=2053)      # n_audio_ctx = 1500: the real window
+        w2 = synth.synth_weights(dims, seed=61)
+        e2, o2 = wb.Whisper.from_tensors(w2), OracleWhisper(w2)
+        s2 = wb.SpecialTokens.for_vocab(2053)
+        a = synth.synth_audio(16000 * 17, 47)                                            # 2 windows: 745 and 260 keys
+        got, wins = wb.waveform_to_tokens(e2, s2, a, 16000, 1, 6)
+        ref, rw = otr.waveform_to_tokens(o2, pu.ost(s2), a, 16000, 1, 6, return_windows=True)
+        assert got == ref and wins == rw and len(wins) == 2, (got, ref, wins, rw)
+        e2.close()
+    elif which == "prodring30":
+        # ... and the opt-in 30 s window (C = 1500 keys: TWO passes through the 768-key ring)
+        assert b"prod" in _lib.load().wb_version(), _lib.load().wb_version()
+        dims = synth.micro_dims(n_state=384, n_head=6, n_layer=1, n_vocab=2053)
+        w2 = synth.synth_weights(dims, seed=63)
+        e2, o2 = wb.Whisper.from_tensors(w2), OracleWhisper(w2, frame_limit_x2=True)
+        e2.set_frame_limit(True)
+        s2 = wb.SpecialTokens.for_vocab(2053)
+        a = synth.synth_audio(16000 * 31, 49)                                            # one 29.9 s window + its tail
+        got, wins = wb.waveform_to_tokens(e2, s2, a, 16000, 1, 5)
+        ref, rw = otr.waveform_to_tokens(o2, pu.ost(s2), a, 16000, 1, 5, return_windows=True)
+        assert got == ref and wins == rw and len(wins) == 2, (got, ref, wins, rw)
+        e2.close()
     elif which == "split_range":
         # range guard of the split-precision encoder GEMM (gemm_f16x3.hip): an activation outside fp16's range (here the
         # GELU output that feeds the first block's second MLP matrix, pushed to ~1e5 by its bias) makes an fp16 piece inf;

@@ -27,6 +27,15 @@ def emu_lib():
     return EMU_LIB
 
 
+@pytest.fixture(scope="module")
+def emu_lib_prod(emu_lib):
+    """The second functional-model library: the same sources with the PRODUCT's geometry constants (decode.h:
+    CROSS_FUSED_MAX_C = 768 instead of the 384-key ring the micro-model library compiles)."""
+    subprocess.run(["make", "-C", EMU_DIR, "-j", str(min(8, os.cpu_count() or 1)), "prod"], check=True,
+                   stdout=subprocess.DEVNULL)
+    return os.path.join(os.path.dirname(emu_lib), "libwhisper_hip_emu_prod.so")
+
+
 def _spawn(emu_lib, which, extra_env=None, allow=True):
     env = dict(os.environ)
     env["WHISPER_HIP_LIB"] = emu_lib
@@ -160,6 +169,17 @@ def test_batch_mode_skinny_gemm_and_fused_streaming_blocks(emu_lib, which, env):
     replaces runs too: test_chained_greedy_windows_ending_at_different_steps).  Token-exact against the oracle."""
     p = _run(emu_lib, which, env)
     assert p.returncode == 0 and f"EMU_CHECK_OK {which}" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
+def test_production_key_ring_under_the_functional_model(emu_lib_prod):
+    """The micro-model library compiles a 384-key ring so that small fixtures reach both of its code paths; the PRODUCT
+    compiles 768 keys.  This runs the product's constant (`make prod`) at the real window lengths: C = 745 keys in one
+    pass (the bench's geometry) and C = 1500 keys in two (the opt-in 30 s window), d = 384, persistent kernel and chain."""
+    jobs = [("prodring", {}), ("prodring", {"WHISPER_HIP_PERSIST": "0"}), ("prodring30", {})]
+    futs = [_POOL.submit(_spawn, emu_lib_prod, which, env) for which, env in jobs]       # side by side
+    for (which, env), f in zip(jobs, futs):
+        p = f.result()
+        assert p.returncode == 0 and f"EMU_CHECK_OK {which}" in p.stdout, (which, env, p.stdout[-2000:] + p.stderr[-4000:])
 
 
 @pytest.mark.parametrize("env", [{}, {"WHISPER_HIP_PERSIST": "0"}])

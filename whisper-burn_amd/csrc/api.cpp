@@ -61,7 +61,9 @@ using namespace wb;
 extern "C" {
 
 const char* wb_last_error(void) { return wb::get_error(); }
-#ifdef HIPEMU   // tools/hipemu: the host build against the functional model (test infrastructure, refused by the binding)
+#if defined(HIPEMU) && defined(HIPEMU_PROD_GEOMETRY)
+const char* wb_version(void) { return "whisper_hip 0.1 (hipemu functional model, prod geometry -- NOT a product build)"; }
+#elif defined(HIPEMU)   // tools/hipemu: the host build against the functional model (test infrastructure, refused by the binding)
 const char* wb_version(void) { return "whisper_hip 0.1 (hipemu functional model -- NOT a product build)"; }
 #else
 const char* wb_version(void) { return "whisper_hip 0.1 (gfx950)"; }
