@@ -272,6 +272,37 @@ int wb_waveform_to_tokens_dev(wb_model* m, const float* pcm_dev, int64_t n, int 
                               int win_end, int32_t* win_tokens, int32_t row_stride, int32_t* win_lens,
                               int32_t* stitched, int64_t stitched_cap, int64_t* n_stitched);
 
+/* ---- multi-GPU: windows sharded over ranks -------------------------------------------------------
+ * The reference is single-device and decodes its windows one after another (transcribe.rs:35-66); they are independent
+ * (the previous-window prompt is discarded, transcribe.rs:195-201), so rank r of R decodes the contiguous block
+ * [ceil(r K / R), ceil((r + 1) K / R)) of the K windows and the ranks exchange ONE fixed-shape buffer of token rows;
+ * every rank then folds the stitch (transcribe.rs:56-63) over all K rows -- identical to world size 1 by construction.
+ *
+ * The exchange is an all-gather the caller supplies: `send` holds bytes_per_rank bytes of this rank, `recv` receives
+ * world x bytes_per_rank bytes in rank order (host memory both).  wb_comm_allgather is the built-in RCCL transport
+ * (RCCL over xGMI; librccl is opened at run time, on first use): rank 0 makes an id with wb_comm_unique_id and ships its
+ * 128 bytes to the other ranks by its own means (a file, a socket, MPI, torch.distributed ...), every rank calls
+ * wb_comm_init with its own device, and passes (wb_comm_allgather, comm) below. */
+typedef int (*wb_allgather_fn)(void* user, const void* send, void* recv, int64_t bytes_per_rank);
+typedef struct wb_comm wb_comm;
+int wb_comm_unique_id(uint8_t* id128);
+int wb_comm_init(const uint8_t* id128, int rank, int world, int device, wb_comm** out);
+void wb_comm_free(wb_comm* c);
+int wb_comm_allgather(void* comm, const void* send, void* recv, int64_t bytes_per_rank);
+
+/* The block of rank `rank`: [*lo, *hi) = [ceil(rank K / world), ceil((rank + 1) K / world)). */
+int wb_shard_partition(int64_t n_windows, int rank, int world, int64_t* lo, int64_t* hi);
+
+/* waveform_to_text (transcribe.rs:23-74) without the tokenizer, sharded: this rank decodes its block of windows of the
+ * WHOLE waveform `pcm` (host memory, or device memory of the model's GPU when pcm_on_device != 0), all-gathers the
+ * rows and stitches.  On return EVERY rank holds all K per-window rows (win_tokens [K][row_stride], win_lens [K],
+ * K <= win_cap) and the stitched stream.  world == 1 needs no all-gather (allgather may be NULL). */
+int wb_waveform_to_tokens_sharded(wb_model* m, const float* pcm, int pcm_on_device, int64_t n, int sample_rate,
+                                  const wb_decode_params* p, const uint8_t* is_special, int rank, int world,
+                                  wb_allgather_fn allgather, void* user, int32_t* win_tokens, int32_t row_stride,
+                                  int32_t* win_lens, int64_t win_cap, int32_t* stitched, int64_t stitched_cap,
+                                  int64_t* n_stitched);
+
 /* Window extents of waveform_to_mel_tensor (transcribe.rs:114-128).  Returns the window
  * count; fills starts/lens when non-NULL (capacity cap). */
 int64_t wb_window_extents(int64_t n_samples, int sample_rate, int64_t window_len, int overlap_seconds,

@@ -12,6 +12,10 @@ pub struct wb_model {
 pub struct wb_session {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct wb_comm {
+    _private: [u8; 0],
+}
 
 #[repr(C)]
 #[derive(Default, Clone, Copy, Debug, PartialEq, Eq)]
@@ -92,8 +96,28 @@ extern "C" {
     pub fn wb_resample_len(n_in: i64, rate_in: i32, rate_out: i32) -> i64;
     pub fn wb_resample_dev(device: c_int, src_dev: *const c_float, n_in: i64, rate_in: i32, rate_out: i32,
                            dst_dev: *mut c_float, capacity: i64, n_out: *mut i64) -> c_int;
+    pub fn wb_comm_unique_id(id128: *mut u8) -> c_int;
+    pub fn wb_comm_init(id128: *const u8, rank: c_int, world: c_int, device: c_int, out: *mut *mut wb_comm) -> c_int;
+    pub fn wb_comm_free(c: *mut wb_comm);
+    pub fn wb_comm_allgather(comm: *mut c_void, send: *const c_void, recv: *mut c_void, bytes_per_rank: i64) -> c_int;
+    pub fn wb_shard_partition(n_windows: i64, rank: c_int, world: c_int, lo: *mut i64, hi: *mut i64) -> c_int;
+    pub fn wb_waveform_to_tokens_sharded(m: *mut wb_model, pcm: *const c_float, pcm_on_device: c_int, n: i64,
+                                         sample_rate: c_int, p: *const wb_decode_params, is_special: *const u8,
+                                         rank: c_int, world: c_int, allgather: wb_allgather_fn, user: *mut c_void,
+                                         win_tokens: *mut i32, row_stride: i32, win_lens: *mut i32, win_cap: i64,
+                                         stitched: *mut i32, stitched_cap: i64, n_stitched: *mut i64) -> c_int;
     pub fn wb_last_error() -> *const c_char;
     pub fn wb_version() -> *const c_char;
+}
+
+/// The exchange of the sharded path: `send` = this rank's bytes, `recv` = world x bytes_per_rank bytes in rank order.
+pub type wb_allgather_fn = Option<unsafe extern "C" fn(user: *mut c_void, send: *const c_void, recv: *mut c_void,
+                                                       bytes_per_rank: i64) -> c_int>;
+
+/// `wb_comm_allgather` under the callback's exact type (same symbol, `comm` as the user pointer).
+pub unsafe extern "C" fn wb_comm_allgather_thunk(user: *mut c_void, send: *const c_void, recv: *mut c_void,
+                                                  bytes_per_rank: i64) -> c_int {
+    wb_comm_allgather(user, send, recv, bytes_per_rank)
 }
 
 /// Opaque user pointer type of callbacks (kept for completeness of the C vocabulary).

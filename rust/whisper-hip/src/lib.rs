@@ -209,3 +209,66 @@ pub fn waveform_to_text<T: Tokenizer>(whisper: &Whisper, bpe: &T, lang: T::Lang,
     let text = bpe.decode(&tokens[..], true)?; // transcribe.rs:67
     Ok((text, tokens))
 }
+
+
+/// One rank of the multi-GPU path (not in the reference, which is single-device): the reference's windows are
+/// independent (transcribe.rs:195-201), so rank `rank` of `world` decodes its contiguous block of them, the ranks
+/// exchange ONE buffer of token rows (RCCL over xGMI through `comm`) and every rank stitches all rows
+/// (transcribe.rs:56-63) -- the result equals `waveform_to_text` on one GPU.
+pub struct Comm { raw: *mut ffi::wb_comm }
+impl Comm {
+    /// Rank 0 makes the id and ships its 128 bytes to the other ranks (a file, a socket, MPI ...).
+    pub fn unique_id() -> Result<[u8; 128]> {
+        let mut id = [0u8; 128];
+        check(unsafe { ffi::wb_comm_unique_id(id.as_mut_ptr()) })?;
+        Ok(id)
+    }
+    pub fn new(id: &[u8; 128], rank: i32, world: i32, device: i32) -> Result<Comm> {
+        let mut raw: *mut ffi::wb_comm = std::ptr::null_mut();
+        check(unsafe { ffi::wb_comm_init(id.as_ptr(), rank as c_int, world as c_int, device as c_int, &mut raw) })?;
+        Ok(Comm { raw })
+    }
+}
+impl Drop for Comm {
+    fn drop(&mut self) { unsafe { ffi::wb_comm_free(self.raw) } }
+}
+
+pub fn waveform_to_text_sharded<T: Tokenizer>(whisper: &Whisper, bpe: &T, lang: T::Lang, waveform: Vec<f32>,
+                                              sample_rate: usize, rank: i32, world: i32, comm: &Comm)
+                                              -> Result<(String, Vec<usize>)> {
+    let mut p = ffi::wb_decode_params::default();
+    unsafe { ffi::wb_decode_params_default(&mut p) };
+    let id = |t: SpecialToken<T::Lang>| -> Result<i32> {
+        bpe.special_token_id(t).map(|v| v as i32).ok_or_else(|| "special token missing from the tokenizer".into())
+    };
+    p.tok_start_of_transcript = id(SpecialToken::StartofTranscript)?;
+    p.tok_language = id(SpecialToken::Language(lang))?;
+    p.tok_transcribe = id(SpecialToken::Transcribe)?;
+    p.tok_no_timestamps = id(SpecialToken::NoTimeStamps)?;
+    p.tok_end_of_text = id(SpecialToken::EndofText)?;
+    if bpe.vocab_size() != whisper.dims.n_vocab as usize {
+        return Err(format!("tokenizer vocabulary ({}) and model vocabulary ({}) differ", bpe.vocab_size(),
+                           whisper.dims.n_vocab).into());
+    }
+    let is_special: Vec<u8> = (0..whisper.dims.n_vocab as usize).map(|t| bpe.is_special(t) as u8).collect();
+    let wlen = max_waveform_samples(whisper.encoder_ctx_size() - p.padding as usize) as i64;
+    let n_win = unsafe {
+        ffi::wb_window_extents(waveform.len() as i64, sample_rate as c_int, wlen, p.overlap_seconds,
+                               std::ptr::null_mut(), std::ptr::null_mut(), 0)
+    } as usize;
+    let stride = (4 + p.max_depth + 4) as usize;
+    let mut rows = vec![0i32; n_win.max(1) * stride];
+    let mut lens = vec![0i32; n_win.max(1)];
+    let mut out = vec![0i32; n_win.max(1) * stride];
+    let mut n_out: i64 = 0;
+    check(unsafe {
+        ffi::wb_waveform_to_tokens_sharded(whisper.raw, waveform.as_ptr(), 0, waveform.len() as i64, sample_rate as c_int,
+                                           &p, is_special.as_ptr(), rank as c_int, world as c_int,
+                                           Some(ffi::wb_comm_allgather_thunk), comm.raw as *mut std::os::raw::c_void,
+                                           rows.as_mut_ptr(), stride as i32, lens.as_mut_ptr(), n_win.max(1) as i64,
+                                           out.as_mut_ptr(), out.len() as i64, &mut n_out)
+    })?;
+    let tokens: Vec<usize> = out[..n_out as usize].iter().map(|&t| t as usize).collect();
+    let text = bpe.decode(&tokens[..], true)?;
+    Ok((text, tokens))
+}

@@ -36,6 +36,20 @@ def _shard_worker(rank, world, port, q):
             return wb.waveform_to_tokens(eng, st, a, 16000, 1, 8, win_begin=lo, win_end=hi)[1]
 
         toks, wins = shard.transcribe_sharded(decode_local, wb.stitch_windows, n_win, rank, world, row)
+        # ... and the same path behind the C ABI (csrc/shard.cpp: wb_waveform_to_tokens_sharded), the exchange handed in as a
+        # callback -- here gloo's all-gather; on GPUs the library's own RCCL transport (wb_comm_allgather)
+        import torch as _t
+
+        def gather(local):
+            t = _t.from_numpy(np.ascontiguousarray(local))
+            out = _t.empty(world * t.numel(), dtype=t.dtype)
+            dist.all_gather_into_tensor(out, t)
+            return out.numpy().reshape(world, -1)
+
+        ctoks, cwins = shard.waveform_to_tokens_sharded(eng, st, a, rank, world, allgather=gather,
+                                                        params=wb.decode_params(st, 1, 8))
+        assert ctoks == toks and cwins == wins, (rank, ctoks, toks)
+        assert shard.c_partition_windows(n_win, rank, world) == shard.partition_windows(n_win, rank, world)
         q.put((rank, n_win, toks, wins))
         eng.close()
     finally:

@@ -220,6 +220,13 @@ def test_partition_windows_is_a_contiguous_cover(n, world):
     assert max(b - a for a, b in blocks) <= shard.rows_per_rank(n, world)
 
 
+@given(st_.integers(0, 2000), st_.integers(1, 64))
+def test_c_abi_partition_equals_the_python_one(n, world):
+    """wb_shard_partition (what a Rust / C caller of the sharded entry point uses) = shard.partition_windows."""
+    for r in sorted({0, world // 2, world - 1}):
+        assert shard.c_partition_windows(n, r, world) == shard.partition_windows(n, r, world)
+
+
 @given(st_.integers(1, 6_000_000), st_.integers(1, 9))
 @settings(max_examples=200, deadline=None)
 def test_rank_pcm_span_reproduces_the_rank_windows(n, world):

@@ -61,7 +61,8 @@ def struct_fields_rust(r, name):
 C_SCALARS = {"int": "c_int", "int32_t": "i32", "int64_t": "i64", "uint8_t": "u8", "uint16_t": "u16", "uint32_t": "u32",
              "uint64_t": "u64", "float": "c_float", "double": "c_double", "char": "c_char", "void": "c_void",
              "size_t": "usize", "wb_model": "wb_model", "wb_session": "wb_session", "wb_dims": "wb_dims",
-             "wb_decode_params": "wb_decode_params", "wb_kernel_stat": "wb_kernel_stat"}
+             "wb_decode_params": "wb_decode_params", "wb_kernel_stat": "wb_kernel_stat", "wb_comm": "wb_comm",
+             "wb_allgather_fn": "wb_allgather_fn"}
 RUST_EQUIV = {"c_int": {"c_int", "i32"}, "i32": {"i32", "c_int"}, "c_float": {"c_float", "f32"}, "c_double": {"c_double", "f64"}}
 
 

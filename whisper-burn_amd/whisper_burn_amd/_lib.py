@@ -36,6 +36,9 @@ class WbDecodeParams(C.Structure):
 STEP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, c_int32_p, c_int32_p, c_int32_p, C.c_int, C.c_int, C.c_int,
                       c_int32_p, c_float_p)
 
+# wb_allgather_fn (include/whisper_hip.h)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
+
 # every symbol include/whisper_hip.h declares: name -> (restype, argtypes)
 TENSOR_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, c_float_p, c_int64_p, C.c_int32)
 
@@ -66,6 +69,14 @@ SIGNATURES = {
     "wb_forward_decoder": (C.c_int, [C.c_void_p, c_int32_p, C.c_int, C.c_int, c_float_p, C.c_int, c_float_p]),
     "wb_forward": (C.c_int, [C.c_void_p, c_float_p, C.c_int, C.c_int, c_int32_p, C.c_int, c_float_p]),
     "wb_decode_params_default": (None, [C.POINTER(WbDecodeParams)]),
+    "wb_comm_unique_id": (C.c_int, [c_uint8_p]),
+    "wb_comm_init": (C.c_int, [c_uint8_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "wb_comm_free": (None, [C.c_void_p]),
+    "wb_comm_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "wb_shard_partition": (C.c_int, [C.c_int64, C.c_int, C.c_int, c_int64_p, c_int64_p]),
+    "wb_waveform_to_tokens_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.POINTER(WbDecodeParams),
+                                               c_uint8_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, c_int32_p, C.c_int32,
+                                               c_int32_p, C.c_int64, c_int32_p, C.c_int64, c_int64_p]),
     "wb_session_begin": (C.c_int, [C.c_void_p, c_float_p, C.c_int64, c_int64_p, c_int64_p, C.c_int, C.c_int,
                                    C.c_int, C.POINTER(C.c_void_p)]),
     "wb_session_begin_mel": (C.c_int, [C.c_void_p, c_float_p, c_int32_p, C.c_int, C.c_int, C.c_int,
