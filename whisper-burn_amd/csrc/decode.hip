@@ -125,8 +125,24 @@ __global__ __launch_bounds__(256) void dec_resolve_ln_kernel(const int* __restri
                                                              int eps_inside_sqrt, float* __restrict__ h) {
   __shared__ float red[8];
   const int r = blockIdx.x;
-  if (r >= st[ST_N]) return;
   const int tid = threadIdx.x;
+  // One memory round trip: the live-row count, the row, every pending plane, the bias and the LayerNorm parameters are
+  // requested before the first use of any of them, and the folded stream is stored last (the launch was 6.6 us for ~1.5 MB
+  // at large-v2's 38 rows, three dependent round trips of it: profiles/r03_m_layer_cycle_large_v2.txt).  Columns past d
+  // and planes past KS alias valid elements and are never used.
+  const int n_live = st[ST_N];
+  float xv[VPT], gv[VPT], bv[VPT], biasv[VPT], t[VPT][KS_MAX];
+  const int64_t plane = (int64_t)S * d;
+#pragma unroll
+  for (int i = 0; i < VPT; i++) {
+    const int c = tid + i * 256, cc = c < d ? c : tid;
+    xv[i] = x_in[(int64_t)r * d + cc];
+    gv[i] = g[cc]; bv[i] = b[cc];
+    biasv[i] = KS > 0 ? bias[cc] : 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < KS_MAX; s2++) t[i][s2] = (s2 < KS) ? P[(int64_t)s2 * plane + (int64_t)r * d + cc] : 0.f;
+  }
+  if (r >= n_live) return;
   float v[VPT];
   float s = 0.f;
 #pragma unroll
@@ -134,9 +150,13 @@ __global__ __launch_bounds__(256) void dec_resolve_ln_kernel(const int* __restri
     const int c = tid + i * 256;
     v[i] = 0.f;
     if (c < d) {
-      float a = x_in[(int64_t)r * d + c];
-      if (KS > 0) a = a + fold_partials(P, KS, (int64_t)S * d, (int64_t)r * d + c, bias[c]);   // mod.rs:346-348
-      x_out[(int64_t)r * d + c] = a;
+      float a = xv[i];
+      if (KS > 0) {                                  // x + (bias + partials), s ascending (mod.rs:346-348)
+        float acc = biasv[i];
+#pragma unroll
+        for (int s2 = 0; s2 < KS_MAX; s2++) acc += t[i][s2];
+        a = a + acc;
+      }
       v[i] = a;
       s += a;
     }
@@ -159,7 +179,10 @@ __global__ __launch_bounds__(256) void dec_resolve_ln_kernel(const int* __restri
 #pragma unroll
   for (int i = 0; i < VPT; i++) {
     const int c = tid + i * 256;
-    if (c < d) h[(int64_t)r * d + c] = (v[i] - mean) / denom * g[c] + b[c];
+    if (c < d) {
+      h[(int64_t)r * d + c] = (v[i] - mean) / denom * gv[i] + bv[i];
+      x_out[(int64_t)r * d + c] = v[i];
+    }
   }
 }
 
@@ -1242,12 +1265,14 @@ void launch_dec_prepare(hipStream_t st, const int* state_host_mapped, int* state
 void launch_dec_resolve_ln(hipStream_t st, const int* state, int n_max, const float* x_in, float* x_out,
                            const float* P, int KS, int S, const float* bias, int d, const LayerNormW& ln,
                            int eps_inside_sqrt, float* h) {
-  if (d <= 1024)
-    WB_KLAUNCH(dec_resolve_ln_kernel<4>, dim3(n_max), dim3(256), 0, st, state, x_in, x_out, P, KS, S, bias, d,
-                       ln.g, ln.b, ln.eps, eps_inside_sqrt, h);
-  else
-    WB_KLAUNCH(dec_resolve_ln_kernel<8>, dim3(n_max), dim3(256), 0, st, state, x_in, x_out, P, KS, S, bias, d,
-                       ln.g, ln.b, ln.eps, eps_inside_sqrt, h);
+#define WB_RESOLVE(VPT_)                                                                                                \
+  WB_KLAUNCH(dec_resolve_ln_kernel<VPT_>, dim3(n_max), dim3(256), 0, st, state, x_in, x_out, P, KS, S, bias, d, ln.g, ln.b, \
+             ln.eps, eps_inside_sqrt, h)
+  if (d <= 768) WB_RESOLVE(3);            // (columns per thread: every one of them is a real load per plane)
+  else if (d <= 1024) WB_RESOLVE(4);
+  else if (d <= 1280) WB_RESOLVE(5);
+  else WB_RESOLVE(8);
+#undef WB_RESOLVE
 }
 
 void gemv_plan(int K, int N, int* KS, int* KSL) {

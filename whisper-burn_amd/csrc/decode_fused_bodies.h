@@ -28,6 +28,11 @@ struct PsStep {
   int n_ctr = 1;                 // the wait covers n_ctr consecutive counters (HX_LINE apart), all with `target`
   // granule tags (handoff.h): what the role's producers stamp their planes with / what the role stamps its own output with
   unsigned tag_in = 0, tag_out = 0;
+  // a row's window has ended: in = the block has seen this role's row dead in an earlier step (it stays dead: the role
+  // requests nothing before its wait -- the weight / cached-K prefetch of dead rows was most of the launch's traffic above
+  // the necessary bytes, profiles/r03_d_pmc_traffic_tiny_en_30s.json); out = the role found its row dead this step
+  bool known_dead = false;
+  mutable bool saw_dead = false;
 };
 constexpr int PS_STAMPS = 8;     // 0 role start, 1 wait passed, 2-5 phases inside the role, 6 done, 7 arrived
 __device__ __forceinline__ void ps_stamp(const PsStep& ps, int k) {
@@ -206,6 +211,27 @@ __device__ __forceinline__ void ln_row_lds(float* __restrict__ row, int d, int l
   for (int i = 0; i < DPL; i++) row[lane + 64 * i] = (v[i] - mean) / denom * gv[i] + bv[i];
 }
 
+// LayerNorm statistics of a row held in LDS, computed by EVERY wave for itself (same loads, same reductions as ln_row_lds:
+// identical bits in every wave), so that a wave can normalise the few elements its own matrix rows need and go on without
+// a second block barrier -- wave 0 normalising the whole row for everybody cost a barrier-delimited phase (~0.5 us of a
+// 10 us role in the persistent kernel, profiles/r03_g_ps_fine.txt).  Returns mean and 1-divisor through `mean`, `denom`.
+template <int DPL>
+__device__ __forceinline__ void ln_stats_lds(const float* __restrict__ row, int d, int lane, float eps, int eps_inside,
+                                             float& mean, float& denom) {
+  float v[DPL];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < DPL; i++) { v[i] = row[lane + 64 * i]; s += v[i]; }
+  mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < DPL; i++) { const float t = v[i] - mean; q += t * t; }
+  const float var = wave_sum(q) / (float)d;
+  denom = eps_inside ? sqrtf(var + eps) : (sqrtf(var) + eps);
+}
+// value of lane `src` (wave-uniform or per-lane) of a register: the LDS crossbar without LDS memory (ds_bpermute_b32)
+__device__ __forceinline__ float lane_get(float v, int src) { return __shfl(v, src, 64); }
+
 // ---------------------------------------------------------------------------------------------------------
 // MLP.  block = 512 threads, grid = 4 d / 64.  Every global load of the block (fold operands, the W1 slice, the
 // W2 slice) is requested before the first use of any of them: one memory round trip on the critical path.
@@ -241,7 +267,11 @@ __device__ __forceinline__ bool dec_mlp_body(const MlpFusedArgs& a, const int jb
   const bool p2 = jg < G;
   const int jb = (p2 ? jg : 0) * RPG;
   float4 w2[RPG];
-  float gv[DPL], bv[DPL];
+  // LayerNorm parameters of the NW1 * 4 columns this wave's W1 rows need: lane l < 4 NW1 owns column 4 wave + (l & 3) +
+  // 32 (l >> 2) = row rg + 32 i of thread group (rg = 4 wave + (l & 3), i = l >> 2)
+  constexpr int NOWN = 4 * NW1;
+  const int own_col = 4 * wave + (lane & 3) + 32 * ((lane < NOWN ? lane : 0) >> 2);
+  float g_own = 0.f, b_own = 0.f;
   float b1v;
   int deadm = 0;                                   // (persistent mode) bit r: row r takes no part (its window has ended)
   {
@@ -264,8 +294,7 @@ __device__ __forceinline__ bool dec_mlp_body(const MlpFusedArgs& a, const int jb
     const int npl = a.KSp;
     const int ch = rec ? PCHR : PCH;                 // planes per round
     auto load_weights = [&]() {                      // LayerNorm parameters, bias, the W1 slice, the W2 slice
-#pragma unroll
-      for (int i = 0; i < DPL; i++) { gv[i] = a.ln_g[lane + 64 * i]; bv[i] = a.ln_b[lane + 64 * i]; }
+      g_own = a.ln_g[own_col]; b_own = a.ln_b[own_col];
       b1v = a.b1[j0 + (tid & 63)];
       {
         const float* wp = a.W1 + (int64_t)rg * a.ld1 + j0 + c4;
@@ -415,33 +444,38 @@ __device__ __forceinline__ bool dec_mlp_body(const MlpFusedArgs& a, const int jb
   WB_STAMP(1);
   __syncthreads();
   if constexpr (PS) { if (!ps_sweeps_ok(ps)) return false; }
-  if (wave < MR) ln_row_lds<DPL>(hs[wave], d, lane, gv, bv, a.ln_eps, a.ln_inside);
-  __syncthreads();
+  // LayerNorm: every wave takes the statistics of every (live) row itself and normalises the columns its own W1 rows
+  // multiply -- no second barrier; the normalised values stay in registers (lane l: column own_col) and reach the
+  // thread groups through the LDS crossbar (lane 4 i + q holds row rg + 32 i of group q = lane / 16)
+  float xn_own[MR];
+#pragma unroll
+  for (int r = 0; r < MR; r++) {
+    xn_own[r] = 0.f;
+    bool skip = r >= n_rows;
+    if constexpr (PS) skip = skip || ((deadm >> r) & 1);
+    if (skip) continue;                              // (block-uniform)
+    float mean, denom;
+    ln_stats_lds<DPL>(hs[r], d, lane, a.ln_eps, a.ln_inside, mean, denom);
+    xn_own[r] = (hs[r][own_col] - mean) / denom * g_own + b_own;
+  }
   WB_STAMP(2);
   float acc[MR][4];
 #pragma unroll
   for (int r = 0; r < MR; r++) { acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.f; }
-  if constexpr (PS) {
-    // (rows whose window has ended cost nothing: block-uniform branches around their FMAs)
+  {
+    const int q4 = lane >> 4;
+    // (rows that take no part cost nothing: block-uniform branches around their FMAs)
 #pragma unroll
     for (int r = 0; r < MR; r++) {
-      if ((deadm >> r) & 1) continue;
+      bool skip = r >= n_rows;
+      if constexpr (PS) skip = skip || ((deadm >> r) & 1);
+      if (skip) continue;
 #pragma unroll
       for (int i = 0; i < NW1; i++) {
-        const float xv = hs[r][rg + 32 * i];
+        const float xv = lane_get(xn_own[r], 4 * i + q4);
         acc[r][0] += xv * w1[i].x; acc[r][1] += xv * w1[i].y; acc[r][2] += xv * w1[i].z; acc[r][3] += xv * w1[i].w;
       }
     }
-  } else {
-#pragma unroll
-  for (int i = 0; i < NW1; i++) {
-    const int k = rg + 32 * i;
-#pragma unroll
-    for (int r = 0; r < MR; r++) {
-      const float xv = hs[r][k];
-      acc[r][0] += xv * w1[i].x; acc[r][1] += xv * w1[i].y; acc[r][2] += xv * w1[i].z; acc[r][3] += xv * w1[i].w;
-    }
-  }
   }
   // lanes l, l ^ 16, l ^ 32, l ^ 48 hold the same columns for different rows: fold them, then the eight waves
 #pragma unroll
@@ -589,7 +623,9 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
     for (int j = 0; j < RK; j++) w[j] = *reinterpret_cast<const float4*>(wq + (int64_t)(RK * it + j) * a.ldqkv);
   };
   float xfold;                                     // this thread's element of x + pending (kept for the final x_out store)
-  float gv[DPL], bv[DPL];                          // LayerNorm parameters (wave 0 normalises)
+  // LayerNorm parameters of the KW rows of x this wave's QKV rounds multiply: lane l < KW owns row wave KW + l
+  const int own_col = wave * KW + (lane < KW ? lane : 0);
+  float g_own = 0.f, b_own = 0.f;
   float qbias = 0.f;
   // ---- the cached K / V rows of the first 128 positions, the coalesced way (16 lanes x 16 B = one 256-byte head row;
   // thread (rg, pq4) holds quad pq4 of positions rg + 32 i): requested behind the first two weight rounds, so that they
@@ -623,10 +659,7 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
     const float* pp = a.pend + (int64_t)r * d + c;
     const int64_t plane = (int64_t)a.S * d;
     auto load_weights = [&]() {
-      if (wave == 0) {
-#pragma unroll
-        for (int i = 0; i < DPL; i++) { gv[i] = a.ln_g[lane + 64 * i]; bv[i] = a.ln_b[lane + 64 * i]; }
-      }
+      g_own = a.ln_g[own_col]; b_own = a.ln_b[own_col];
       load_round(wr[0], 0);
       if (NIT > 1) load_round(wr[1], 1);
       if constexpr (PS) { if (tid < 192) qbias = a.bqkv[(tid >> 6) * d + h * 64 + (tid & 63)]; }
@@ -635,11 +668,13 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
       // persistent mode: the first weight rounds are in flight (or landed) while the block waits; the wait is a PRE-wake
       // (the stage before the producers has finished) -- the planes themselves arrive as tagged granules, re-read until
       // every tag is the producers' (arrival and payload in one round trip)
-      load_weights();
-      load_cache_tile();
+      if (!ps.known_dead) {
+        load_weights();
+        load_cache_tile();
+      }
       if (!ps_wait(ps)) return false;
-      dead = ld_i<true>(ps.dead + r);
-      if (r >= n_rows || dead) return true;
+      dead = ps.known_dead ? 1 : ld_i<true>(ps.dead + r);
+      if (r >= n_rows || dead) { ps.saw_dead = true; return true; }
       const Buf16 xgb(a.g_x_in), pgb(a.g_pend);
       const uint32_t pvo = (uint32_t)(r * d + c);
       const int iplane = a.S * d;
@@ -709,8 +744,14 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
   if constexpr (PS) ps_stamp(ps, 2);
   __syncthreads();
   if constexpr (PS) { if (!ps_sweeps_ok(ps)) return false; }
-  if (wave == 0) ln_row_lds<DPL>(hs, d, lane, gv, bv, a.ln_eps, a.ln_inside);
-  __syncthreads();
+  // LayerNorm: every wave takes the row's statistics itself and normalises its own KW rows into a register (lane l: row
+  // wave KW + l) -- no second barrier; the QKV loop broadcasts them with v_readlane
+  float xn_own;
+  {
+    float mean, denom;
+    ln_stats_lds<DPL>(hs, d, lane, a.ln_eps, a.ln_inside, mean, denom);
+    xn_own = (hs[own_col] - mean) / denom * g_own + b_own;
+  }
   if constexpr (PS) ps_stamp_fine(ps, 4);
   WB_STAMP(2);
   // ---- QKV for head h (rolled on purpose: unrolled, every round's loads are hoisted to the top and spill)
@@ -720,10 +761,10 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
 #pragma unroll
     for (int b = 0; b < 2; b++) {
       if (it + b < NIT) {
-        const int kb = wave * KW + RK * (it + b);
+        const int kb = RK * (it + b);              // (row of the wave's own KW = lane that holds it)
 #pragma unroll
         for (int j = 0; j < RK; j++) {
-          const float xv = hs[kb + j];
+          const float xv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xn_own), kb + j));
           acc[0] += xv * wr[b][j].x; acc[1] += xv * wr[b][j].y; acc[2] += xv * wr[b][j].z; acc[3] += xv * wr[b][j].w;
         }
         if (it + b + 2 < NIT) load_round(wr[b], it + b + 2);
@@ -933,17 +974,18 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
   const int vC8 = a.win_C[wi8], vR8 = a.win_row0[wi8];
   // ---- requested first (in order of use): fold operands, LayerNorm parameters, bias, the Wq slice
   float xfold;
-  float gv[DPL], bv[DPL];
   const int rg = tid >> 4, c4 = (tid & 15) * 4;
+  // LayerNorm parameters of the 4 NWQ columns this wave's Wq rows need: lane l < 4 NWQ owns column 4 wave + (l & 3) +
+  // 32 (l >> 2) = row rg + 32 i of thread group (rg = 4 wave + (l & 3), i = l >> 2)
+  constexpr int NOWN = 4 * NWQ;
+  const int own_col = 4 * wave + (lane & 3) + 32 * ((lane < NOWN ? lane : 0) >> 2);
+  float g_own = 0.f, b_own = 0.f;
   float4 wqr[NWQ];
   float4 kv[NTILE][SL];
   const float* Kh; const float* Vh; int C;
   float qbias = 0.f;
   auto load_weights = [&]() {
-    if (wave == 0) {
-#pragma unroll
-      for (int i = 0; i < DPL; i++) { gv[i] = a.ln_g[lane + 64 * i]; bv[i] = a.ln_b[lane + 64 * i]; }
-    }
+    g_own = a.ln_g[own_col]; b_own = a.ln_b[own_col];
     if constexpr (PS) { if (tid < 64) qbias = a.bq[h * 64 + tid]; }
     {
       const float* wp = a.Wq + (int64_t)rg * d + h * 64 + c4;
@@ -980,11 +1022,13 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
       // persistent mode: neither the weights nor the window's cached keys depend on the predecessor -- the Wq slice and
       // the WHOLE K of the head are in flight (or landed) while the block waits (pre-wake); the self-attention planes
       // arrive as tagged granules
-      load_weights();
-      load_keys();
+      if (!ps.known_dead) {
+        load_weights();
+        load_keys();
+      }
       if (!ps_wait(ps)) return false;
-      dead = ld_i<true>(ps.dead + r);
-      if (r >= n_live || dead) return true;
+      dead = ps.known_dead ? 1 : ld_i<true>(ps.dead + r);
+      if (r >= n_live || dead) { ps.saw_dead = true; return true; }
       const Buf16 xgb(a.g_x_in), pgb(a.g_pend);
       const uint32_t pvo = (uint32_t)(r * d + c);
       const int iplane = a.S * d;
@@ -1045,15 +1089,21 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
   if constexpr (PS) ps_stamp(ps, 2);
   __syncthreads();
   if constexpr (PS) { if (!ps_sweeps_ok(ps)) return false; }
-  if (wave == 0) ln_row_lds<DPL>(hs, d, lane, gv, bv, a.ln_eps, a.ln_inside);
-  __syncthreads();
+  // LayerNorm: statistics per wave, each wave normalises the columns its own Wq rows multiply -- no second barrier
+  float xn_own;
+  {
+    float mean, denom;
+    ln_stats_lds<DPL>(hs, d, lane, a.ln_eps, a.ln_inside, mean, denom);
+    xn_own = (hs[own_col] - mean) / denom * g_own + b_own;
+  }
   if constexpr (PS) ps_stamp_fine(ps, 4);
   // ---- q = (cross_attn_ln(x) Wq + bq) * s for head h  (mod.rs:483, :506-509)
   {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int q4 = lane >> 4;
 #pragma unroll
     for (int i = 0; i < NWQ; i++) {
-      const float xv = hs[rg + 32 * i];
+      const float xv = lane_get(xn_own, 4 * i + q4);
       acc[0] += xv * wqr[i].x; acc[1] += xv * wqr[i].y; acc[2] += xv * wqr[i].z; acc[3] += xv * wqr[i].w;
     }
 #pragma unroll

@@ -57,12 +57,8 @@ __device__ __forceinline__ bool ps_finln_role(const PersistArgs& a, const int r,
   constexpr int d = 64 * DPL, FP = 4 * DPL;
   __shared__ __attribute__((aligned(16))) float hs[d];
   const int tid = role_tid<true>(), lane = tid & 63, wave = tid >> 6;
-  float gv[DPL], bv[DPL];
-  if (wave == 0) {
-#pragma unroll
-    for (int i = 0; i < DPL; i++) { gv[i] = a.ln_g[lane + 64 * i]; bv[i] = a.ln_b[lane + 64 * i]; }
-  }
   const int c = tid < d ? tid : 0;
+  const float g_own = a.ln_g[c], b_own = a.ln_b[c];   // thread = column: every wave normalises its own 64 columns
   float accp = a.b2_last[c];
   if (!ps_wait(ps)) return false;                   // pre-wake: the last layer's cross-attention blocks have finished
   if (ld_i<true>(ps.dead + r) != 0) return true;
@@ -95,9 +91,12 @@ __device__ __forceinline__ bool ps_finln_role(const PersistArgs& a, const int r,
   ps_stamp(ps, 2);
   __syncthreads();
   if (!ps_sweeps_ok(ps)) return false;
-  if (wave == 0) ln_row_lds<DPL>(hs, d, lane, gv, bv, a.ln_eps, a.ln_inside);
-  __syncthreads();
-  if (tid < d) { const Buf16 xo(a.g_xn); st_gran(xo, (uint32_t)(r * d + tid), ps.tag_out, hs[tid]); }
+  if (wave < DPL) {                                 // (statistics per wave: no second barrier, no LDS round trip of the result)
+    float mean, denom;
+    ln_stats_lds<DPL>(hs, d, lane, a.ln_eps, a.ln_inside, mean, denom);
+    const Buf16 xo(a.g_xn);
+    st_gran(xo, (uint32_t)(r * d + tid), ps.tag_out, (v - mean) / denom * g_own + b_own);
+  }
   return true;
 }
 
@@ -328,10 +327,12 @@ __global__ __launch_bounds__(PS_NT) void dec_persist_kernel(PersistArgs a) {
 #pragma unroll
   for (int k = 0; k < 8; k++) n_per_ctr[k] = (a.n_logits_roles + 7 - k) / 8;
   const int i_lo = a.role_off[blockIdx.x], i_hi = a.role_off[blockIdx.x + 1];
+  unsigned long long dead_seen = 0;                 // bit k: role i_lo + k of this block has found its row dead (it stays dead)
   for (int e = 0; e < a.n_steps; e++) {
     for (int i = i_lo; i < i_hi; i++) {
       const PsRole role = a.roles[i];
       PsStep ps;
+      ps.known_dead = i - i_lo < 64 && ((dead_seen >> (i - i_lo)) & 1ull) != 0;
       ps.ctl = a.ctl; ps.step = a.step0 + e; ps.n_rows = R; ps.dead = a.dead; ps.lds_flag = &wait_flag;
       unsigned long long* stp = a.stamps ? a.stamps + ((size_t)e * a.n_roles + i) * PS_STAMPS : nullptr;
       if (stp && threadIdx.x == 0) stp[0] = wall_clock64();
@@ -387,6 +388,7 @@ __global__ __launch_bounds__(PS_NT) void dec_persist_kernel(PersistArgs a) {
         out = C_X + role.b;
       }
       if (!ok) return;                               // the decode was stopped (or a wait gave up): leave
+      if (ps.saw_dead && i - i_lo < 64) dead_seen |= 1ull << (i - i_lo);
       if (stp && threadIdx.x == 0) stp[6] = wall_clock64();
       if (role.kind == PSR_CROSS && role.layer == NL - 1)
         hx_arrive_broadcast(cptr(out), (unsigned)(e + 1) * H * R, cptr(C_GO), PS_NGO, (unsigned)(e + 1));
