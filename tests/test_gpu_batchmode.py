@@ -14,16 +14,20 @@ generated token is the (lowest-id) argmax of its row and the row stops where bea
   small,    batch-mode sessions (9 windows x 1 beam = streaming cross-attention; 5 windows x 2 beams = chunked +
             combine) for 122 positions -- past position 112, the second self-attention tile of dec_self_attn_kernel
 
-Log-prob tolerance at these depths.  The north star's 1e-3 is met at tiny.en's shape (test_gpu_workloads.py,
-test_gpu_budget.py).  At `small` and large-v2 two CORRECT f32 evaluations are no longer within 1e-3 of each other: measured
-on the MI355X box (whisper-burn_amd/tools/diag_batch_logprob.py, profiles/r03_b_diag_logprob_*.log), the f32 oracle
-itself sits 5e-4 .. 8e-4 (small, 12 + 12 layers) and 4e-3 .. 1.1e-2 (large-v2, 32 + 32 layers) from the f64 evaluation
-of the same algorithm on sequences picked at random among the top 5; the HIP path sits 9e-4 .. 2.6e-3 and 2e-2 .. 5.5e-2
-(3 .. 8 x further: the exact-f32 MFMA GEMMs accumulate K sequentially, the K = 4 d = 5120 products of large-v2's MLPs are
-2.8 x less accurate per product than a blocked sum -- recorded in DESIGN.md as a numerics gap to close).  These tests
-therefore pin the rows against the EXACT twin with a stated budget: |hip - f64| <= max(1e-3, 10 x |oracle_f32 - f64|)
-and an absolute cap per model (small 5e-3, large-v2 1e-1), plus the device top-k order on every row; token parity of the
-batch-mode path is pinned separately and exactly by the two depth-100 greedy tests above.
+Log-prob tolerance at these depths.  The north star's 1e-3 is met outright at tiny.en's shape (test_gpu_workloads.py,
+test_gpu_budget.py) and at `small`'s (asserted below).  At large-v2 (32 + 32 layers) two CORRECT f32 evaluations are no longer
+within 1e-3 of each other: the f32 oracle itself sits up to 3.5e-2 from the f64 evaluation of the same algorithm on sequences
+picked at random among the top 5 (rms over rows 5.5e-3; the synthetic checkpoints amplify a relative perturbation of 1e-6 of the
+encoder output into up to 3e-2 of log-prob, heavy-tailed from row to row).  The rows are therefore pinned against the EXACT
+twin with the oracle's own distance as the budget: worst row |hip - f64| <= max(1e-3, 2 x worst row |oracle_f32 - f64|) over the
+same rows, and rms over rows |hip - f64| <= 1.5 x rms |oracle_f32 - f64| -- no absolute cap.  Measured on the MI355X box with
+the stage-split diagnostic (whisper-burn_amd/tools/diag_stage_split.py, profiles/r04_b_diag_*.log; 9 windows x 33 positions):
+large-v2 worst 4.1e-2 (oracle 3.5e-2), rms 5.2e-3 (5.5e-3); small worst 6.1e-4 (8.1e-4), rms 1.9e-4 (2.3e-4) -- the HIP path
+is as close to the exact result as the reference-style f32 evaluation, or closer.  (Round 3 sat 3 - 8 x further out: the
+exact-f32 MFMA GEMMs sum K in ONE sequential chain per output -- 1280 to 5120 terms for the encoder's Linear layers and the
+cross-K/V projection, 3840 for conv2, 750 keys in P.V -- which a blocked CPU sum does not; the split-precision GEMM's chain is
+16 x shorter and the attention kernel sums per key tile: profiles/r04_a_diag_*.)  Token parity of the batch-mode path is pinned
+separately and exactly by the two depth-100 greedy tests above.
 """
 import numpy as np
 import pytest
@@ -38,8 +42,8 @@ from whisper_burn_amd import synth
 pytestmark = pytest.mark.gpu
 
 LOGPROB_TOL = 1e-3      # north_star: logits within 1e-3 (fp32)
-BUDGET_FACTOR = 10.0    # |hip - exact| <= max(LOGPROB_TOL, BUDGET_FACTOR x |oracle_f32 - exact|)  (see the module docstring)
-ABS_CAP = {"small": 5e-3, "large-v2": 1e-1}
+BUDGET_FACTOR = 2.0     # worst row: |hip - exact| <= max(LOGPROB_TOL, BUDGET_FACTOR x worst |oracle_f32 - exact|)  (module docstring)
+RMS_FACTOR = 1.5        # rms over rows: |hip - exact| <= RMS_FACTOR x |oracle_f32 - exact|
 WLEN = 238559           # max_waveform_samples(1500 - 10), transcribe.rs:32-34
 
 
@@ -166,6 +170,7 @@ def _session_logprob_rows(eng, o, st, audio, use_windows, max_beams, n_steps, fo
         worst32 = max(worst32, float(np.abs(got[fin] - ref[fin]).max()))
     # the exact twin (f64 evaluation of the same operators on the same log-mel) on the windows asked for
     d_hip, d_o32 = 0.0, 0.0
+    sq_hip, sq_o32, n_exact = 0.0, 0.0, 0
     if exact_windows:
         o64 = OracleWhisper(o.w, dtype=torch.float64)
         maskv = torch.tensor(np.where(np.asarray(st.is_special).astype(bool), -np.inf, 0.0), dtype=torch.float64)
@@ -181,31 +186,49 @@ def _session_logprob_rows(eng, o, st, audio, use_windows, max_beams, n_steps, fo
                 if w2 == wdx and s2 == seq[:len(s2)]:
                     ref64, ref32 = r64[len(s2) - 4], rows[(s2, w2)]
                     fin = np.isfinite(ref64)
-                    d_hip = max(d_hip, float(np.abs(got[fin] - ref64[fin]).max()))
-                    d_o32 = max(d_o32, float(np.abs(ref32[fin] - ref64[fin]).max()))
+                    e_hip, e_o32 = float(np.abs(got[fin] - ref64[fin]).max()), float(np.abs(ref32[fin] - ref64[fin]).max())
+                    d_hip, d_o32 = max(d_hip, e_hip), max(d_o32, e_o32)
+                    sq_hip += e_hip ** 2; sq_o32 += e_o32 ** 2; n_exact += 1
         del o64
     return {"hip_o32": worst32, "hip_exact": d_hip, "o32_exact": d_o32, "n_live": n_live, "n_rows": len(records),
+            "rms_hip_exact": (sq_hip / max(n_exact, 1)) ** 0.5, "rms_o32_exact": (sq_o32 / max(n_exact, 1)) ** 0.5,
+            "n_exact_rows": n_exact,
             "longest": max(len(r[0]) for r in records)}
 
 
 def _assert_budget(res, model):
+    assert res["n_exact_rows"] >= 40, res
     assert res["hip_exact"] <= max(LOGPROB_TOL, BUDGET_FACTOR * res["o32_exact"]), res
-    assert res["hip_exact"] <= ABS_CAP[model], res
+    assert res["rms_hip_exact"] <= max(0.3 * LOGPROB_TOL, RMS_FACTOR * res["rms_o32_exact"]), res
+    if model == "small":
+        assert res["hip_exact"] <= LOGPROB_TOL, res                 # the north star's tolerance, outright
     # every window against the f32 oracle: a sanity bound (two f32 evaluations of an ill-conditioned chain differ by up to
-    # the sum of their distances to the exact one; profiles/r03_e_diag_large_v2.log: 0.26 at large-v2's first positions)
-    assert res["hip_o32"] <= 6.0 * ABS_CAP[model], res
+    # the sum of their distances to the exact one; the rows of the windows without an exact twin are in this one)
+    assert res["hip_o32"] <= max(2.0 * LOGPROB_TOL, 6.0 * res["o32_exact"]), res
 
 
 def test_large_v2_batch_mode_beams_logprob_rows(large_v2):
     """large-v2, 5 windows x 2 beams = 10 live rows: batch mode with beams, i.e. dec_cross_attn_kernel<2> + the chunk
-    combine at d = 1280 (the streaming kernel serves one beam per window only); 14 positions, the compared log-prob
-    rows inside the stated budget of the exact twin (module docstring)."""
+    combine at d = 1280 (the streaming kernel serves one beam per window only); 20 positions, the compared log-prob
+    rows of ALL five windows inside the stated budget of the exact twin (module docstring)."""
     eng, o = large_v2
     st = wb.SpecialTokens.for_vocab(51865)
     audio = synth.synth_audio(1900000, 1240)
-    res = _session_logprob_rows(eng, o, st, audio, [0, 2, 4, 6, 9], 2, 14, 3, 11, exact_windows=(1,))
-    assert res["n_live"] == 10 and res["longest"] >= 14
+    res = _session_logprob_rows(eng, o, st, audio, [0, 2, 4, 6, 9], 2, 20, 3, 11, exact_windows=(0, 1, 2, 3, 4))
+    assert res["n_live"] == 10 and res["longest"] >= 20
     print(f"large-v2 5 x 2 beams: {res}")
+    _assert_budget(res, "large-v2")
+
+
+def test_large_v2_batch_mode_streaming_logprob_rows(large_v2):
+    """large-v2, 9 windows x 1 beam = the streaming cross-attention kernel (dec_cross_attn_stream_kernel: config #5's
+    per-GPU path) at d = 1280: 24 positions, the compared rows of five windows inside the budget of the exact twin."""
+    eng, o = large_v2
+    st = wb.SpecialTokens.for_vocab(51865)
+    audio = synth.synth_audio(1900000, 1240)
+    res = _session_logprob_rows(eng, o, st, audio, list(range(9)), 1, 24, -1, 21, exact_windows=(0, 2, 4, 6, 8))
+    assert res["n_live"] == 9 and res["longest"] >= 24
+    print(f"large-v2 9 x 1 beam: {res}")
     _assert_budget(res, "large-v2")
 
 

@@ -46,7 +46,10 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SK_NT = 512;          // 8 waves: one 64-column strip, the block's K slice in 8 parts
-constexpr int SK_MAX_LD = 20;       // float4 loads a wave keeps in flight (80 K-rows); 12 with more than two row tiles
+constexpr int SK_MAX_LD = 20;       // float4 loads a wave keeps in flight (80 K-rows); 16 with four row tiles
+// loads in flight per wave by row tiles: the activations of a block's K slice (16 MT rows x 32 LDW K-rows) share the LDS with
+// the eight waves' partial tiles; three row tiles with 20 loads are 120 KB (one block per CU either way: > 128 registers)
+__host__ __device__ constexpr int sk_ldw(int mt) { return mt <= 3 ? SK_MAX_LD : 16; }
 
 // PAIR (opt-in, WHISPER_HIP_SK_PAIR=1; to be measured): the partial tiles meet pairwise -- waves 4-7 park theirs, waves 0-3 add
 // their own and park the sums, the plane items sum those four: half the LDS (16 KB per row tile instead of 32), so that a
@@ -59,10 +62,13 @@ template <int MT, bool PAIR>
 __global__ __launch_bounds__(SK_NT, MT <= 2 ? 2 : 1) void dec_skinny_gemm_kernel(SkinnyArgs a) {
   // one region, two lives: the activations of the block's K slice, k-major in row tiles of 16 (As[mt][k][16]: the A
   // operand of lane l for K-rows k0 .. k0 + 3 is word 16 k0 + l -- conflict-free), then the 8 waves' partial tiles
-  // (K-rows per block <= 32 x 20 = 640: 10240 words per row tile -- 32 x 12 = 384 rows with three or four row tiles;
-  // the partial tiles need 8 x 16 x 64 = 8192)
-  constexpr int LDW = MT <= 2 ? SK_MAX_LD : 12;
-  __shared__ __attribute__((aligned(16))) float smem[MT * (MT <= 2 ? 10240 : (PAIR ? 6144 : 8192))];
+  // (K-rows per block <= 32 x 20 = 640: 10240 words per row tile -- 32 x 16 = 512 rows with four row tiles;
+  // the partial tiles need 8 x 16 x 64 = 8192 words per row tile)
+  // (round 3 kept 12 loads in flight with three / four row tiles: large-v2's MLP products then needed 320 blocks = TWO rounds
+  // of the chip at one block per CU, 19.5 us against 11.2 us for the QKV product's 240 blocks -- profiles/r03_m_*; with 20 / 16
+  // loads the same products are 160 - 200 blocks with every byte in flight from the start)
+  constexpr int LDW = sk_ldw(MT);
+  __shared__ __attribute__((aligned(16))) float smem[MT * 512 * LDW > MT * (PAIR ? 4096 : 8192) ? MT * 512 * LDW : MT * (PAIR ? 4096 : 8192)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int strip = blockIdx.x, z = blockIdx.y;
   const int kchunk = a.K / a.ksplit;                 // host: K % (32 ksplit) == 0
@@ -181,7 +187,7 @@ int skinny_ksplit(int K, int N, int max_ks, int max_rows) {
   int best = 0;
   for (int ks = 1; ks <= std::min(KS_MAX, max_ks); ks++) {
     if (K % (32 * ks) != 0) continue;
-    if (K / ks / 32 > (max_rows <= 32 ? SK_MAX_LD : 12)) continue;
+    if (K / ks / 32 > sk_ldw((max_rows + 15) / 16)) continue;
     if (best > 0 && strips * ks > max_blocks) break;
     best = ks;
   }
@@ -192,7 +198,7 @@ bool skinny_supported(int M, int K, int N) { return M >= 1 && M <= 64 && skinny_
 
 int launch_dec_skinny_gemm(hipStream_t st, const SkinnyArgs& a) {
   if (a.ksplit < 1 || a.ksplit > KS_MAX || a.K % (32 * a.ksplit) != 0 || a.N % 64 != 0 || a.M < 1 || a.M > 64) return -1;
-  if (a.K / a.ksplit / 32 > (a.M <= 32 ? SK_MAX_LD : 12)) return -1;
+  if (a.K / a.ksplit / 32 > sk_ldw((a.M + 15) / 16)) return -1;
   const int MT = (a.M + 15) / 16;
   const dim3 grid(a.N / 64, a.ksplit), block(SK_NT);
   static const bool pair = []() { const char* e = getenv("WHISPER_HIP_SK_PAIR"); return e && e[0] == '1'; }();
