@@ -191,6 +191,9 @@ def main() -> None:
                     help="extra timed leg: large-v2, --large-v2-seconds of audio per GPU (BASELINE.json's 8-GPU headline is "
                          "large-v2; the driver's command line cannot select a model).  auto = only when --gpus > 1; "
                          "`value` stays the tiny.en figure in every case")
+    ap.add_argument("--beam5-leg", default="auto", choices=["auto", "on", "off"],
+                    help="extra timed leg: the same workload with the reference's live beam_size 5 (auto: with the greedy "
+                         "reference-geometry run)")
     ap.add_argument("--large-v2-seconds", type=float, default=450.0,
                     help="audio per GPU of the large-v2 leg (450 s = 38 windows = one GPU's share of the 8-GPU hour)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
@@ -365,6 +368,47 @@ def main() -> None:
         cpu_baseline = run_cpu_baseline(weights, st, audio, sr, int(wlen), args.beam, args.max_depth, args.geometry,
                                         args.model)
 
+    # ---- beam-5 leg: the reference's LIVE decode setting (transcribe.rs:232-233: beam_size 5, max_depth 100) on the same model,
+    # audio and windows as the headline figure (greedy = the same code with beam_size 1); `value` stays greedy
+    beam5 = None
+    if args.beam5_leg == "on" or (args.beam5_leg == "auto" and args.beam == 1 and args.geometry == "reference"):
+        bparams = wb.decode_params(st, beam_size=5, max_depth=args.max_depth)
+
+        def bdecode(lo, hi):
+            assert (lo, hi) == local_win
+            return wb.waveform_to_tokens(eng, st, None, sr, params=bparams, win_begin=0, win_end=hi - lo,
+                                         device_ptr=pcm_dev.data_ptr(), n_samples=n_local)[1]
+
+        def bstep():
+            return shard.transcribe_sharded(bdecode, wb.stitch_windows, n_win, rank, world, row_stride,
+                                            device=dev if world > 1 else None)
+
+        b_steps, b_warm = max(2, min(10, args.steps)), min(2, args.warmup)
+        for _ in range(b_warm):
+            bstep()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(b_steps):
+            btok, brows = bstep()
+        barrier()
+        bdt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([bdt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            bdt = float(t.item())
+        if rank == 0:
+            beam5 = {"metric": "real-time factor (audio-sec/wall-sec)",
+                     "value": round(args.seconds * world * b_steps / bdt, 2), "unit": "x real-time", "n_gpus": world,
+                     "steps": b_steps, "warmup": b_warm, "ms_per_step": round(bdt / b_steps * 1e3, 3), "dtype": args.dtype,
+                     "config": {"workload": f"{args.model}, {args.seconds:g} s of 16 kHz audio per GPU per step, reference windowing "
+                                            f"({n_win} windows), beam_size 5, max_depth {args.max_depth} (the reference's live "
+                                            f"setting, transcribe.rs:232-233)",
+                                "tokens_out": len(btok),
+                                "generated_tokens_per_window": [max(0, len(r) - 4) for r in brows],
+                                "path": "host-driven beam search (beam.rs restated in C++) over KV-cached session steps: fused "
+                                        "sublayer kernels while <= 8 beams are live, batch mode above; the persistent kernel "
+                                        "serves greedy only"}}
+
     # ---- large-v2 leg (BASELINE.json's multi-GPU headline config): every rank decodes --large-v2-seconds of audio ----
     large_v2 = None
     if args.large_v2_leg == "on" or (args.large_v2_leg == "auto" and args.model in ("tiny.en", "tiny_en")
@@ -505,6 +549,7 @@ def main() -> None:
             "e2e_roofline": e2e,
             "mel_frontend": mel_frontend,
             "stages": stages,
+            "beam5": beam5,
             "large_v2": large_v2,
         }
         print(json.dumps(out), flush=True)

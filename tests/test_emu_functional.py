@@ -267,6 +267,11 @@ def test_bench_main_runs_to_its_json_line(emu_lib, extra):
     assert len(cb["runs_s"]) == 3
     assert out["config"]["encoder_gemm"].startswith("exact-f32" if "--encoder" in extra else "split precision")
     assert cb["depth"] == 4 and cb["depth32"]["depth"] == 4 and cb["depth32"]["value"] > 0
+    if "--beam" not in extra:             # the greedy reference-geometry line carries the reference's live beam-5 setting too
+        b5 = out["beam5"]
+        assert b5["value"] > 0 and b5["steps"] == 2 and "beam_size 5" in b5["config"]["workload"]
+    else:
+        assert out["beam5"] is None
     if "--large-v2-seconds" in extra:      # the default tiny.en line carries the large-v2 leg at ONE GPU too (auto = on)
         lv = out["large_v2"]
         assert lv["n_gpus"] == 1 and lv["value"] > 0 and lv["steps"] == 3 and "large-v2" in lv["config"]["workload"]
