@@ -45,10 +45,11 @@ WORKLOADS = {
     # config #3: base.en, 30 s, beam 5: to max_depth 32 (no EOT), and with windows ending on EOT
     "base_beam5": Workload("base.en", 480000, 1237, 5, 32, None, NO_EOT),
     "base_beam5_eot": Workload("base.en", 480000, 1237, 5, 100),
-    # config #4: small (multilingual, V = 51 865), 10 minutes -> 51 windows; first and last window vs the oracle
-    "small_10min": Workload("small", 9600000, 1238, 1, 12, (0, 50)),
-    # config #5: large-v2, one full 14.9 s window
-    "large_window": Workload("large-v2", 238559, 1239, 1, 8),
+    # config #4: small (multilingual, V = 51 865), 10 minutes -> 51 windows; five windows spread over the clip vs the
+    # oracle's LITERAL loop to depth 32 (the depth-100 evidence on all 51 windows is teacher-forced: test_gpu_batchmode.py)
+    "small_10min": Workload("small", 9600000, 1238, 1, 32, (0, 12, 25, 38, 50)),
+    # config #5: large-v2, one full 14.9 s window, literal loop to depth 16
+    "large_window": Workload("large-v2", 238559, 1239, 1, 16),
     # config #2(b), the "perf geometry" of SURVEY 8d: ONE window of T = 2990 (+10 zero) frames, C = 1500 encoder
     # positions -- Whisper's own 30 s chunk, which the reference cannot run (mod.rs:236-241 bounds the FRAMES by
     # n_audio_ctx); opt-in on both sides (wb_model_set_frame_limit / OracleWhisper(frame_limit_x2=True))
