@@ -146,7 +146,7 @@ def test_persistent_flag_chained_decode_under_the_functional_model(emu_lib, whic
 
 
 @pytest.mark.parametrize("env", [{"WHISPER_HIP_PERSIST_INJECT_FAIL": "launch"}, {"HIPEMU_NO_COOP": "1"}],
-                         ids=["launch-refused", "no-cooperative-launch"])
+                         ids=["launch-refused", "no-cooperative-launch"])  # (both prefill on the host, then run the chain)
 def test_persistent_decode_falls_back_to_the_chain(emu_lib, env):
     """The persistent kernel is the default greedy path; when it cannot run -- the cooperative launch is refused (CU masking,
     a partition, a second cooperative client) or the device reports no cooperative launches at all (a wait that gives up

@@ -35,7 +35,9 @@ SWITCHES = [{}, {"WHISPER_HIP_FUSE_X": "0"}, {"WHISPER_HIP_FUSE_SUB": "0"}, {"WH
             {"WHISPER_HIP_PERSIST": "0"},
             # the cooperative launch of the persistent kernel is refused (CU masking, a partition, a second cooperative
             # client): the session falls back to the chain instead of failing
-            {"WHISPER_HIP_PERSIST_INJECT_FAIL": "launch"}]
+            {"WHISPER_HIP_PERSIST_INJECT_FAIL": "launch"},
+            # the prompt prefill as host-driven steps in front of the persistent launch instead of forced steps inside it
+            {"WHISPER_HIP_PERSIST_PREFILL": "0"}]
 
 
 _CACHE = {}

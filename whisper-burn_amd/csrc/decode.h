@@ -192,6 +192,7 @@ int launch_dec_skinny_gemm(hipStream_t st, const SkinnyArgs& a);
 struct PsLayerArgs { AttnFusedArgs attn; CrossFusedArgs cross; MlpFusedArgs mlp; };
 enum { PSR_ATTN = 0, PSR_CROSS = 1, PSR_MLP = 2, PSR_LOGITS = 3, PSR_MERGE = 4, PSR_FINLN = 5 };
 struct PsRole { int kind, layer, a, b; };     // a: head / hidden slice / first tile, b: row (logits: tiles of the role; layer: its ordinal)
+constexpr int PS_MAX_FORCED = 8;
 struct PersistArgs {
   const PsLayerArgs* layers = nullptr;        // [n_layer] (device)
   const PsRole* roles = nullptr; int n_roles = 0;   // one step's roles, grouped by block, each block's in dependency order (device)
@@ -201,6 +202,9 @@ struct PersistArgs {
   int n_pass = 1;                             // key passes of the cross-attention roles (2: a window with > CROSS_FUSED_MAX_C keys)
   int* ctl = nullptr;                         // HX_* control words + arrival counters (device; set up by the host)
   int step0 = 0, n_steps = 0;                 // first decode step of the chain, most steps to run
+  // prompt prefill inside the launch: the first n_forced steps do not choose their next token -- position step0 + e + 1 holds
+  // forced[e] (the rest of the prompt, transcribe.rs:203) -- and skip the logits work
+  int n_forced = 0; int forced[PS_MAX_FORCED] = {0, 0, 0, 0, 0, 0, 0, 0};
   int mask_until_len = 0;                     // special-token mask while len <= this (transcribe.rs:271-275)
   // logits role: LN(x_fin + b2 + sum P2) . E^T tile -> (best value, best id) per row and tile (x_fin, P2: granules)
   const void* x_fin = nullptr; const void* P2 = nullptr; const float* b2_last = nullptr;

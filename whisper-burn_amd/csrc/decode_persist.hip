@@ -105,7 +105,8 @@ __device__ __forceinline__ bool ps_finln_role(const PersistArgs& a, const int r,
 // rows arrive as granules from the final-LN roles.  Per row and tile the block leaves the best masked logit and its id --
 // greedy needs the argmax only (log_softmax is monotone: transcribe.rs:276 with beam.rs k = 1).
 template <int MR, int DPL>
-__device__ __forceinline__ bool ps_logits_role(const PersistArgs& a, const int tile0, const int n_t, const PsStep& ps) {
+__device__ __forceinline__ bool ps_logits_role(const PersistArgs& a, const int tile0, const int n_t, const PsStep& ps,
+                                               const bool forced) {
   constexpr int d = 64 * DPL, NT = PS_NT, CT = PS_CT;
   constexpr int NR = d / 16;                        // E^T rows per thread: k = (2 wave + hh) NR + i
   constexpr int EPT = (MR * d + NT - 1) / NT;
@@ -131,8 +132,10 @@ __device__ __forceinline__ bool ps_logits_role(const PersistArgs& a, const int t
   // second tile of 203 blocks (40 MB at once, next to everybody's weight prefetch for the next step) took ~20 us
   // (profiles/r03_c_ps_timeline_phases.txt).
   float4 w0[NR], w1[TWO ? NR : 1];
-  load_tile(w0, tile0);
-  if constexpr (TWO) { if (n_t > 1) load_tile(w1, tile0 + 1); }
+  if (!forced) {                                    // (a prompt step chooses nothing: no E^T stream)
+    load_tile(w0, tile0);
+    if constexpr (TWO) { if (n_t > 1) load_tile(w1, tile0 + 1); }
+  }
   const int use_mask = (ps.step + 1 <= a.mask_until_len) ? 1 : 0;          // transcribe.rs:271-275
   int deadm = 0;                                    // bit r: row r takes no part (its window has ended)
   if (!ps_wait(ps)) return false;                   // pre-wake: the last layer's cross-attention blocks have finished
@@ -176,6 +179,9 @@ __device__ __forceinline__ bool ps_logits_role(const PersistArgs& a, const int t
   __syncthreads();
   if (!ps_sweeps_ok(ps)) return false;
   ps_stamp(ps, 3);
+  // a prompt step: the role has kept its place in the chain (it arrives after the final-LN roles, the merge role after it --
+  // the order the reuse of the x rows and planes relies on) and is done
+  if (forced) return true;
   // one tile: GEMV from the registers, column sums over the eight waves, mask, per-row best (value desc, id asc)
   auto run_tile = [&](const float4 (&w)[NR], int tile) {
     const int n0 = tile * CT;
@@ -266,27 +272,32 @@ __device__ __forceinline__ bool ps_merge_role(const PersistArgs& a, const int r,
   const int len = ps.step + 1;                      // tokens in the row so far; the new one lands at index len
   const int fin_now = ld_i<true>(a.dead + r);
   const int tok_prev = ld_i<true>(a.gctl + GC_HDR + r);
-  float bv = -INFINITY; int bi = 0x7fffffff;
-  for (int t = tid; t < a.n_tiles; t += PS_NT) {
-    const float* ts = a.tstats + ((int64_t)r * a.n_tiles + t) * 2;
-    const float v = ld_f<true>(ts);
-    const int id = __float_as_int(ld_f<true>(ts + 1));
-    if (better(v, id, bv, bi)) { bv = v; bi = id; }
-  }
-  wave_argmax(bv, bi);
-  if (lane == 0) { redv[wave] = bv; redi[wave] = bi; }
-  __syncthreads();
-  float gv = redv[0]; int gi = redi[0];
+  int gi;
+  if (e < a.n_forced) {
+    gi = a.forced[e];                               // prompt prefill: the next position holds the next prompt token
+  } else {
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int t = tid; t < a.n_tiles; t += PS_NT) {
+      const float* ts = a.tstats + ((int64_t)r * a.n_tiles + t) * 2;
+      const float v = ld_f<true>(ts);
+      const int id = __float_as_int(ld_f<true>(ts + 1));
+      if (better(v, id, bv, bi)) { bv = v; bi = id; }
+    }
+    wave_argmax(bv, bi);
+    if (lane == 0) { redv[wave] = bv; redi[wave] = bi; }
+    __syncthreads();
+    float gv = redv[0]; gi = redi[0];
 #pragma unroll
-  for (int j = 1; j < 8; j++)
-    if (better(redv[j], redi[j], gv, gi)) { gv = redv[j]; gi = redi[j]; }
-  const int finished = fin_now || gi == a.eot;
+    for (int j = 1; j < 8; j++)
+      if (better(redv[j], redi[j], gv, gi)) { gv = redv[j]; gi = redi[j]; }
+  }
+  const int finished = fin_now || (gi == a.eot && e >= a.n_forced);
   const int tok_next = fin_now ? tok_prev : gi;     // a finished row keeps its last token (its later argmax is stale)
   if (tid == 0 && !fin_now) {
     st_i_sc1(a.gctl + GC_HDR + r, gi);
     a.gtok[r * a.Lmax + len] = gi;
     a.gctl[GC_HDR + 2 * a.S + r] = len + 1;
-    if (gi == a.eot) {                              // transcribe.rs:235-241: the row has ended
+    if (gi == a.eot && e >= a.n_forced) {           // transcribe.rs:235-241: the row has ended
       a.gctl[GC_HDR + a.S + r] = 1;
       st_i_sc1(a.dead + r, 1);
       const unsigned n = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(a.ctl + HX_NDONE), 1u, __ATOMIC_RELAXED,
@@ -381,7 +392,7 @@ __global__ __launch_bounds__(PS_NT) void dec_persist_kernel(PersistArgs a) {
         ps.ctr_index = C_GO + (role.layer % PS_NGO); ps.target = (unsigned)(e + 1);
         ps.ctr = cptr(ps.ctr_index);
         ps.tag_in = tag_l + 2u;
-        ok = ps_logits_role<MR, DPL>(a, role.a, role.b, ps);
+        ok = ps_logits_role<MR, DPL>(a, role.a, role.b, ps, e < a.n_forced);
         out = C_LOG + (role.layer & 7);
       } else {
         ok = ps_merge_role(a, role.b, e, ps, cptr(C_LOG), n_per_ctr);

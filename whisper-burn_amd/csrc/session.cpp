@@ -781,8 +781,10 @@ namespace wb {
 // second cooperative client) or a wait gave up before ANY step was committed -- the caller re-seeds the control block and
 // runs the graph-replayed chain of one launch per sublayer instead (it derives everything from gctl), and the session
 // stops trying the persistent kernel.  A wait that gives up after steps were committed stays an error.
-static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_until_len, int* steps_done, bool* fell_back) {
+static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_until_len, const int32_t* forced, int n_forced,
+                                int* steps_done, bool* fell_back) {
   *fell_back = false;
+  WB_REQUIRE(n_forced >= 0 && n_forced <= PS_MAX_FORCED, WB_ERR_ARG, "persistent decode: %d prompt steps", n_forced);
   // test hook (tests/test_emu_functional.py, tests/test_gpu_switches.py): "launch" = behave as if the cooperative launch was refused
   static const char* inject = getenv("WHISPER_HIP_PERSIST_INJECT_FAIL");
   wb_model* m = s->m;
@@ -912,7 +914,9 @@ static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_
   a.n_logits_roles = n_lg;
   a.n_layer = NL; a.n_rows = W; a.S = S; a.d = d; a.n_head = H; a.nb_mlp = NB;
   a.n_pass = s->maxC > CROSS_FUSED_MAX_C ? 2 : 1;
-  a.ctl = s->ps_ctl.as<int>(); a.step0 = s->step; a.n_steps = max_depth; a.mask_until_len = mask_until_len;
+  a.ctl = s->ps_ctl.as<int>(); a.step0 = s->step; a.n_steps = n_forced + max_depth; a.mask_until_len = mask_until_len;
+  a.n_forced = n_forced;
+  for (int i = 0; i < n_forced; i++) a.forced[i] = forced[i];
   a.g_xn = s->ps_gxn.p;
   a.x_fin = gxb[xi]; a.P2 = s->ps_gp2.p; a.b2_last = m->dec[NL - 1].mlp2.b; a.tag_base = tag_base;
   a.ln_g = m->ln_dec.g; a.ln_b = m->ln_dec.b; a.ln_eps = m->ln_dec.eps; a.ln_inside = m->ln_eps_inside_sqrt;
@@ -922,13 +926,13 @@ static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_
   a.E = m->tok_emb; a.pos = m->dec_pos; a.x0 = gxb[0]; a.tabs = s->tabs.as<int>(); a.dead = s->ps_dead.as<int>();
   // optional role timeline (developer): WHISPER_HIP_PS_STAMPS=<file> dumps [n_steps][n_roles][3] 100 MHz clock values
   static const char* stamps_path = getenv("WHISPER_HIP_PS_STAMPS");
-  const size_t n_stamps = stamps_path ? (size_t)max_depth * roles.size() * 8 : 0;
+  const size_t n_stamps = stamps_path ? (size_t)(n_forced + max_depth) * roles.size() * 8 : 0;
   if (n_stamps) {
     WB_TRY(s->ps_stamps.ensure(n_stamps * 8));
     WB_HIP(hipMemsetAsync(s->ps_stamps.p, 0, n_stamps * 8, st));
     a.stamps = s->ps_stamps.as<unsigned long long>();
   }
-  WB_REQUIRE(3 * NL * (max_depth + 1) + 4 < 0x10000, WB_ERR_SHAPE,
+  WB_REQUIRE(3 * NL * (n_forced + max_depth + 1) + 4 < 0x10000, WB_ERR_SHAPE,
              "persistent decode: %d layers x %d steps do not fit the 16-bit granule tags", NL, max_depth);
   // first step of the chain: token + position embedding of the last prompt token (every later step: the merge role)
   launch_dec_prepare(st, reinterpret_cast<const int*>(s->host_block_dev), s->state.as<int>(), L, W, s->tabs.as<int>(),
@@ -964,7 +968,7 @@ static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_
     std::vector<unsigned long long> hs(n_stamps);
     WB_HIP(hipMemcpy(hs.data(), s->ps_stamps.p, n_stamps * 8, hipMemcpyDeviceToHost));
     if (FILE* f = fopen(stamps_path, "wb")) {
-      const int hdr[4] = {max_depth, (int)roles.size(), grid, 8};
+      const int hdr[4] = {n_forced + max_depth, (int)roles.size(), grid, 8};
       fwrite(hdr, 4, 4, f);
       std::vector<int> kinds(roles.size());
       for (size_t i = 0; i < roles.size(); i++)
@@ -975,7 +979,7 @@ static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_
       fclose(f);
     }
   }
-  *steps_done = std::max(0, std::min(max_depth, gstep - s->step));
+  *steps_done = std::max(0, std::min(n_forced + max_depth, gstep - s->step));
   return WB_OK;
 }
 
@@ -983,12 +987,26 @@ static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_
 // argmax is fed to the next step on the device; the host only replays the step graph and checks the
 // per-window finished flags every `chunk` steps.  Equivalent to beam.rs with k = 1: the single beam is
 // extended by its best continuation (lowest id on ties) until it ends in EOT or max_depth tokens.
-int session_greedy_chain(wb_session* s, int first_token, int eot, int max_depth, int mask_until_len, int prompt_len,
+// A fresh session (step 0) hands in the whole prompt: the persistent kernel runs the prompt's first prompt_len - 1 positions as
+// forced steps of the same launch (no host round trip between the prompt and the first generated token); the chain of one
+// launch per sublayer (and the persistent kernel's fallback) prefills through host-driven steps first, as before.
+int session_greedy_chain(wb_session* s, const int32_t* prompt, int eot, int max_depth, int mask_until_len, int prompt_len,
                          int32_t* out_tokens, int32_t row_stride, int32_t* out_lens) {
   wb_model* m = s->m;
   const int S = s->S, W = s->W;
   WB_REQUIRE(S == W, WB_ERR_STATE, "chained greedy decode needs max_beams == 1");
-  WB_REQUIRE(s->prev_n == W && s->step == prompt_len - 1, WB_ERR_STATE, "chained greedy decode: prompt prefill missing");
+  WB_REQUIRE(prompt && prompt_len >= 1, WB_ERR_ARG, "chained greedy decode: empty prompt");
+  WB_REQUIRE(s->step == 0 || (s->prev_n == W && s->step == prompt_len - 1), WB_ERR_STATE,
+             "chained greedy decode: the session is neither fresh nor prefilled");
+  const int n_forced_max = prompt_len - 1;          // prompt positions that can run inside the persistent launch
+  auto host_prefill = [&]() -> int {                 // transcribe.rs:203: the prompt, one KV-cached step per token, no logits
+    std::vector<int32_t> tok(W), par(W), win(W);
+    for (int t = s->step; t < prompt_len - 1; t++) {
+      for (int w = 0; w < W; w++) { tok[w] = prompt[t]; par[w] = t == 0 ? -1 : w; win[w] = w; }
+      WB_TRY(wb_session_step(s, tok.data(), par.data(), win.data(), W, 0, 0, nullptr, nullptr));
+    }
+    return WB_OK;
+  };
   // the first steps read the special-token mask (transcribe.rs:271-275): same contract as wb_session_step
   WB_REQUIRE(s->has_mask || mask_until_len < prompt_len || max_depth == 0, WB_ERR_STATE,
              "wb_session_decode: special mask not set");
@@ -996,7 +1014,7 @@ int session_greedy_chain(wb_session* s, int first_token, int eot, int max_depth,
   // whose windows all end on EOT earlier succeeds.  Run at most the steps the context holds; raise the
   // reference's error afterwards if a window is still unfinished.
   const int asked_depth = max_depth;
-  max_depth = std::min(max_depth, s->Lmax - s->step);
+  max_depth = std::min(max_depth, s->Lmax - (prompt_len - 1));
   WB_HIP(hipSetDevice(m->device));
   hipStream_t st = s->st;
   const size_t ctl_ints = GC_HDR + 3 * (size_t)S;
@@ -1005,10 +1023,14 @@ int session_greedy_chain(wb_session* s, int first_token, int eot, int max_depth,
   // (= slot 0 of the next row, a prompt position nobody reads), so the buffer carries one extra slot
   WB_TRY(s->gtok.ensure(((size_t)S * s->Lmax + 1) * 4));
   std::vector<int> ctl(ctl_ints, 0);
-  ctl[GC_STEP] = s->step;
-  for (int i = 0; i < W; i++) ctl[GC_HDR + i] = first_token;
-  WB_HIP(hipMemcpyAsync(s->gctl.p, ctl.data(), ctl_ints * 4, hipMemcpyHostToDevice, st));
-  WB_HIP(hipStreamSynchronize(st));
+  auto seed_ctl = [&]() -> int {                     // the chain starts at the session's step with that position's prompt token
+    std::fill(ctl.begin(), ctl.end(), 0);
+    ctl[GC_STEP] = s->step;
+    for (int i = 0; i < W; i++) ctl[GC_HDR + i] = prompt[s->step];
+    WB_HIP(hipMemcpyAsync(s->gctl.p, ctl.data(), ctl_ints * 4, hipMemcpyHostToDevice, st));
+    WB_HIP(hipStreamSynchronize(st));
+    return WB_OK;
+  };
   const int n_launch = W <= 4 ? std::min(4, S) : W <= 8 ? std::min(8, S) : S;
   const bool fuse_ln = n_launch <= 8;
   static const bool graphs_enabled = []() { const char* e = getenv("WHISPER_HIP_GRAPH"); return !(e && e[0] == '0'); }();
@@ -1030,17 +1052,32 @@ int session_greedy_chain(wb_session* s, int first_token, int eot, int max_depth,
     if (s->ps_grid < 0) s->ps_grid = dec_persist_max_grid(m->device, m->dims.n_text_state, W, s->maxC);
     persist = s->ps_grid > 0;
   }
+  // prompt positions the persistent launch runs itself (a fresh session; WHISPER_HIP_PERSIST_PREFILL=0: host-driven prefill)
+  static const bool fold_prefill = []() { const char* e = getenv("WHISPER_HIP_PERSIST_PREFILL"); return !(e && e[0] == '0'); }();
+  int n_forced = 0;
+  if (persist && fold_prefill && s->step == 0 && n_forced_max <= PS_MAX_FORCED && s->has_mask) n_forced = n_forced_max;
+  if (n_forced == 0) WB_TRY(host_prefill());
+  WB_TRY(seed_ctl());
   ScopedTimer tm(st, 3);
   if (persist) {
     bool fell_back = false;
-    WB_TRY(run_persistent_chain(s, eot, max_depth, mask_until_len, &depth, &fell_back));
+    WB_TRY(run_persistent_chain(s, eot, max_depth, mask_until_len, prompt + s->step + 1, n_forced, &depth, &fell_back));
     if (fell_back) {
-      // rows whose merge role ran before the give-up have moved their control words: start over from the seed
+      // rows whose merge role ran before the give-up have moved their control words: prefill on the host (if the launch was
+      // to do it) and start the chain over from the seed
       persist = false;
       depth = 0;
-      WB_HIP(hipMemcpyAsync(s->gctl.p, ctl.data(), ctl_ints * 4, hipMemcpyHostToDevice, st));
-      WB_HIP(hipStreamSynchronize(st));
-    } else if (profile().on) profile().ms[4] += depth;
+      WB_TRY(host_prefill());
+      WB_TRY(seed_ctl());
+      n_forced = 0;
+    } else {
+      if (profile().on) profile().ms[4] += depth;
+      depth -= n_forced;                             // from here on `depth` counts GENERATED positions
+      s->step += n_forced;
+      s->prev_n = W;
+      s->prev_win.resize(W);
+      for (int w = 0; w < W; w++) s->prev_win[w] = w;
+    }
   }
   if (!persist) {
   if (fuse_ln)   // first step of the chain; every later one is prepared by its predecessor's merge kernel
@@ -1187,7 +1224,9 @@ int session_greedy_chain(wb_session* s, int first_token, int eot, int max_depth,
     // necessary bytes of the persistent launch: weights + E^T once per executed step, a row's cached cross K/V and
     // self-attention rows only while its window is live
     const double dm = m->dims.n_text_state, NL = m->dims.n_text_layer;
-    double bytes = (double)depth * 4.0 * (NL * 14.0 * dm * dm + (double)m->dims.n_vocab * dm);
+    double bytes = (double)(depth + n_forced) * 4.0 * NL * 14.0 * dm * dm + (double)depth * 4.0 * (double)m->dims.n_vocab * dm;
+    for (int w = 0; w < W; w++)                      // (the prompt positions the launch ran itself: every row is live there)
+      for (int t = 0; t < n_forced; t++) bytes += NL * (8.0 * s->C[w] * dm + 8.0 * (t + 1) * dm);
     for (int w = 0; w < W; w++) {
       const int live = std::max(0, std::min(out_lens[w] - prompt_len, depth));
       for (int t = 0; t < live; t++) bytes += NL * (8.0 * s->C[w] * dm + 8.0 * (s->step + t + 1) * dm);

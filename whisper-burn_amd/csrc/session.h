@@ -77,6 +77,6 @@ int session_create(wb_model* m, int n_windows, int max_beams, int padding, wb_se
 int session_encode_pcm(wb_session* s, const float* pcm, int64_t n_pcm, const int64_t* starts, const int64_t* lens,
                        bool pcm_on_device);
 int session_reserve(wb_session* s, int max_len);
-int session_greedy_chain(wb_session* s, int first_token, int eot, int max_depth, int mask_until_len, int prompt_len,
+int session_greedy_chain(wb_session* s, const int32_t* prompt, int eot, int max_depth, int mask_until_len, int prompt_len,
                          int32_t* out_tokens, int32_t row_stride, int32_t* out_lens);
 }  // namespace wb

@@ -302,13 +302,9 @@ extern "C" int wb_session_decode(wb_session* s, const wb_decode_params* p, int32
     for (int t : prompt) WB_REQUIRE(t >= 0 && t < V, WB_ERR_ARG, "prompt token %d out of range", t);
     WB_REQUIRE(p->tok_end_of_text >= 0 && p->tok_end_of_text < V, WB_ERR_ARG, "end-of-text token out of range");
     WB_REQUIRE(row_stride >= 4 + p->max_depth, WB_ERR_ARG, "row_stride %d < %d", row_stride, 4 + p->max_depth);
-    std::vector<int32_t> tok(W), par(W), win(W);
-    for (int t = 0; t < 3; t++) {
-      for (int w = 0; w < W; w++) { tok[w] = prompt[t]; par[w] = t == 0 ? -1 : w; win[w] = w; }
-      WB_TRY(wb_session_step(s, tok.data(), par.data(), win.data(), W, 0, 0, nullptr, nullptr));
-    }
     for (int w = 0; w < W; w++) memcpy(out_tokens + (size_t)w * row_stride, prompt, sizeof(prompt));
-    return session_greedy_chain(s, prompt[3], p->tok_end_of_text, p->max_depth, p->mask_until_len, 4, out_tokens,
+    // (the prompt prefill happens inside: as forced steps of the persistent launch, or as host-driven steps in front of the chain)
+    return session_greedy_chain(s, prompt, p->tok_end_of_text, p->max_depth, p->mask_until_len, 4, out_tokens,
                                 row_stride, out_lens);
   }
   return beam_search_windows(p, s->W, s->m->dims.n_vocab, s->S, session_step_thunk, s, out_tokens, row_stride, out_lens);
