@@ -26,8 +26,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "whisper-burn_amd")]
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0,   # dense peaks, same guide
-                    "f16x3": 2500.0 / 3.0}           # split precision: three fp16 MFMAs per f32-grade product
+MFMA_PEAK_TFLOPS = {"f32": 157.3,                    # dense peak of the exact-f32 MFMA, same guide
+                    "f16x3": 2500.0 / 3.0}           # split precision: three fp16 MFMAs (2.5 PF dense) per f32-grade product
 
 
 def e2e_roofline_ms(dims, lens, n_steps, dtype, clip=1490, gen_lens=None, prompt_steps=3, encoder_peak=None):
@@ -37,7 +37,7 @@ def e2e_roofline_ms(dims, lens, n_steps, dtype, clip=1490, gen_lens=None, prompt
     only the NECESSARY bytes are counted -- a window's cached K/V for the steps in which it is still live, and no step
     after the last window has ended (the engine marks finished rows dead and stops)."""
     d, L, V = dims["n_text_state"], dims["n_text_layer"], dims["n_vocab"]
-    s = 2.0 if dtype == "bf16" else 4.0
+    s = 4.0
     frames = [int(n) // 160 for n in lens]
     T = [min(f, clip) + 10 for f in frames]
     C = [(t - 1) // 2 + 1 for t in T]
@@ -196,8 +196,9 @@ def main() -> None:
                          "reference-geometry run)")
     ap.add_argument("--large-v2-seconds", type=float, default=450.0,
                     help="audio per GPU of the large-v2 leg (450 s = 38 windows = one GPU's share of the 8-GPU hour)")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
-                    help="f32 = exact-f32 MFMA parity path (the judged configuration); bf16 = speed path")
+    ap.add_argument("--dtype", default="f32", choices=["f32"],
+                    help="the arithmetic type of the path's results (f32, as the reference's TchBackend<f32>); the bf16 speed "
+                         "path of rounds 1-3 was retired")
     ap.add_argument("--encoder", default=None, choices=["f32", "split"],
                     help="encoder-side GEMMs of the f32 path: f32 = exact-f32 MFMA (default), split = three fp16 MFMAs per "
                          "product (f32-grade results, ~1.9x the rate); default: the library's (WHISPER_HIP_ENCODER_SPLIT)")
@@ -239,8 +240,7 @@ def main() -> None:
 
     lib = _lib.load()
     weights = synth.synth_preset(args.model)
-    eng = wb.Whisper.from_tensors(weights, device=local_rank,
-                                  compute_dtype=wb.WB_BF16 if args.dtype == "bf16" else wb.WB_F32)
+    eng = wb.Whisper.from_tensors(weights, device=local_rank)
     if args.geometry == "whisper30":
         eng.set_frame_limit(True)
     V = eng.dims["n_vocab"]
@@ -416,8 +416,7 @@ def main() -> None:
         eng.close()
         del pcm_dev
         lw = synth.synth_preset("large-v2")
-        leng = wb.Whisper.from_tensors(lw, device=local_rank,
-                                       compute_dtype=wb.WB_BF16 if args.dtype == "bf16" else wb.WB_F32)
+        leng = wb.Whisper.from_tensors(lw, device=local_rank)
         del lw
         leng_split = leng.encoder_gemm() == "f16x3"
         lst = wb.SpecialTokens.for_vocab(leng.dims["n_vocab"])
@@ -459,7 +458,7 @@ def main() -> None:
             lkern = kernel_table(lkstats)
             l_enc_ms, l_ckv_ms, l_dec_ms, l_nsteps = lbuf[1], lbuf[2], lbuf[3], lbuf[4]
             lgen = [max(0, len(r) - 4) for r in lrows[lwin[0]:lwin[1]]]
-            lenc_peak = "f16x3" if (leng_split and args.dtype != "bf16") else args.dtype
+            lenc_peak = "f16x3" if leng_split else args.dtype
             lrl = e2e_roofline_ms(leng.dims, llens[lwin[0]:lwin[1]], 3 + args.max_depth, args.dtype,
                                   leng.max_mel_frames() - lparams.padding, gen_lens=lgen, encoder_peak=lenc_peak)
             lwork = lrl.pop("_work")
@@ -540,7 +539,7 @@ def main() -> None:
                        "windows": n_win, "beam_size": args.beam, "max_depth": args.max_depth,
                        "encoder_gemm": {"f16x3": "split precision: three fp16 MFMAs per product on fp16 hi / lo pieces, f32 "
                                                  "accumulate (f32-grade results; WHISPER_HIP_ENCODER_SPLIT=0 selects exact-f32 MFMA)",
-                                        "bf16": "bf16 MFMA", "f32": "exact-f32 MFMA"}[enc_gemm],
+                                        "f32": "exact-f32 MFMA"}[enc_gemm],
                        "tokens_out": len(tokens) if tokens is not None else 0,
                        "parallelism": f"windows sharded over {world} GPU(s), 1 token all-gather"},
             "roofline": roofline,

@@ -39,8 +39,10 @@ typedef enum wb_status {
 } wb_status;
 
 /* compute_dtype for wb_model_load_*: the arithmetic the GEMMs run in. */
-enum { WB_F32 = 0,     /* exact-f32 MFMA (v_mfma_f32_32x32x2_f32): the parity path */
-       WB_BF16 = 1 };  /* bf16 MFMA, f32 accumulate: the speed path               */
+enum { WB_F32 = 0,     /* f32 results: exact-f32 MFMA, and the split-precision fp16 MFMA kernel (three products per pair,
+                          f32 accumulate: f32-grade) for the encoder side -- see wb_model_encoder_gemm */
+       WB_BF16 = 1 };  /* RETIRED in round 4 (wb_model_load_* return WB_ERR_ARG): plain bf16 inputs cannot hold the
+                          path's 1e-3 logit tolerance; the 16-bit matrix path is the split-precision kernel above */
 
 typedef struct wb_model wb_model;     /* Whisper<B>            src/model/mod.rs:41-45   */
 typedef struct wb_session wb_session; /* per window-batch decode state (new: the
@@ -100,7 +102,6 @@ int wb_model_set_frame_limit(wb_model* m, int whisper_geometry);
  *   1 = split precision: three fp16 MFMAs per product on fp16 hi / lo pieces, f32 accumulation -- f32-grade results
  *       (default for f32 models; WHISPER_HIP_ENCODER_SPLIT=0 at load time selects 0, and a model whose activations leave
  *       fp16's range, |x| >= 65504, falls back to 0 by itself: the pass is repeated, the answer changes from then on)
- *   2 = bf16 MFMA (compute_dtype WB_BF16: the speed path)
  * Replaces nothing in the reference (its Linear is Burn's, mod.rs:377-379); a caller reports it next to its timings. */
 int wb_model_encoder_gemm(const wb_model* m);
 

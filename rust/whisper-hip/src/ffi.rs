@@ -58,7 +58,7 @@ pub const WB_ERR_HIP: c_int = -4;
 pub const WB_ERR_OOM: c_int = -5;
 pub const WB_ERR_STATE: c_int = -6;
 pub const WB_F32: c_int = 0;
-pub const WB_BF16: c_int = 1;
+pub const WB_BF16: c_int = 1; // retired: wb_model_load_* return an error
 
 extern "C" {
     pub fn wb_model_load_dump_dir(dir: *const c_char, device: c_int, compute_dtype: c_int, out: *mut *mut wb_model) -> c_int;

@@ -273,9 +273,9 @@ def test_end_to_end_roofline_model_of_the_bench():
     lens = [238559, 238559, 98882]                          # the 30 s bench workload
     a = bench.e2e_roofline_ms(dims, lens, 103, "f32")
     b = bench.e2e_roofline_ms(dims, lens, 206, "f32")
-    c = bench.e2e_roofline_ms(dims, lens, 103, "bf16")
+    c = bench.e2e_roofline_ms(dims, lens, 103, "f32", encoder_peak="f16x3")
     assert abs(b["decode"] - 2 * a["decode"]) < 1e-9 and b["mel"] == a["mel"]
-    assert c["encoder_and_cross_kv"] < a["encoder_and_cross_kv"] and c["decode"] < a["decode"]
+    assert c["encoder_and_cross_kv"] < a["encoder_and_cross_kv"] and c["decode"] == a["decode"]
     frames = sum(n // 160 for n in lens)
     assert abs(a["mel"] - 960.0 * frames / 8e12 * 1e3) < 1e-12
     # logits stream alone: 4 * V * d bytes per step

@@ -110,7 +110,6 @@ int wb_model_set_frame_limit(wb_model* m, int whisper_geometry) {
 
 int wb_model_encoder_gemm(const wb_model* m) {
   if (!m) return WB_ERR_ARG;
-  if (m->compute_dtype == WB_BF16) return 2;
   return m->split_active() ? 1 : 0;        // (0 as well once the range guard of the split kernel has tripped)
 }
 

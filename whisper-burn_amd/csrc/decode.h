@@ -44,7 +44,6 @@ inline StepLayout make_step_layout(int S, int W) {
 enum { PRO_PLAIN = 0, PRO_GELU = 1, PRO_ATTN = 2, PRO_LN = 3 };
 struct GemvArgs {
   const float* W = nullptr; int ldw = 0;    // [K][ldw] row-major
-  const uint16_t* Wb = nullptr;             // speed path: the same matrix in bf16 (then W is not read)
   int K = 0, N = 0, KS = 1, KSL = 0;        // K-split count / slice length
   int pro = PRO_PLAIN;
   // PLAIN: src [rows][K].  GELU: src = partials [KSp][S][K] of lin1, pbias.  ATTN: src = chunk partials.

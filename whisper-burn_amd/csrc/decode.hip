@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void dec_resolve_ln_kernel(const int* __restri
 // wave per row folds x + pending partials, takes the LayerNorm statistics with shuffles only, and stages
 // the block's K-slice.  CT = 64 (logits) doubles the blocks per CU so that one block's prologue and
 // statistics epilogue overlap another block's weight stream.
-template <int MR, int XLD, int DPL, bool LN, bool STATS, bool WBF, int CT>
+template <int MR, int XLD, int DPL, bool LN, bool STATS, int CT>
 __global__ __launch_bounds__(256, (MR >= 8 && DPL >= 16) ? 1 : 2) void dec_gemv_kernel(GemvArgs a) {
   constexpr int LPR = CT / 4, G = 64 / LPR, KH = 16 * G;
   __shared__ __attribute__((aligned(16))) float xbuf[MR * XLD];   // input rows; later the cross-wave reduction buffer
@@ -227,13 +227,7 @@ __global__ __launch_bounds__(256, (MR >= 8 && DPL >= 16) ? 1 : 2) void dec_gemv_
       const int ku = 2 * KH * it + (j >> 2) * KH;      // block-uniform; kn is a multiple of KH
       if (ku < kn) {
         const int64_t off = wbase + (int64_t)(ku + (j & 3)) * ldw;
-        if constexpr (WBF) {                           // speed path: the same [K][ldw] matrix in bf16
-          const uint2 u = *reinterpret_cast<const uint2*>(a.Wb + off + voff);
-          wr[j] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
-                              __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
-        } else {
-          wr[j] = *reinterpret_cast<const float4*>(a.W + off + voff);
-        }
+        wr[j] = *reinterpret_cast<const float4*>(a.W + off + voff);
       }
     }
   };
@@ -1291,21 +1285,15 @@ static void launch_gemv_k(K kernel, hipStream_t st, dim3 grid, const GemvArgs& a
   WB_KLAUNCH(kernel, grid, dim3(256), 0, st, a);
 }
 
-struct GemmvDummy;
-template <int MR, int XLD, bool LN, bool STATS, bool WBF>
-static void launch_gemv_dpl2(hipStream_t st, dim3 grid, const GemmvDummy*, const GemvArgs& a) {
-  constexpr int CT = STATS ? GV_CT_LOGITS : GV_CT;
-  if (!LN) { launch_gemv_k(dec_gemv_kernel<MR, XLD, 1, LN, STATS, WBF, CT>, st, grid, a); return; }
-  if (a.K <= 384) launch_gemv_k(dec_gemv_kernel<MR, XLD, LN ? 6 : 1, LN, STATS, WBF, CT>, st, grid, a);
-  else if (a.K <= 512) launch_gemv_k(dec_gemv_kernel<MR, XLD, LN ? 8 : 1, LN, STATS, WBF, CT>, st, grid, a);
-  else if (a.K <= 768) launch_gemv_k(dec_gemv_kernel<MR, XLD, LN ? 12 : 1, LN, STATS, WBF, CT>, st, grid, a);
-  else if (a.K <= 1024) launch_gemv_k(dec_gemv_kernel<MR, XLD, LN ? 16 : 1, LN, STATS, WBF, CT>, st, grid, a);
-  else launch_gemv_k(dec_gemv_kernel<MR, XLD, LN ? 20 : 1, LN, STATS, WBF, CT>, st, grid, a);
-}
 template <int MR, int XLD, bool LN, bool STATS>
 static void launch_gemv_dpl(hipStream_t st, dim3 grid, const GemvArgs& a) {
-  if (a.Wb) launch_gemv_dpl2<MR, XLD, LN, STATS, true>(st, grid, nullptr, a);
-  else launch_gemv_dpl2<MR, XLD, LN, STATS, false>(st, grid, nullptr, a);
+  constexpr int CT = STATS ? GV_CT_LOGITS : GV_CT;
+  if (!LN) { launch_gemv_k(dec_gemv_kernel<MR, XLD, 1, LN, STATS, CT>, st, grid, a); return; }
+  if (a.K <= 384) launch_gemv_k(dec_gemv_kernel<MR, XLD, LN ? 6 : 1, LN, STATS, CT>, st, grid, a);
+  else if (a.K <= 512) launch_gemv_k(dec_gemv_kernel<MR, XLD, LN ? 8 : 1, LN, STATS, CT>, st, grid, a);
+  else if (a.K <= 768) launch_gemv_k(dec_gemv_kernel<MR, XLD, LN ? 12 : 1, LN, STATS, CT>, st, grid, a);
+  else if (a.K <= 1024) launch_gemv_k(dec_gemv_kernel<MR, XLD, LN ? 16 : 1, LN, STATS, CT>, st, grid, a);
+  else launch_gemv_k(dec_gemv_kernel<MR, XLD, LN ? 20 : 1, LN, STATS, CT>, st, grid, a);
 }
 
 void launch_dec_gemv(hipStream_t st, const GemvArgs& a, int n_rows_hint, bool stats) {

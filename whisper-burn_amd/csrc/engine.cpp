@@ -33,20 +33,14 @@ static int upload(hipStream_t st, DevMem& dst, const void* src, size_t bytes) {
   return WB_OK;
 }
 
-// Dispatch on the model's compute dtype: exact-f32 MFMA (parity path) or bf16 MFMA (speed path) when the
-// weight has a bf16 copy and the shape fits that kernel (the conv1 gather stays on the f32 kernel).
-int gemm_dispatch(const wb_model* m, hipStream_t st, const GemmArgs& a, const uint16_t* wt, int ldwt, const uint16_t* sh,
-                  const uint16_t* sl) {
+// Dispatch: the split-precision fp16 MFMA kernel when the weight carries split copies (sh, sl: [N][ldwt] fp16) and the shape
+// fits it, else the exact-f32 MFMA kernel (the conv1 gather, split-K launches, decoder-side weights).
+int gemm_dispatch(const wb_model* m, hipStream_t st, const GemmArgs& a, int ldwt, const uint16_t* sh, const uint16_t* sl) {
   // exact-f32 models: encoder-side weights that carry a split copy go through the three-product fp16 kernel
   if (m->split_active() && sh && sl && a.conv1_tstride == 0 && a.K % 32 == 0 && ldwt % 8 == 0 && a.ksplit <= 1) {
     GemmArgs g = a;
     g.range_flag = m->split_flag_dev;
     WB_REQUIRE(launch_gemm_f16x3(st, g, sh, sl, ldwt) == 0, WB_ERR_SHAPE, "split gemm: unsupported shape M=%d N=%d K=%d", a.M,
-               a.N, a.K);
-    return WB_OK;
-  }
-  if (m->compute_dtype == WB_BF16 && wt && a.conv1_tstride == 0 && a.K % 32 == 0 && ldwt % 8 == 0) {
-    WB_REQUIRE(launch_gemm_bf16(st, a, wt, ldwt) == 0, WB_ERR_SHAPE, "bf16 gemm: unsupported shape M=%d N=%d K=%d", a.M,
                a.N, a.K);
     return WB_OK;
   }
@@ -68,9 +62,9 @@ int split_guarded(wb_model* m, hipStream_t st, const std::function<int()>& body)
   return body();
 }
 
-// GEMM against a model weight: `w` supplies the bf16 copy for the speed path (null: f32 kernel only).
+// GEMM against a model weight: `w` supplies the split copies (null: f32 kernel only).
 static int gemm(const wb_model* m, hipStream_t st, const GemmArgs& a, const LinearW* w) {
-  return gemm_dispatch(m, st, a, w ? w->wt : nullptr, w ? w->k : 0, w ? w->sh : nullptr, w ? w->sl : nullptr);
+  return gemm_dispatch(m, st, a, w ? w->k : 0, w ? w->sh : nullptr, w ? w->sl : nullptr);
 }
 
 // y = x + (h W + b) for a long contraction (the MLP's second matrix, K = 4 d): K in blocks of GEMM_KBLOCK rows, each block's
@@ -80,7 +74,7 @@ static int gemm(const wb_model* m, hipStream_t st, const GemmArgs& a, const Line
 // exact result.  Blocks of 1024 cost one extra read + write of the [M][d] result per block (~1.5 % of the encoder).
 constexpr int GEMM_KBLOCK = 1024;
 static int gemm_residual_kblocked(const wb_model* m, hipStream_t st, const float* A, int M, const LinearW& w, float* x) {
-  const bool blocked = m->compute_dtype != WB_BF16 && w.k >= 2 * GEMM_KBLOCK && w.k % GEMM_KBLOCK == 0;
+  const bool blocked = w.k >= 2 * GEMM_KBLOCK && w.k % GEMM_KBLOCK == 0;
   const int kb = blocked ? GEMM_KBLOCK : w.k;
   for (int k0 = 0; k0 < w.k; k0 += kb) {
     GemmArgs g;
@@ -88,7 +82,7 @@ static int gemm_residual_kblocked(const wb_model* m, hipStream_t st, const float
     g.bias = k0 == 0 ? w.b : nullptr;              // first block: + bias + the residual stream; later blocks: + the running sum
     g.residual = x; g.ldr = w.n;
     g.M = M; g.N = w.n; g.K = kb;
-    WB_TRY(gemm_dispatch(m, st, g, blocked ? nullptr : w.wt, w.k, w.sh ? w.sh + k0 : nullptr, w.sl ? w.sl + k0 : nullptr));
+    WB_TRY(gemm_dispatch(m, st, g, w.k, w.sh ? w.sh + k0 : nullptr, w.sl ? w.sl + k0 : nullptr));
   }
   return WB_OK;
 }
@@ -266,7 +260,7 @@ static int run_decoder_stateless_body(wb_model* m, hipStream_t st, Workspace& ws
   GemmArgs lg;
   lg.A = h; lg.lda = d; lg.B = m->tok_emb_t; lg.ldb = m->vocab_ld; lg.C = logits_dev; lg.ldc = V;
   lg.M = rows; lg.N = V; lg.K = d;
-  WB_TRY(gemm_dispatch(m, st, lg, m->tok_emb_bf, m->dims.n_text_state));
+  WB_TRY(gemm_dispatch(m, st, lg, 0));
   WB_HIP(hipGetLastError());
   return WB_OK;
 }

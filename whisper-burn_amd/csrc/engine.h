@@ -35,9 +35,9 @@ int split_guarded(wb_model* m, hipStream_t st, const std::function<int()>& body)
 int run_decoder_stateless(wb_model* m, hipStream_t st, Workspace& ws, const int32_t* tokens_dev, int n, int L,
                           const float* enc_dev, int C, float* logits_dev);
 
-// f32 (parity) or bf16 (speed) MFMA GEMM according to the model's compute dtype; wt = bf16 [N][ldwt] copy or null.
-int gemm_dispatch(const wb_model* m, hipStream_t st, const GemmArgs& a, const uint16_t* wt, int ldwt,
-                  const uint16_t* sh = nullptr, const uint16_t* sl = nullptr);
+// split-precision fp16 MFMA GEMM when split copies sh / sl ([N][ldwt] fp16) are given and the shape fits, else exact-f32 MFMA
+int gemm_dispatch(const wb_model* m, hipStream_t st, const GemmArgs& a, int ldwt, const uint16_t* sh = nullptr,
+                  const uint16_t* sl = nullptr);
 
 // Process-wide mel constant tables for (device, sample_rate).
 int get_mel_tables(int device, double sample_rate, const MelTables** out_dev);

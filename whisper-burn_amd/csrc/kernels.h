@@ -89,8 +89,6 @@ struct GemmArgs {
                                                  // finite, i.e. an operand left fp16's range (|x| >= 65504)
 };
 int launch_gemm_f32(hipStream_t st, const GemmArgs& a);   // exact-f32 MFMA (v_mfma_f32_32x32x2_f32)
-// speed path (gemm_bf16.hip): same contract, weight given as Wt [N][ldwt] bf16 (K-contiguous); a.B ignored
-int launch_gemm_bf16(hipStream_t st, const GemmArgs& a, const uint16_t* Wt, int ldwt);
 // split precision (gemm_f16x3.hip): f32-grade products from three fp16 MFMAs; weight pre-split as Wh, Wl [N][ldwt] fp16
 int launch_gemm_f16x3(hipStream_t st, const GemmArgs& a, const uint16_t* Wh, const uint16_t* Wl, int ldwt);
 void launch_split_weight_f16(hipStream_t st, const float* W, int K, int N, uint16_t* hi, uint16_t* lo);

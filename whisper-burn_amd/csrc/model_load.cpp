@@ -216,8 +216,10 @@ static int usize_of(Builder& B, const std::string& name, int* v) {
 }
 
 int build_model(TensorMap& tm, int device, int compute_dtype, wb_model** out) {
-  WB_REQUIRE(compute_dtype == WB_F32 || compute_dtype == WB_BF16, WB_ERR_ARG, "bad compute_dtype %d",
-             compute_dtype);
+  WB_REQUIRE(compute_dtype != WB_BF16, WB_ERR_ARG,
+             "compute_dtype WB_BF16 was retired in round 4: the 16-bit matrix path is the split-precision fp16 kernel of WB_F32 "
+             "models (f32-grade results; wb_model_encoder_gemm)");
+  WB_REQUIRE(compute_dtype == WB_F32, WB_ERR_ARG, "bad compute_dtype %d", compute_dtype);
   Builder B(tm);
   auto m = std::make_unique<wb_model>();
   wb_dims& D = m->dims;
@@ -375,53 +377,11 @@ int build_model(TensorMap& tm, int device, int compute_dtype, wb_model** out) {
   }
   m->ckv_all = lin(ckv);
   m->ln_dec = ln(ln_dec);
-  if (compute_dtype == WB_BF16) {
-    // ---- speed path: bf16 copies (round to nearest even) of every GEMM weight ----
-    std::vector<uint16_t> hb;
-    auto bf = [](float f) -> uint16_t {
-      uint32_t u; memcpy(&u, &f, 4);
-      u += 0x7fffu + ((u >> 16) & 1u);
-      return (uint16_t)(u >> 16);
-    };
-    auto reserve16 = [&](size_t n) { size_t off = (hb.size() + 127) & ~size_t(127); hb.resize(off + n, 0); return off; };
-    struct Fix { LinearW* l; size_t wt, wkn; };
-    std::vector<Fix> fixes;
-    auto add = [&](LinearW& l, const Off& o, bool decode_gemv) {
-      const float* W = &B.host[o.w];
-      Fix f{&l, reserve16((size_t)o.k * o.n), SIZE_MAX};
-      for (int kk = 0; kk < o.k; kk++)
-        for (int nn = 0; nn < o.n; nn++) hb[f.wt + (size_t)nn * o.k + kk] = bf(W[(size_t)kk * o.n + nn]);
-      if (decode_gemv) {
-        f.wkn = reserve16((size_t)o.k * o.n);
-        for (size_t i = 0; i < (size_t)o.k * o.n; i++) hb[f.wkn + i] = bf(W[i]);
-      }
-      fixes.push_back(f);
-    };
-    add(m->conv2, conv2, false);
-    for (int i = 0; i < D.n_audio_layer; i++) {
-      add(m->enc[i].qkv, eo[i].qkv, false); add(m->enc[i].out, eo[i].out, false);
-      add(m->enc[i].mlp1, eo[i].mlp1, false); add(m->enc[i].mlp2, eo[i].mlp2, false);
-    }
-    for (int i = 0; i < NL; i++) {
-      add(m->dec[i].qkv, dof[i].qkv, true); add(m->dec[i].out, dof[i].out, true);
-      add(m->dec[i].cq, dof[i].cq, true); add(m->dec[i].cout, dof[i].cout, true);
-      add(m->dec[i].mlp1, dof[i].mlp1, true); add(m->dec[i].mlp2, dof[i].mlp2, true);
-    }
-    add(m->ckv_all, ckv, false);
-    const size_t e_bf = reserve16((size_t)V * d), et_bf = reserve16((size_t)Vp * d);
-    for (size_t i = 0; i < (size_t)V * d; i++) hb[e_bf + i] = bf(B.host[emb + i]);
-    for (size_t i = 0; i < (size_t)Vp * d; i++) hb[et_bf + i] = bf(B.host[emb_t + i]);
-    WB_TRY(m->arena_bf16.alloc(hb.size() * 2));
-    WB_HIP(hipMemcpy(m->arena_bf16.p, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
-    uint16_t* b16 = m->arena_bf16.as<uint16_t>();
-    for (auto& f : fixes) { f.l->wt = b16 + f.wt; if (f.wkn != SIZE_MAX) f.l->wkn = b16 + f.wkn; }
-    m->tok_emb_bf = b16 + e_bf; m->tok_emb_t_bf = b16 + et_bf;
-  }
-  // ---- exact-f32 models: fp16 hi / lo copies of the encoder-side GEMM weights for the three-product kernel
+  // ---- fp16 hi / lo copies of the encoder-side GEMM weights for the three-product kernel
   // (gemm_f16x3.hip: f32-grade results at ~2x the rate of the exact-f32 MFMA); made on the device, once.
   // WHISPER_HIP_ENCODER_SPLIT=0 keeps the exact-f32 MFMA kernel for everything.
   static const bool split_enabled = []() { const char* e = getenv("WHISPER_HIP_ENCODER_SPLIT"); return e ? e[0] == '1' : WB_ENCODER_SPLIT_DEFAULT; }();
-  if (compute_dtype != WB_BF16 && split_enabled) {
+  if (split_enabled) {
     std::vector<LinearW*> cand, ws;
     for (int i = 0; i < D.n_audio_layer; i++) {
       cand.push_back(&m->enc[i].qkv); cand.push_back(&m->enc[i].out); cand.push_back(&m->enc[i].mlp1); cand.push_back(&m->enc[i].mlp2);

@@ -175,7 +175,7 @@ static int session_finish_encode(wb_session* s, const MelBatch& mb) {
     g.A = s->enc_out.as<float>(); g.lda = d; g.B = m->ckv_all.w; g.ldb = ldkv_all; g.C = s->ckv.as<float>(); g.ldc = ldkv_all;
     g.bias = m->ckv_all.b; g.M = rows_all; g.N = ldkv_all; g.K = d;
     g.col_scale = m->qk_scale; g.col_scale_period = 2 * d; g.col_scale_width = d;   // K * s (mod.rs:510-514)
-    WB_TRY(gemm_dispatch(m, s->st, g, m->ckv_all.wt, m->ckv_all.k, m->ckv_all.sh, m->ckv_all.sl));
+    WB_TRY(gemm_dispatch(m, s->st, g, m->ckv_all.k, m->ckv_all.sh, m->ckv_all.sl));
     tm.stop();
     if (tm.on) { WB_HIP(hipStreamSynchronize(s->st)); tm.collect(); }
   }
@@ -437,7 +437,7 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
   const int* win_C = win_row0 + s->W;
   const int n = n_launch;
   // algorithmic bytes of the tagged launches (profiling): the weights a launch streams + the cached K/V it reads
-  const double wsz = m->compute_dtype == WB_BF16 ? 2.0 : 4.0, dd = (double)d * d;
+  const double wsz = 4.0, dd = (double)d * d;
   double ckv_bytes = 0;
   for (int c : s->C) ckv_bytes += 8.0 * c * d;                    // K and V rows of one layer, f32
   const double self_kv_bytes = 8.0 * (double)n * (s->step + s->prof_step_off + 1) * d;
@@ -452,7 +452,6 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
   auto gemv = [&](const LinearW& w, int ks, int ksl, int pro, const float* src, int ld_src, float* P) {
     GemvArgs a;
     a.W = w.w; a.ldw = w.n; a.K = w.k; a.N = w.n; a.KS = ks; a.KSL = ksl; a.pro = pro; a.src = src; a.ld_src = ld_src;
-    a.Wb = m->compute_dtype == WB_BF16 ? w.wkn : nullptr;
     a.P = P; a.st = dst; a.S = S;
     return a;
   };
@@ -474,7 +473,7 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
       g.A = A; g.lda = w.k; g.B = w.w; g.ldb = w.n; g.C = P; g.ldc = w.n; g.M = n; g.N = w.n; g.K = w.k;
       g.ksplit = ks; g.c_split_stride = (int64_t)S * w.n;
       prof_tag(KC_B_GEMM, wsz * (double)w.k * w.n + 4.0 * n * ((double)w.k + (double)ks * w.n));
-      return gemm_dispatch(m, st, g, w.wt, w.k);
+      return gemm_dispatch(m, st, g, w.k);
     };
     auto resolve = [&](const float* pend, int ks_pend, const float* pbias, const LayerNormW& ln) {
       prof_tag(KC_B_RESOLVE_LN, 4.0 * n * d * (ks_pend + 3));
@@ -484,7 +483,7 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
     // the skinny weight-stream GEMM (decode_batch.hip) for up to 64 rows of exact-f32 models: every weight row in flight
     // from the start.  WHISPER_HIP_BATCH_SKINNY=0 keeps the tiled GEMM.
     static const bool skinny_enabled = []() { const char* e = getenv("WHISPER_HIP_BATCH_SKINNY"); return !(e && e[0] == '0'); }();
-    const bool skinny = skinny_enabled && m->compute_dtype != WB_BF16 && n <= 64 && s->sk_qkv > 0 && s->sk_o > 0 &&
+    const bool skinny = skinny_enabled && n <= 64 && s->sk_qkv > 0 && s->sk_o > 0 &&
                         s->sk_1 > 0 && s->sk_2 > 0;
     auto thin = [&](const LinearW& w, int ks, const float* A, float* P) -> int {
       SkinnyArgs g;
@@ -506,7 +505,7 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
     // Measured both ways (profiles/r03_j_*): small, 10 min +3 %; large-v2 (327 KB of Wq per block, 220 VGPRs)
     // 441x -> 433x, so d = 1024 / 1280 keep the launches.  WHISPER_HIP_CROSS_STREAM_FUSE=0 / 1 forces it off / on.
     static const int stream_fuse_mode = []() { const char* e = getenv("WHISPER_HIP_CROSS_STREAM_FUSE"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-    const bool stream_fused = cross_stream && m->compute_dtype != WB_BF16 && cross_stream_can_fuse(d) &&
+    const bool stream_fused = cross_stream && cross_stream_can_fuse(d) &&
                               (stream_fuse_mode < 0 ? d <= 768 : stream_fuse_mode == 1);
     const int kq = skinny ? s->sk_qkv : s->ks_qkv, ko = skinny ? s->sk_o : s->ks_o;
     for (int l = 0; l < NL; l++) {
@@ -568,7 +567,7 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
       g.A = h; g.lda = d; g.B = m->tok_emb_t; g.ldb = m->vocab_ld; g.C = s->logits.as<float>(); g.ldc = V;
       g.M = n; g.N = V; g.K = d;
       prof_tag(KC_B_LOGITS_GEMM, wsz * (double)V * d + 4.0 * n * ((double)d + V));
-      WB_TRY(gemm_dispatch(m, st, g, m->tok_emb_bf, d));
+      WB_TRY(gemm_dispatch(m, st, g, d));
       tm_logits.stop();
       prof_tag(KC_B_TOPK_ROWS, 4.0 * (double)n * V);
       launch_dec_topk_rows(st, s->state.as<int>(), n, s->logits.as<float>(), V, s->mask.as<float>(), use_mask, k, out_id_dev,
@@ -585,11 +584,11 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
   // small models, exact-f32 weights, few enough blocks for one resident wave of them: the cross-attention blocks
   // project their own queries (decode.hip)
   static const bool fuse_q_enabled = []() { const char* e = getenv("WHISPER_HIP_FUSE_Q"); return !(e && e[0] == '0'); }();
-  const bool fuse_q = fuse_q_enabled && fuse_ln && cross_attn_can_fuse_q(d) && m->compute_dtype != WB_BF16 &&
+  const bool fuse_q = fuse_q_enabled && fuse_ln && cross_attn_can_fuse_q(d) &&
                       s->n_chunks * H * s->W <= 256;
   // sublayer fusion (decode_fused.hip): self-attention block and MLP block are ONE launch each
   static const bool fuse_sub_enabled = []() { const char* e = getenv("WHISPER_HIP_FUSE_SUB"); return !(e && e[0] == '0'); }();
-  const bool fuse_sub = fuse_sub_enabled && dec_fused_supported(d) && m->compute_dtype != WB_BF16 && d == 64 * H;
+  const bool fuse_sub = fuse_sub_enabled && dec_fused_supported(d) && d == 64 * H;
   // the whole cross-attention sublayer (LN + Wq + attention over the window's cached K/V + Wo) as one launch per
   // (head, beam): 10.6 us against 9.5 + 5.9 us (+ a kernel boundary) for chunked cross-attention + out-projection GEMV
   // once the block keeps its head's whole K in flight (decode_fused.hip); WHISPER_HIP_FUSE_X=0 restores the chunked pair
@@ -700,7 +699,6 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
     ScopedTimer tm_logits(st, 6);
     GemvArgs a;
     a.W = m->tok_emb_t; a.ldw = m->vocab_ld; a.K = d; a.N = V; a.KS = 1; a.KSL = d;
-    a.Wb = m->compute_dtype == WB_BF16 ? m->tok_emb_t_bf : nullptr;
     a.P = s->logits.as<float>(); a.st = dst; a.S = S;
     a.mask = s->mask.as<float>(); a.use_mask = use_mask; a.topk = k; a.tstats = s->tstats.as<float>(); a.ct = s->ct_v;
     prof_tag(KC_LOGITS, wsz * (double)V * d + 4.0 * ((double)n * d + (double)n * V));
@@ -1045,7 +1043,7 @@ int session_greedy_chain(wb_session* s, const int32_t* prompt, int eot, int max_
     const char* a = getenv("WHISPER_HIP_FUSE_SUB"); const char* b = getenv("WHISPER_HIP_FUSE_X");
     return !(a && a[0] == '0') && !(b && b[0] == '0');
   }();
-  bool persist = persist_enabled && fused_enabled && fuse_ln && max_depth > 0 && m->compute_dtype != WB_BF16 &&
+  bool persist = persist_enabled && fused_enabled && fuse_ln && max_depth > 0 &&
                  dec_fused_supported(m->dims.n_text_state) && m->dims.n_text_state == 64 * m->dims.n_text_head &&
                  dec_persist_supported(m->dims.n_text_state, W, s->maxC);
   if (persist) {

@@ -86,8 +86,6 @@ int build_model(TensorMap& tm, int device, int compute_dtype, wb_model** out);
 struct LayerNormW { float* g = nullptr; float* b = nullptr; float eps = 1e-5f; };
 struct LinearW {
   float* w = nullptr; float* b = nullptr; int k = 0, n = 0;   // w: [k][n] row-major f32
-  uint16_t* wt = nullptr;    // speed path: bf16 [n][k] (K-contiguous, MFMA GEMM operand)
-  uint16_t* wkn = nullptr;   // speed path: bf16 [k][n] (decode GEMV streams N contiguously); decoder weights only
   uint16_t* sh = nullptr; uint16_t* sl = nullptr;   // split-precision path: fp16 hi / lo * 2^11, [n][k] (encoder-side weights)
 };
 
@@ -134,14 +132,11 @@ struct wb_model {
   int max_mel_frames() const { return frame_limit_x2 ? 2 * dims.n_audio_ctx : dims.n_audio_ctx; }
   // all weights live in one arena allocation
   wb::DevMem arena;
-  wb::DevMem arena_bf16;      // WB_BF16: bf16 copies of the GEMM weights
   wb::DevMem arena_split;     // exact-f32 models with the split-precision encoder: fp16 hi / lo copies of the encoder-side weights
   // range guard of the split-precision kernel: a mapped host word the kernel raises when a result is not finite; once it
   // has tripped the model stays on the exact-f32 kernel (split_off)
   int* split_flag_host = nullptr; int* split_flag_dev = nullptr; int split_off = 0;
-  bool split_active() const { return compute_dtype != WB_BF16 && arena_split.p && !split_off; }
-  uint16_t* tok_emb_bf = nullptr;     // E   [V][d] bf16 (already K-contiguous for logits = x E^T)
-  uint16_t* tok_emb_t_bf = nullptr;   // E^T [d][vocab_ld] bf16
+  bool split_active() const { return arena_split.p && !split_off; }
   // encoder
   wb::LinearW conv1;   // repacked [240 = ci*3+kk][d]
   wb::LinearW conv2;   // repacked [3d = kk*d+ci][d]

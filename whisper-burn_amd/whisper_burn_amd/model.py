@@ -220,8 +220,8 @@ class Whisper:
 
     def encoder_gemm(self) -> str:
         """Arithmetic of the encoder-side Linear layers: "f32" (exact-f32 MFMA), "f16x3" (split precision: three fp16 MFMAs
-        per product, f32-grade; the default) or "bf16"."""
-        return ("f32", "f16x3", "bf16")[_lib.load().wb_model_encoder_gemm(self._h)]
+        per product, f32-grade; the default)."""
+        return ("f32", "f16x3")[_lib.load().wb_model_encoder_gemm(self._h)]
 
     def max_mel_frames(self) -> int:
         """Mel frames one window may hold (what transcribe.rs:32 calls n_ctx_max_encoder)."""
