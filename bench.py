@@ -337,6 +337,8 @@ def main() -> None:
                   "mel_frames_per_s": round(n_frames_local / (mel_ms / n_prof * 1e-3), 1) if mel_ms > 0 else None,
                   "mel_GBps_algorithmic": round(960.0 * n_frames_local / (mel_ms / n_prof * 1e-3) / 1e9, 2) if mel_ms > 0 else None}
 
+    enc_gemm_after = eng.encoder_gemm()     # ("f32" after "f16x3" at load: the split kernel's range guard tripped during the run)
+
     # ---- the frontend alone (BASELINE.json's second metric): >= 100 batched reference windows, PCM resident ----
     mel_frontend = None
     if rank == 0:
@@ -444,8 +446,11 @@ def main() -> None:
             lstep()
         barrier()
         t0 = time.perf_counter()
+        l_step_s = []
         for _ in range(l_steps):
+            t1 = time.perf_counter()
             ltok, lrows = lstep()
+            l_step_s.append(time.perf_counter() - t1)   # (host-side per-step times: the leg's value is over the whole region)
         barrier()
         ldt = time.perf_counter() - t0
         if world > 1:
@@ -486,6 +491,10 @@ def main() -> None:
                                            "profiled pass attaches events to every launch, which inflates its wall time -- only its per-kernel "
                                            "durations are used"},
                         "e2e_roofline_ms_per_step": {k: round(v, 3) for k, v in lrl.items()},
+                        "encoder_gemm": {"at_load": "f16x3" if leng_split else "f32", "after_the_leg": leng.encoder_gemm(),
+                                         "note": "f16x3 -> f32 would mean the split-precision kernel's range guard tripped "
+                                                 "(an activation outside fp16's range) and the encoder fell back to exact f32"},
+                        "step_ms": [round(x * 1e3, 1) for x in l_step_s],
                         "target": ">= 50x real-time on 8 GPUs (BASELINE.json north_star)"}
         leng.close()
 
@@ -540,6 +549,7 @@ def main() -> None:
                        "encoder_gemm": {"f16x3": "split precision: three fp16 MFMAs per product on fp16 hi / lo pieces, f32 "
                                                  "accumulate (f32-grade results; WHISPER_HIP_ENCODER_SPLIT=0 selects exact-f32 MFMA)",
                                         "f32": "exact-f32 MFMA"}[enc_gemm],
+                       "encoder_gemm_after_the_run": enc_gemm_after,
                        "tokens_out": len(tokens) if tokens is not None else 0,
                        "parallelism": f"windows sharded over {world} GPU(s), 1 token all-gather"},
             "roofline": roofline,
