@@ -441,7 +441,7 @@ def main() -> None:
             return shard.transcribe_sharded(ldecode, wb.stitch_windows, ln_win, rank, world, row_stride,
                                             device=dev if world > 1 else None)
 
-        l_steps, l_warm = 3, 1
+        l_steps, l_warm = 5, 1
         for _ in range(l_warm):
             lstep()
         barrier()
