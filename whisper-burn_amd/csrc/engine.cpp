@@ -77,11 +77,15 @@ static int gemm_residual_kblocked(const wb_model* m, hipStream_t st, const float
   const bool blocked = w.k >= 2 * GEMM_KBLOCK && w.k % GEMM_KBLOCK == 0;
   const int kb = blocked ? GEMM_KBLOCK : w.k;
   for (int k0 = 0; k0 < w.k; k0 += kb) {
+    // In-place accumulation (C == residual == x): sound only because every GEMM kernel reads residual[row][col] and writes
+    // C[row][col] from the SAME thread, once, with ksplit <= 1 (GemmArgs::residual: "may alias C") -- a split-K or
+    // multi-pass tile configuration would break it, hence the explicit ksplit below and the check in gemm_dispatch's callee.
     GemmArgs g;
     g.A = A + k0; g.lda = w.k; g.B = w.w + (size_t)k0 * w.n; g.ldb = w.n; g.C = x; g.ldc = w.n;
     g.bias = k0 == 0 ? w.b : nullptr;              // first block: + bias + the residual stream; later blocks: + the running sum
     g.residual = x; g.ldr = w.n;
-    g.M = M; g.N = w.n; g.K = kb;
+    g.M = M; g.N = w.n; g.K = kb; g.ksplit = 1;
+    WB_REQUIRE(g.residual == g.C && g.ksplit <= 1, WB_ERR_STATE, "k-blocked residual GEMM: aliasing contract");
     WB_TRY(gemm_dispatch(m, st, g, w.k, w.sh ? w.sh + k0 : nullptr, w.sl ? w.sl + k0 : nullptr));
   }
   return WB_OK;

@@ -79,7 +79,8 @@ struct GemmArgs {
   const float* B = nullptr; int ldb = 0;         // [K][N] row-major
   float* C = nullptr; int ldc = 0;
   const float* bias = nullptr;                   // [N]
-  const float* residual = nullptr; int ldr = 0;  // [M][N], added after activation (may alias C)
+  const float* residual = nullptr; int ldr = 0;  // [M][N], added after activation.  May alias C ONLY with ksplit <= 1: every
+                                                 // kernel reads residual[row][col] and writes C[row][col] from the same thread, once
   const float* aux = nullptr; const int32_t* aux_idx = nullptr; int ld_aux = 0;  // + aux[aux_idx[m]][n]
   float col_scale = 1.f; int col_scale_period = 0, col_scale_width = 0;  // out *= col_scale where (n % period) < width
   int M = 0, N = 0, K = 0;                       // K % 16 == 0
