@@ -105,7 +105,10 @@ __device__ __forceinline__ void dft20(cpx (&x)[20]) {
   }
 }
 
-__global__ __launch_bounds__(MEL_THREADS, 4) void mel_spectrogram_kernel(
+#ifndef WB_MEL_MIN_BLOCKS
+#define WB_MEL_MIN_BLOCKS 4
+#endif
+__global__ __launch_bounds__(MEL_THREADS, WB_MEL_MIN_BLOCKS) void mel_spectrogram_kernel(
     const float* __restrict__ pcm, const MelWindow* __restrict__ wins, const MelTables* __restrict__ tabs,
     float* __restrict__ out, int64_t win_stride, int row_stride, float* __restrict__ gmax, int bmax_stride, int pad,
     int pad_limit) {
@@ -272,19 +275,27 @@ __global__ __launch_bounds__(MEL_THREADS, 4) void mel_spectrogram_kernel(
       const int* meta = reinterpret_cast<const int*>(&lds[(m / 5) * 2 * FROW + TAP_OFF + 5 * MEL_MAX_TAPS + (m % 5) * 2]);
       s0v[r] = meta[0]; lenv[r] = meta[1];
     }
+    // chunk-major: the eight rows of the group advance together (eight independent sums: their LDS reads are in flight
+    // together -- a row-major loop waits for one row's chunk at a time: 1.09 -> 1.16 G frames/s, profiles/r04_h_mel_variants.txt); the trip count is the group's longest row,
+    // taps past a row's length are stored as zeros and Pf[s0 + t] stays inside the pair's region (finite FFT leftovers)
+    float accv[8];
+    int nch = 0;
+#pragma unroll
+    for (int r = 0; r < 8; r++) { accv[r] = 0.f; nch = max(nch, (lenv[r] + 3) >> 2); }
+    for (int c = 0; c < nch; c++) {
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        const int m = grp * 8 + r;
+        const float* tw = lds + (m / 5) * 2 * FROW + TAP_OFF + (m % 5) * MEL_MAX_TAPS;
+        const float4 w4 = *reinterpret_cast<const float4*>(tw + 4 * c);
+        const float* pp = Pf + s0v[r] + 4 * c;
+        accv[r] += w4.x * pp[0]; accv[r] += w4.y * pp[1]; accv[r] += w4.z * pp[2]; accv[r] += w4.w * pp[3];
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 8; r++) {
       const int m = grp * 8 + r;
-      const int s0 = s0v[r], len = lenv[r];
-      float acc = 0.f;
-      const float* tw = lds + (m / 5) * 2 * FROW + TAP_OFF + (m % 5) * MEL_MAX_TAPS;   // uniform over the half-wave
-      // taps past len are stored as zeros and Pf[s0 + t] stays inside the pair's region (finite FFT leftovers),
-      // so a chunk of four needs no predicate: its eight LDS reads are in flight together
-      for (int t0 = 0; t0 < len; t0 += 4) {
-        const float4 w4 = *reinterpret_cast<const float4*>(tw + t0);
-        const float p0 = Pf[s0 + t0], p1 = Pf[s0 + t0 + 1], p2 = Pf[s0 + t0 + 2], p3 = Pf[s0 + t0 + 3];
-        acc += w4.x * p0; acc += w4.y * p1; acc += w4.z * p2; acc += w4.w * p3;
-      }
+      const float acc = accv[r];
       // tensor_max_scalar(x, 1e-10) = relu(x - 1e-10) + 1e-10 (helper.rs:8-10); log10 = ln/ln10 (:24-27)
       // ln(x) / ln 10 (helper.rs:24-27) through the hardware log2 (v_log_f32, <= 1 ulp; the argument is >= 1e-10, normal):
       // log10 x = log2 x * log10 2 -- within 2e-7 of the reference's two-step form, tolerance class "mel"
