@@ -175,7 +175,7 @@ def test_production_key_ring_under_the_functional_model(emu_lib_prod):
     """The micro-model library compiles a 384-key ring so that small fixtures reach both of its code paths; the PRODUCT
     compiles 768 keys.  This runs the product's constant (`make prod`) at the real window lengths: C = 745 keys in one
     pass (the bench's geometry) and C = 1500 keys in two (the opt-in 30 s window), d = 384, persistent kernel and chain."""
-    jobs = [("prodring", {}), ("prodring", {"WHISPER_HIP_PERSIST": "0"}), ("prodring30", {})]
+    jobs = [("prodring", {}), ("prodring30", {"WHISPER_HIP_PERSIST": "0"}), ("prodring30", {})]
     futs = [_POOL.submit(_spawn, emu_lib_prod, which, env) for which, env in jobs]       # side by side
     for (which, env), f in zip(jobs, futs):
         p = f.result()
@@ -241,7 +241,7 @@ def test_two_ranks_shard_the_windows_of_the_real_engine(emu_lib):
 
 
 @pytest.mark.parametrize("extra", [["--large-v2-leg", "on", "--large-v2-seconds", "4"], ["--geometry", "whisper30", "--beam", "2"],
-                                   ["--encoder", "f32", "--large-v2-seconds", "4"]],
+                                   ["--encoder", "f32", "--large-v2-leg", "off", "--beam5-leg", "off"]],
                          ids=["default+large-v2-leg", "whisper30-beam2", "f32-encoder"])
 def test_bench_main_runs_to_its_json_line(emu_lib, extra):
     """bench.py cannot start without cuda:0, and a broken bench line cannot be repaired after a round: tools/
@@ -267,7 +267,7 @@ def test_bench_main_runs_to_its_json_line(emu_lib, extra):
     assert len(cb["runs_s"]) == 3
     assert out["config"]["encoder_gemm"].startswith("exact-f32" if "--encoder" in extra else "split precision")
     assert cb["depth"] == 4 and cb["depth32"]["depth"] == 4 and cb["depth32"]["value"] > 0
-    if "--beam" not in extra:             # the greedy reference-geometry line carries the reference's live beam-5 setting too
+    if "--beam" not in extra and "--beam5-leg" not in extra:   # the greedy reference-geometry line carries the live beam-5 setting too
         b5 = out["beam5"]
         assert b5["value"] > 0 and b5["steps"] == 2 and "beam_size 5" in b5["config"]["workload"]
     else:
