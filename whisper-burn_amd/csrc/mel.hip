@@ -108,6 +108,119 @@ __device__ __forceinline__ void dft20(cpx (&x)[20]) {
 #ifndef WB_MEL_MIN_BLOCKS
 #define WB_MEL_MIN_BLOCKS 4
 #endif
+
+#ifdef WB_MEL_PK_DFT
+// ---- opt-in (-DWB_MEL_PK_DFT; built and checked on the functional model in round 4, NOT yet measured or run on a GPU):
+// the same 20-point DFT with every complex value held as one 64-bit register pair and every butterfly written as ONE packed
+// instruction, the half-swaps and sign flips of "multiply by -i" / complex multiplication expressed through the VOP3P
+// op_sel / neg modifiers instead of register moves.  The compiler's own SLP packing of dft20() above leaves ~400 v_mov next
+// to ~380 packed operations (it builds the swapped pairs with moves); this form needs ~136 packed instructions per transform.
+typedef float f2 __attribute__((ext_vector_type(2)));
+#if defined(HIPEMU)
+// functional model: the helpers by their arithmetic (mul then fma, as the two-instruction forms below round)
+static inline f2 pk_add(f2 a, f2 b) { return a + b; }
+static inline f2 pk_sub(f2 a, f2 b) { return a - b; }
+static inline f2 pk_add_mi(f2 a, f2 b) { return f2{a.x + b.y, a.y - b.x}; }          // a - i b
+static inline f2 pk_add_pi(f2 a, f2 b) { return f2{a.x - b.y, a.y + b.x}; }          // a + i b
+static inline f2 pk_cmul(f2 a, f2 w) {                                                 // a * (w.x + i w.y)
+  f2 r = f2{a.x * w.x, a.y * w.x};
+  return f2{fmaf(-a.y, w.y, r.x), fmaf(a.x, w.y, r.y)};
+}
+static inline f2 pk_fma_lo(f2 a, f2 c, f2 acc) { return f2{fmaf(a.x, c.x, acc.x), fmaf(a.y, c.x, acc.y)}; }   // acc + a * c.x
+static inline f2 pk_fma_hi(f2 a, f2 c, f2 acc) { return f2{fmaf(a.x, c.y, acc.x), fmaf(a.y, c.y, acc.y)}; }   // acc + a * c.y
+static inline f2 pk_mul_lo(f2 a, f2 c) { return f2{a.x * c.x, a.y * c.x}; }
+static inline f2 pk_mul_hi(f2 a, f2 c) { return f2{a.x * c.y, a.y * c.y}; }
+#else
+__device__ __forceinline__ f2 pk_add(f2 a, f2 b) { return a + b; }
+__device__ __forceinline__ f2 pk_sub(f2 a, f2 b) { return a - b; }
+// a - i b = (a.x + b.y, a.y - b.x): LO = src0.lo + src1.hi, HI = src0.hi - src1.lo
+__device__ __forceinline__ f2 pk_add_mi(f2 a, f2 b) {
+  f2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// a + i b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ f2 pk_add_pi(f2 a, f2 b) {
+  f2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// a * (w.x + i w.y) = (a.x w.x - a.y w.y, a.y w.x + a.x w.y): two instructions, the twiddle one 64-bit constant pair
+__device__ __forceinline__ f2 pk_cmul(f2 a, f2 w) {
+  f2 r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(w));                 // (a.x w.x, a.y w.x)
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "+v"(r) : "v"(a), "v"(w));   // LO -= a.y w.y; HI += a.x w.y
+  return r;
+}
+// acc + a * c.x / acc + a * c.y (a complex value times one REAL constant of the pair c, both halves)
+__device__ __forceinline__ f2 pk_fma_lo(f2 a, f2 c, f2 acc) {
+  f2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(c), "v"(acc));
+  return r;
+}
+__device__ __forceinline__ f2 pk_fma_hi(f2 a, f2 c, f2 acc) {
+  f2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(a), "v"(c), "v"(acc));
+  return r;
+}
+__device__ __forceinline__ f2 pk_mul_lo(f2 a, f2 c) {
+  f2 r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(c));
+  return r;
+}
+__device__ __forceinline__ f2 pk_mul_hi(f2 a, f2 c) {
+  f2 r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "v"(c));
+  return r;
+}
+#endif
+
+// Same decomposition and operation order as dft20(): 5 radix-4 butterflies, twiddles W20^{bc}, 4 radix-5 butterflies.
+__device__ __forceinline__ void dft20_pk(cpx (&xc)[20]) {
+  // W20^j = (cos(2 pi j / 20), -sin(2 pi j / 20)), j = 0..12 as (re, im) pairs
+  const f2 W[13] = {{1.f, 0.f}, {0.95105651629515357f, -0.30901699437494742f}, {0.80901699437494742f, -0.58778525229247313f},
+                    {0.58778525229247313f, -0.80901699437494742f}, {0.30901699437494742f, -0.95105651629515357f}, {0.f, -1.f},
+                    {-0.30901699437494742f, -0.95105651629515357f}, {-0.58778525229247313f, -0.80901699437494742f},
+                    {-0.80901699437494742f, -0.58778525229247313f}, {-0.95105651629515357f, -0.30901699437494742f}, {-1.f, 0.f},
+                    {-0.95105651629515357f, 0.30901699437494742f}, {-0.80901699437494742f, 0.58778525229247313f}};
+  const f2 C12 = {0.30901699437494742f, -0.80901699437494742f};     // (cos 2 pi / 5, cos 4 pi / 5)
+  const f2 S12 = {0.95105651629515357f, 0.58778525229247313f};      // (sin 2 pi / 5, sin 4 pi / 5)
+  f2 x[20], u[5][4];
+#pragma unroll
+  for (int i = 0; i < 20; i++) x[i] = f2{xc[i].re, xc[i].im};
+#pragma unroll
+  for (int b = 0; b < 5; b++) {
+    const f2 s02 = pk_add(x[b], x[10 + b]), d02 = pk_sub(x[b], x[10 + b]);
+    const f2 s13 = pk_add(x[5 + b], x[15 + b]), d13 = pk_sub(x[5 + b], x[15 + b]);
+    const f2 t0 = pk_add(s02, s13), t2 = pk_sub(s02, s13);
+    const f2 t1 = pk_add_mi(d02, d13), t3 = pk_add_pi(d02, d13);   // d02 - i d13, d02 + i d13
+    u[b][0] = t0;
+    if (b == 0) { u[b][1] = t1; u[b][2] = t2; u[b][3] = t3; }
+    else { u[b][1] = pk_cmul(t1, W[b]); u[b][2] = pk_cmul(t2, W[2 * b]); u[b][3] = pk_cmul(t3, W[3 * b]); }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const f2 u0 = u[0][c];
+    const f2 a1 = pk_add(u[1][c], u[4][c]), a2 = pk_add(u[2][c], u[3][c]);
+    const f2 b1 = pk_sub(u[1][c], u[4][c]), b2 = pk_sub(u[2][c], u[3][c]);
+    const f2 p1 = pk_fma_hi(a2, C12, pk_fma_lo(a1, C12, u0));      // u0 + C1 a1 + C2 a2
+    const f2 p2 = pk_fma_lo(a2, C12, pk_fma_hi(a1, C12, u0));      // u0 + C2 a1 + C1 a2
+    const f2 q1 = pk_fma_hi(b2, S12, pk_mul_lo(b1, S12));          // S1 b1 + S2 b2
+    const f2 q2 = pk_sub(pk_mul_hi(b1, S12), pk_mul_lo(b2, S12));  // S2 b1 - S1 b2
+    x[c] = pk_add(pk_add(u0, a1), a2);
+    x[c + 4] = pk_add_mi(p1, q1);                                   // p1 - i q1
+    x[c + 16] = pk_add_pi(p1, q1);                                  // p1 + i q1
+    x[c + 8] = pk_add_mi(p2, q2);
+    x[c + 12] = pk_add_pi(p2, q2);
+  }
+#pragma unroll
+  for (int i = 0; i < 20; i++) xc[i] = cpx{x[i].x, x[i].y};
+}
+#define WB_DFT20 dft20_pk
+#else
+#define WB_DFT20 dft20
+#endif
+
 __global__ __launch_bounds__(MEL_THREADS, WB_MEL_MIN_BLOCKS) void mel_spectrogram_kernel(
     const float* __restrict__ pcm, const MelWindow* __restrict__ wins, const MelTables* __restrict__ tabs,
     float* __restrict__ out, int64_t win_stride, int row_stride, float* __restrict__ gmax, int bmax_stride, int pad,
@@ -201,7 +314,7 @@ __global__ __launch_bounds__(MEL_THREADS, WB_MEL_MIN_BLOCKS) void mel_spectrogra
     const float hw = tabs->hann[20 * n1 + q];   // periodic Hann (audio.rs:272-278); L1-resident, same for every block
     z[n1] = {reg[20 * n1 + q] * hw, reg[FROW + 20 * n1 + q] * hw};
   }
-  dft20(z);
+  WB_DFT20(z);
   __syncthreads();   // everyone has consumed the frame rows; region becomes U[k1][n2]
   float2* U = reinterpret_cast<float2*>(reg);
 #pragma unroll
@@ -217,7 +330,7 @@ __global__ __launch_bounds__(MEL_THREADS, WB_MEL_MIN_BLOCKS) void mel_spectrogra
     float2 v = U[q * UROW + n2];
     z[n2] = {v.x, v.y};
   }
-  dft20(z);
+  WB_DFT20(z);
   __syncthreads();
   float2* Z = reinterpret_cast<float2*>(reg);   // Z[k], k = 0..399
 #pragma unroll
