@@ -402,7 +402,16 @@ __global__ __launch_bounds__(MEL_THREADS, WB_MEL_MIN_BLOCKS) void mel_spectrogra
         const float* tw = lds + (m / 5) * 2 * FROW + TAP_OFF + (m % 5) * MEL_MAX_TAPS;
         const float4 w4 = *reinterpret_cast<const float4*>(tw + 4 * c);
         const float* pp = Pf + s0v[r] + 4 * c;
+#if defined(WB_MEL_FMAC_ASM) && !defined(HIPEMU)
+        // opt-in (to be measured): plain v_fmac -- the compiler SLP-packs the sums of two rows into v_pk_fma_f32 and builds
+        // each operand pair with two or three v_mov (16 packed + ~40 moves per chunk against 32 scalar FMAs)
+        asm("v_fmac_f32 %0, %1, %2" : "+v"(accv[r]) : "v"(w4.x), "v"(pp[0]));
+        asm("v_fmac_f32 %0, %1, %2" : "+v"(accv[r]) : "v"(w4.y), "v"(pp[1]));
+        asm("v_fmac_f32 %0, %1, %2" : "+v"(accv[r]) : "v"(w4.z), "v"(pp[2]));
+        asm("v_fmac_f32 %0, %1, %2" : "+v"(accv[r]) : "v"(w4.w), "v"(pp[3]));
+#else
         accv[r] += w4.x * pp[0]; accv[r] += w4.y * pp[1]; accv[r] += w4.z * pp[2]; accv[r] += w4.w * pp[3];
+#endif
       }
     }
 #pragma unroll
