@@ -37,7 +37,8 @@ static int upload(hipStream_t st, DevMem& dst, const void* src, size_t bytes) {
 // fits it, else the exact-f32 MFMA kernel (the conv1 gather, split-K launches, decoder-side weights).
 int gemm_dispatch(const wb_model* m, hipStream_t st, const GemmArgs& a, int ldwt, const uint16_t* sh, const uint16_t* sl) {
   // exact-f32 models: encoder-side weights that carry a split copy go through the three-product fp16 kernel
-  if (m->split_active() && sh && sl && a.conv1_tstride == 0 && a.K % 32 == 0 && ldwt % 8 == 0 && a.ksplit <= 1) {
+  if (m->split_active() && sh && sl && a.conv1_tstride == 0 && a.K % 32 == 0 && ldwt % 8 == 0 && a.ksplit <= 1 &&
+      (a.a_desc == nullptr || a.a_mask_align % 8 == 0)) {
     GemmArgs g = a;
     g.range_flag = m->split_flag_dev;
     WB_REQUIRE(launch_gemm_f16x3(st, g, sh, sl, ldwt) == 0, WB_ERR_SHAPE, "split gemm: unsupported shape M=%d N=%d K=%d", a.M,
@@ -171,7 +172,7 @@ int run_encoder_unguarded(wb_model* m, hipStream_t st, Workspace& ws, const MelB
   // conv2 (stride 2) + GELU + transpose + positional add (mod.rs:244-252): rows 2c-1..2c+1 of x1 form one A row
   {
     GemmArgs g;
-    g.A = x1; g.a_desc = ws.desc2.as<RowDesc>();
+    g.A = x1; g.a_desc = ws.desc2.as<RowDesc>(); g.a_mask_align = d;     // (klo in {0, d}, khi in {2 d, 3 d})
     g.B = m->conv2.w; g.ldb = d; g.C = x; g.ldc = d; g.bias = m->conv2.b;
     g.M = rows2; g.N = d; g.K = 3 * d; g.act = ACT_GELU;
     g.aux = m->enc_pos; g.aux_idx = ws.auxidx.as<int32_t>(); g.ld_aux = d;

@@ -107,15 +107,12 @@ __global__ __launch_bounds__(NT, WB_F16X3_MIN_WAVES) void gemm_f16x3_kernel(Gemm
     for (int i = 0; i < A_IT; i++) {
       const int idx = tid + i * NT, k = k0 + (idx % (BK / 8)) * 8;
       float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
-      if (a_row[i] != nullptr && k >= a_klo[i] && k + 7 < a_khi[i]) {   // (every caller's masks are multiples of 8)
+      // whole octets only: a row mask [klo, khi) must be a multiple of 8 at both ends -- the HOST guarantees it
+      // (GemmArgs::a_mask_align, checked in gemm_dispatch; a per-element path for straddling octets cost the hot loop ~100
+      // compare / branch instructions per k-tile for a case no caller has)
+      if (a_row[i] != nullptr && k >= a_klo[i] && k + 7 < a_khi[i]) {
         lo = *reinterpret_cast<const float4*>(a_row[i] + k);
         hi = *reinterpret_cast<const float4*>(a_row[i] + k + 4);
-      } else if (a_row[i] != nullptr && k + 7 >= a_klo[i] && k < a_khi[i]) {   // an octet that straddles a mask edge: by element
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; e++) v[e] = (k + e >= a_klo[i] && k + e < a_khi[i]) ? a_row[i][k + e] : 0.f;
-        lo = make_float4(v[0], v[1], v[2], v[3]);
-        hi = make_float4(v[4], v[5], v[6], v[7]);
       }
       ra_lo[i] = lo; ra_hi[i] = hi;
     }

@@ -75,6 +75,8 @@ struct RowDesc {             // optional per-row A addressing (implicit-GEMM con
 struct GemmArgs {
   const float* A = nullptr; int64_t lda = 0;     // ROWS: A[m][k] = A[m*lda + k] (or A[desc[m].off + k])
   const RowDesc* a_desc = nullptr;               // per-row descriptors (device), or null
+  int a_mask_align = 1;                          // the caller's guarantee: every klo / khi of a_desc is a multiple of this
+                                                 // (the split-precision kernel stages whole octets: it needs a multiple of 8)
   int conv1_tstride = 0;                         // >0 selects CONV1 gather: A[m][ci*3+kk] = A[off + ci*tstride + kk - 1]
   const float* B = nullptr; int ldb = 0;         // [K][N] row-major
   float* C = nullptr; int ldc = 0;
