@@ -227,6 +227,20 @@ def test_c_abi_partition_equals_the_python_one(n, world):
         assert shard.c_partition_windows(n, r, world) == shard.partition_windows(n, r, world)
 
 
+def test_sharded_entry_point_validates_its_arguments_before_touching_a_device():
+    """wb_waveform_to_tokens_sharded / wb_shard_partition: argument errors are reported without a GPU (nothing is decoded)."""
+    lib = _lib.load()
+    lo, hi = C.c_int64(0), C.c_int64(0)
+    assert lib.wb_shard_partition(10, 3, 3, C.byref(lo), C.byref(hi)) != 0          # rank outside [0, world)
+    assert lib.wb_shard_partition(10, 0, 0, C.byref(lo), C.byref(hi)) != 0          # world < 1
+    assert lib.wb_shard_partition(0, 0, 4, C.byref(lo), C.byref(hi)) == 0 and (lo.value, hi.value) == (0, 0)
+    n_st = C.c_int64(0)
+    # null model / buffers
+    rc = lib.wb_waveform_to_tokens_sharded(None, None, 0, 0, 16000, None, None, 0, 1, None, None, None, 108, None, 0, None, 0,
+                                           C.byref(n_st))
+    assert rc != 0 and b"null argument" in lib.wb_last_error()
+
+
 @given(st_.integers(1, 6_000_000), st_.integers(1, 9))
 @settings(max_examples=200, deadline=None)
 def test_rank_pcm_span_reproduces_the_rank_windows(n, world):
