@@ -16,7 +16,10 @@
  *    parameter name ends in `_dev`.
  *  - all floating point data is IEEE f32 (the reference runs TchBackend<f32>,
  *    src/bin/transcribe/main.rs:80); token ids are int32.
- *  - a wb_model is immutable after load and may be shared by threads; a wb_session is
+ *  - a wb_model may be shared by threads: its weights never change after load.  The one
+ *    piece of state it carries is the encoder arithmetic (wb_model_encoder_gemm), which
+ *    can switch from 1 to 0 once, atomically, when the range guard of the split-precision
+ *    kernel trips; passes that use that kernel are serialised per model.  A wb_session is
  *    not thread-safe.
  */
 #ifndef WHISPER_HIP_H
@@ -97,7 +100,7 @@ int wb_model_set_ln_variant(wb_model* m, int eps_inside_sqrt);
  *                            formulas (transcribe.rs:32-34, :171-177) with the larger bound. */
 int wb_model_set_frame_limit(wb_model* m, int whisper_geometry);
 
-/* Arithmetic of the encoder-side Linear layers of this model (fixed at load time):
+/* Arithmetic of the encoder-side Linear layers of this model (chosen at load time; 1 can turn into 0 ONCE, see below):
  *   0 = exact-f32 MFMA (v_mfma_f32_32x32x2_f32)
  *   1 = split precision: three fp16 MFMAs per product on fp16 hi / lo pieces, f32 accumulation -- f32-grade results
  *       (default for f32 models; WHISPER_HIP_ENCODER_SPLIT=0 at load time selects 0, and a model whose activations leave

@@ -14,20 +14,14 @@ generated token is the (lowest-id) argmax of its row and the row stops where bea
   small,    batch-mode sessions (9 windows x 1 beam = streaming cross-attention; 5 windows x 2 beams = chunked +
             combine) for 122 positions -- past position 112, the second self-attention tile of dec_self_attn_kernel
 
-Log-prob tolerance at these depths.  The north star's 1e-3 is met outright at tiny.en's shape (test_gpu_workloads.py,
-test_gpu_budget.py) and at `small`'s (asserted below).  At large-v2 (32 + 32 layers) two CORRECT f32 evaluations are no longer
-within 1e-3 of each other: the f32 oracle itself sits up to 3.5e-2 from the f64 evaluation of the same algorithm on sequences
-picked at random among the top 5 (rms over rows 5.5e-3; the synthetic checkpoints amplify a relative perturbation of 1e-6 of the
-encoder output into up to 3e-2 of log-prob, heavy-tailed from row to row).  The rows are therefore pinned against the EXACT
-twin with the oracle's own distance as the budget: worst row |hip - f64| <= max(1e-3, 2 x worst row |oracle_f32 - f64|) over the
-same rows, and rms over rows |hip - f64| <= 1.5 x rms |oracle_f32 - f64| -- no absolute cap.  Measured on the MI355X box with
-the stage-split diagnostic (whisper-burn_amd/tools/diag_stage_split.py, profiles/r04_b_diag_*.log; 9 windows x 33 positions):
-large-v2 worst 4.1e-2 (oracle 3.5e-2), rms 5.2e-3 (5.5e-3); small worst 6.1e-4 (8.1e-4), rms 1.9e-4 (2.3e-4) -- the HIP path
-is as close to the exact result as the reference-style f32 evaluation, or closer.  (Round 3 sat 3 - 8 x further out: the
-exact-f32 MFMA GEMMs sum K in ONE sequential chain per output -- 1280 to 5120 terms for the encoder's Linear layers and the
-cross-K/V projection, 3840 for conv2, 750 keys in P.V -- which a blocked CPU sum does not; the split-precision GEMM's chain is
-16 x shorter and the attention kernel sums per key tile: profiles/r04_a_diag_*.)  Token parity of the batch-mode path is pinned
-separately and exactly by the two depth-100 greedy tests above.
+Log-prob tolerance: the north star's 1e-3, asserted OUTRIGHT against the f32 oracle at every size (LOGPROB_TOL below; no
+ratio, no budget factor).  Rounds 3 / 4 could not do that at large-v2: the synthetic checkpoint amplified a 1e-7 perturbation
+190-fold through its 32 cross-attention layers, two correct f32 evaluations differed by up to 3e-2, and the rows were gated on
+a ratio of two noisy 41-row samples against an f64 twin -- which failed on the driver's box in round 4.  Round 5 fixed the
+FIXTURE instead (synth.synth_weights, "Depth normalisation"): the f32 oracle now sits 1e-5 - 8e-5 from the f64 evaluation of
+the same operators at `small` and large-v2 (/tmp study recorded in LABLOG R5.1), so |hip - oracle_f32| <= 1e-3 is a plain
+assertion with an order of magnitude of headroom.  Token parity of the batch-mode path is pinned separately and exactly by the
+two depth-100 greedy tests.
 """
 import numpy as np
 import pytest
@@ -41,9 +35,7 @@ from whisper_burn_amd import synth
 
 pytestmark = pytest.mark.gpu
 
-LOGPROB_TOL = 1e-3      # north_star: logits within 1e-3 (fp32)
-BUDGET_FACTOR = 2.0     # worst row: |hip - exact| <= max(LOGPROB_TOL, BUDGET_FACTOR x worst |oracle_f32 - exact|)  (module docstring)
-RMS_FACTOR = 1.5        # rms over rows: |hip - exact| <= RMS_FACTOR x |oracle_f32 - exact|
+LOGPROB_TOL = 1e-3      # north_star: logits within 1e-3 (fp32) -- asserted outright on every compared row
 WLEN = 238559           # max_waveform_samples(1500 - 10), transcribe.rs:32-34
 
 
@@ -108,27 +100,11 @@ def test_large_v2_10_windows_depth_100_batch_mode(large_v2):
     print(f"large-v2 10 windows: {n_tok} teacher-forced decisions, smallest oracle top-2 gap {gap:.3e}")
 
 
-_TWIN = {}
-
-
-def _exact_twin(o):
-    """The f64 evaluation of the same operators on the same weights (one per oracle: the two large-v2 row tests share it --
-    converting 1.5 G parameters takes longer than evaluating them)."""
-    key = (o.dims.n_text_state, o.dims.n_text_layer, o.dims.n_vocab,          # (content key: an object id can be reused)
-           float(o.w["decoder/token_embedding/weight"][:64].double().sum()), float(o.w["encoder/conv1/weight"].double().sum()))
-    if key not in _TWIN:
-        _TWIN.clear()                                # (one model's twin at a time: large-v2's is 12 GB)
-        _TWIN[key] = OracleWhisper(o.w, dtype=torch.float64)
-    return _TWIN[key]
-
-
-def _session_logprob_rows(eng, o, st, audio, use_windows, max_beams, n_steps, fork_at, seed, exact_windows=(),
-                          exact_one_per_window=False):
+def _session_logprob_rows(eng, o, st, audio, use_windows, max_beams, n_steps, fork_at, seed):
     """Drive a KV-cached session over `use_windows` with up to `max_beams` beams per window for `n_steps` positions and
-    return the largest |session log-prob row - stateless oracle row| over the compared beams and steps, against the
-    f32 oracle and (for the window indices in `exact_windows`) against the f64 evaluation of the same operators.  Beams fork once at step
-    `fork_at` (when max_beams > 1); every beam continues with a random pick among its own top-5, so rows depend on the
-    whole history."""
+    return the largest (and the rms over rows of the per-row largest) |session log-prob row - stateless oracle row| over
+    the compared beams and steps.  Beams fork once at step `fork_at` (when max_beams > 1); every beam continues with a
+    random pick among its own top-5, so rows depend on the whole history."""
     starts, lens = wb.window_extents(len(audio), 16000, WLEN)
     sess = wb.Session.begin(eng, audio, starts[use_windows], lens[use_windows], max_beams=max_beams)
     sess.set_special_mask(st.is_special)
@@ -177,82 +153,46 @@ def _session_logprob_rows(eng, o, st, audio, use_windows, max_beams, n_steps, fo
         lp = pu.teacher_forced_logprobs(o, st, encs[wdx], list(seq))
         for n in range(4, len(seq) + 1):
             rows.setdefault((seq[:n], wdx), lp[n - 4])
-    worst32 = 0.0
+    worst32, sq = 0.0, 0.0
     for seq, wdx, got in records:
         ref = rows[(seq, wdx)]
         fin = np.isfinite(ref)
         assert (np.isfinite(got) == fin).all()
-        worst32 = max(worst32, float(np.abs(got[fin] - ref[fin]).max()))
-    # the exact twin (f64 evaluation of the same operators on the same log-mel) on the windows asked for
-    d_hip, d_o32 = 0.0, 0.0
-    sq_hip, sq_o32, n_exact = 0.0, 0.0, 0
-    if exact_windows:
-        o64 = _exact_twin(o)
-        maskv = torch.tensor(np.where(np.asarray(st.is_special).astype(bool), -np.inf, 0.0), dtype=torch.float64)
-        done = set()
-        for seq, wdx in finals:
-            if wdx not in exact_windows or any(seq == f[:len(seq)] and wdx == w2 for f, w2 in done):
-                continue
-            if exact_one_per_window and any(w2 == wdx for _, w2 in done):
-                continue                              # (the longest sequence of the window: `finals` is sorted by length)
-            done.add((seq, wdx))
-            enc64 = o64.forward_encoder(mels[use_windows[wdx]].double())[0]
-            lg = o64.forward_decoder(torch.tensor([list(seq)], dtype=torch.long), enc64[None])[0]
-            r64 = np.stack([torch.log_softmax(lg[p] + (maskv if p + 1 <= 5 else 0.0), 0).numpy() for p in range(3, len(seq))])
-            for s2, w2, got in records:
-                if w2 == wdx and s2 == seq[:len(s2)]:
-                    ref64, ref32 = r64[len(s2) - 4], rows[(s2, w2)]
-                    fin = np.isfinite(ref64)
-                    e_hip, e_o32 = float(np.abs(got[fin] - ref64[fin]).max()), float(np.abs(ref32[fin] - ref64[fin]).max())
-                    d_hip, d_o32 = max(d_hip, e_hip), max(d_o32, e_o32)
-                    sq_hip += e_hip ** 2; sq_o32 += e_o32 ** 2; n_exact += 1
-    return {"hip_o32": worst32, "hip_exact": d_hip, "o32_exact": d_o32, "n_live": n_live, "n_rows": len(records),
-            "rms_hip_exact": (sq_hip / max(n_exact, 1)) ** 0.5, "rms_o32_exact": (sq_o32 / max(n_exact, 1)) ** 0.5,
-            "n_exact_rows": n_exact,
+        e = float(np.abs(got[fin] - ref[fin]).max())
+        worst32 = max(worst32, e); sq += e * e
+    return {"hip_o32": worst32, "rms_hip_o32": (sq / max(len(records), 1)) ** 0.5, "n_live": n_live, "n_rows": len(records),
             "longest": max(len(r[0]) for r in records)}
 
 
-def _assert_budget(res, model):
-    """The rows against the exact twin, with the f32 oracle's own distance over the SAME rows as the budget.
-
-    The per-row distances are heavy-tailed (the synthetic checkpoints amplify 1e-7 of log-mel rounding into 1e-3 of
-    log-prob on single rows), so the WORST row of either evaluation is an unstable statistic: the mel kernel's change of
-    summation order in round 4 (a 1e-7 change of the shared log-mel) moved the f32 oracle's own worst row of the `small`
-    9 x 1 session from 1.96e-3 to below 5.7e-4 while the rms moved by a few per cent (profiles/r04_f_pytest_rows.log vs the
-    run after it).  The primary criterion is therefore the rms over rows (factor 1.5; measured 0.5 - 0.85); the worst row
-    is bounded by the larger of 2 x the oracle's worst row and 12 x the oracle's rms (a tail of the same distribution)."""
-    assert res["n_exact_rows"] >= 30, res
-    assert res["rms_hip_exact"] <= max(0.3 * LOGPROB_TOL, RMS_FACTOR * res["rms_o32_exact"]), res
-    assert res["hip_exact"] <= max(LOGPROB_TOL, BUDGET_FACTOR * res["o32_exact"], 12.0 * res["rms_o32_exact"]), res
-    # every window against the f32 oracle: a sanity bound (two f32 evaluations of an ill-conditioned chain differ by up to
-    # the sum of their distances to the exact one; the rows of the windows without an exact twin are in this one)
-    assert res["hip_o32"] <= max(2.0 * LOGPROB_TOL, 6.0 * res["o32_exact"], 24.0 * res["rms_o32_exact"]), res
+def _assert_rows(res):
+    """north_star: every compared log-prob row within 1e-3 of the reference-style f32 evaluation (module docstring)."""
+    assert res["n_rows"] >= 30, res
+    assert res["hip_o32"] <= LOGPROB_TOL, res
 
 
 def test_large_v2_batch_mode_beams_logprob_rows(large_v2):
     """large-v2, 5 windows x 2 beams = 10 live rows: batch mode with beams, i.e. dec_cross_attn_kernel<2> + the chunk
     combine at d = 1280 (the streaming kernel serves one beam per window only); 20 positions, the compared log-prob
-    rows of three windows (one beam each against the exact twin) inside the stated budget of the exact twin (module docstring)."""
+    rows within 1e-3 of the f32 oracle's stateless rows (module docstring)."""
     eng, o = large_v2
     st = wb.SpecialTokens.for_vocab(51865)
     audio = synth.synth_audio(1900000, 1240)
-    res = _session_logprob_rows(eng, o, st, audio, [0, 2, 4, 6, 9], 2, 20, 3, 11, exact_windows=(0, 2, 4),
-                                exact_one_per_window=True)
+    res = _session_logprob_rows(eng, o, st, audio, [0, 2, 4, 6, 9], 2, 20, 3, 11)
     assert res["n_live"] == 10 and res["longest"] >= 20
     print(f"large-v2 5 x 2 beams: {res}")
-    _assert_budget(res, "large-v2")
+    _assert_rows(res)
 
 
 def test_large_v2_batch_mode_streaming_logprob_rows(large_v2):
     """large-v2, 9 windows x 1 beam = the streaming cross-attention kernel (dec_cross_attn_stream_kernel: config #5's
-    per-GPU path) at d = 1280: 24 positions, the compared rows of three windows inside the budget of the exact twin."""
+    per-GPU path) at d = 1280: 24 positions, every compared row within 1e-3 of the f32 oracle's."""
     eng, o = large_v2
     st = wb.SpecialTokens.for_vocab(51865)
     audio = synth.synth_audio(1900000, 1240)
-    res = _session_logprob_rows(eng, o, st, audio, list(range(9)), 1, 24, -1, 21, exact_windows=(0, 4, 8))
+    res = _session_logprob_rows(eng, o, st, audio, list(range(9)), 1, 24, -1, 21)
     assert res["n_live"] == 9 and res["longest"] >= 24
     print(f"large-v2 9 x 1 beam: {res}")
-    _assert_budget(res, "large-v2")
+    _assert_rows(res)
 
 
 @pytest.mark.parametrize("mode", ["stream_9x1", "chunked_5x2"])
@@ -266,12 +206,12 @@ def test_small_batch_mode_session_past_the_second_self_attention_tile(mode):
     st = wb.SpecialTokens.for_vocab(51865)
     audio = wl.audio()[:190559 * 9 + 48000]                           # 9 full windows + a 3 s tail window
     if mode == "stream_9x1":
-        res = _session_logprob_rows(eng, o, st, audio, list(range(9)), 1, 122, -1, 21, exact_windows=(0, 4, 8))
+        res = _session_logprob_rows(eng, o, st, audio, list(range(9)), 1, 122, -1, 21)
         assert res["n_live"] == 9
     else:
-        res = _session_logprob_rows(eng, o, st, audio, [0, 2, 4, 6, 9], 2, 122, 3, 22, exact_windows=(0, 2, 4))
+        res = _session_logprob_rows(eng, o, st, audio, [0, 2, 4, 6, 9], 2, 122, 3, 22)
         assert res["n_live"] == 10
     eng.close()
     assert res["longest"] >= 122
     print(f"small {mode}: {res}")
-    _assert_budget(res, "small")
+    _assert_rows(res)

@@ -129,13 +129,13 @@ __global__ __launch_bounds__(256) void dec_resolve_ln_kernel(const int* __restri
   // One memory round trip: the live-row count, the row, every pending plane, the bias and the LayerNorm parameters are
   // requested before the first use of any of them, and the folded stream is stored last (the launch was 6.6 us for ~1.5 MB
   // at large-v2's 38 rows, three dependent round trips of it: profiles/r03_m_layer_cycle_large_v2.txt).  Columns past d
-  // and planes past KS alias valid elements and are never used.
+  // re-read column 0 and planes past KS are zero; neither is used.
   const int n_live = st[ST_N];
   float xv[VPT], gv[VPT], bv[VPT], biasv[VPT], t[VPT][KS_MAX];
   const int64_t plane = (int64_t)S * d;
 #pragma unroll
   for (int i = 0; i < VPT; i++) {
-    const int c = tid + i * 256, cc = c < d ? c : tid;
+    const int c = tid + i * 256, cc = c < d ? c : 0;     // (d = 128: threads past the row re-read column 0)
     xv[i] = x_in[(int64_t)r * d + cc];
     gv[i] = g[cc]; bv[i] = b[cc];
     biasv[i] = KS > 0 ? bias[cc] : 0.f;

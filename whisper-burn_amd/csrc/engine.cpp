@@ -52,14 +52,21 @@ int gemm_dispatch(const wb_model* m, hipStream_t st, const GemmArgs& a, int ldwt
 
 // Run `body` (a pass that may use the split-precision kernel); if that kernel raised its range flag -- an activation left
 // fp16's range, so some outputs are inf / NaN -- switch the model to the exact-f32 kernel for good and run the pass again.
-// Costs one stream synchronisation per pass while the split kernel is in use.
+// Costs one stream synchronisation per pass while the split kernel is in use.  The flag word is per model and sessions of
+// one model may run on different streams from different threads: guarded passes hold the model's split_mu from the first
+// launch to the read of the flag, so a pass can neither see nor clear a flag raised by another session's pass (it would
+// otherwise return that session's inf / NaN output as WB_OK).  A pass that started on the split kernel while another
+// thread's pass tripped the guard simply runs to its end on the kernel it started with and is checked like any other.
 int split_guarded(wb_model* m, hipStream_t st, const std::function<int()>& body) {
   if (!m->split_active()) return body();
+  std::unique_lock<std::mutex> lk(m->split_mu);
+  if (!m->split_active()) { lk.unlock(); return body(); }     // tripped while this thread waited for the lock
   WB_TRY(body());
   WB_HIP(hipStreamSynchronize(st));
   if (__atomic_load_n(m->split_flag_host, __ATOMIC_ACQUIRE) == 0) return WB_OK;
   __atomic_store_n(m->split_flag_host, 0, __ATOMIC_RELEASE);
-  m->split_off = 1;
+  __atomic_store_n(&m->split_off, 1, __ATOMIC_RELEASE);
+  lk.unlock();
   return body();
 }
 
@@ -204,6 +211,7 @@ static int run_decoder_stateless_body(wb_model* m, hipStream_t st, Workspace& ws
                                       const float* enc_dev, int C, float* logits_dev);
 int run_decoder_stateless(wb_model* m, hipStream_t st, Workspace& ws, const int32_t* tokens_dev, int n, int L,
                           const float* enc_dev, int C, float* logits_dev) {
+  // (guarded: the cross-K/V projection of every layer, ckv_all, runs on the split-precision kernel here too)
   return split_guarded(m, st, [&]() { return run_decoder_stateless_body(m, st, ws, tokens_dev, n, L, enc_dev, C, logits_dev); });
 }
 

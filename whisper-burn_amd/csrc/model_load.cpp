@@ -396,12 +396,14 @@ int build_model(TensorMap& tm, int device, int compute_dtype, wb_model** out) {
       for (size_t i = 0, n = (size_t)l->k * l->n; i < n && ok; i++) ok = std::fabs(hw[i]) < 65000.f;
       if (ok) ws.push_back(l);
     }
-    WB_HIP(hipHostMalloc((void**)&m->split_flag_host, 64, hipHostMallocMapped));
-    *m->split_flag_host = 0;
-    WB_HIP(hipHostGetDevicePointer((void**)&m->split_flag_dev, m->split_flag_host, 0));
     size_t total = 0;
     for (LinearW* l : ws) total += ((size_t)l->k * l->n + 127) & ~size_t(127);
-    WB_TRY(m->arena_split.alloc(total * 2 * 2));
+    if (total) {                                // (no weight qualifies: no flag word, no arena -- the model is exact-f32)
+      WB_HIP(hipHostMalloc((void**)&m->split_flag_host, 64, hipHostMallocMapped));      // freed by ~wb_model
+      *m->split_flag_host = 0;
+      WB_HIP(hipHostGetDevicePointer((void**)&m->split_flag_dev, m->split_flag_host, 0));
+      WB_TRY(m->arena_split.alloc(total * 2 * 2));
+    }
     uint16_t* p = m->arena_split.as<uint16_t>();
     for (LinearW* l : ws) {
       const size_t n = ((size_t)l->k * l->n + 127) & ~size_t(127);

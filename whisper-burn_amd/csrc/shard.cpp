@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "wb_internal.h"
@@ -152,6 +153,8 @@ int wb_waveform_to_tokens_sharded(wb_model* m, const float* pcm, int pcm_on_devi
   const size_t rec = (size_t)1 + row_stride;                                         // [length | tokens]
   std::vector<int32_t> local((size_t)rows * rec, 0);
   for (int64_t i = 0; i < rows; i++) local[(size_t)i * rec] = -1;                    // -1: unused row
+  int local_rc = WB_OK;
+  std::string local_err;
   if (hi > lo) {
     std::vector<int32_t> toks((size_t)(hi - lo) * row_stride, 0), lens((size_t)(hi - lo), 0);
     const int rc = pcm_on_device
@@ -159,15 +162,28 @@ int wb_waveform_to_tokens_sharded(wb_model* m, const float* pcm, int pcm_on_devi
                                     nullptr, 0, nullptr)
         : wb_waveform_to_tokens(m, pcm, n, sample_rate, p, is_special, (int)lo, (int)hi, toks.data(), row_stride, lens.data(),
                                 nullptr, 0, nullptr);
-    WB_TRY(rc);
-    for (int64_t i = 0; i < hi - lo; i++) {
-      local[(size_t)i * rec] = lens[(size_t)i];
-      memcpy(&local[(size_t)i * rec + 1], &toks[(size_t)i * row_stride], (size_t)row_stride * 4);
+    local_rc = rc;
+    if (rc == WB_OK) {
+      for (int64_t i = 0; i < hi - lo; i++) {
+        local[(size_t)i * rec] = lens[(size_t)i];
+        memcpy(&local[(size_t)i * rec + 1], &toks[(size_t)i * row_stride], (size_t)row_stride * 4);
+      }
+    } else {
+      // A rank whose decode failed (out of memory, a HIP error) must still ENTER the collective: the other ranks are
+      // already inside it (or about to be) and would block for ever.  It sends its rows with the sentinel length -2 and
+      // its status in the first token slot; every rank then returns an error after the gather.
+      local_err = wb_last_error();
+      for (int64_t i = 0; i < rows; i++) { local[(size_t)i * rec] = -2; local[(size_t)i * rec + 1] = rc; }
     }
   }
   std::vector<int32_t> all((size_t)world * rows * rec);
   if (world == 1) all = local;
   else WB_TRY(allgather(user, local.data(), all.data(), (int64_t)(local.size() * 4)));   // the ONE exchange of the path
+  WB_REQUIRE(local_rc == WB_OK, local_rc, "rank %d: local decode failed: %s", rank, local_err.c_str());
+  for (int r = 0; r < world; r++) {
+    const int32_t* row = &all[(size_t)r * rows * rec];
+    WB_REQUIRE(row[0] != -2, WB_ERR_STATE, "rank %d reported a failed decode (status %d); no rank has a transcript", r, (int)row[1]);
+  }
   // unpack in window order and fold the stitch over all K rows (transcribe.rs:56-63): identical on every rank
   int64_t w = 0;
   for (int r = 0; r < world; r++) {

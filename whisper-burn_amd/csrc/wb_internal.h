@@ -8,6 +8,7 @@
 #include <memory>
 #include <string>
 #include <unordered_map>
+#include <mutex>
 #include <vector>
 
 #include "../../include/whisper_hip.h"
@@ -135,8 +136,13 @@ struct wb_model {
   wb::DevMem arena_split;     // exact-f32 models with the split-precision encoder: fp16 hi / lo copies of the encoder-side weights
   // range guard of the split-precision kernel: a mapped host word the kernel raises when a result is not finite; once it
   // has tripped the model stays on the exact-f32 kernel (split_off)
+  // Guarded passes of ONE model are serialised by split_mu (engine.cpp: split_guarded): the flag word is per model, so the
+  // flag a pass reads after its synchronisation can only have been raised by that pass.  split_off is the one field of a
+  // loaded model that ever changes (0 -> 1, once); it is atomic and read once per GEMM dispatch.
   int* split_flag_host = nullptr; int* split_flag_dev = nullptr; int split_off = 0;
-  bool split_active() const { return arena_split.p && !split_off; }
+  std::mutex split_mu;
+  bool split_active() const { return arena_split.p && !__atomic_load_n(&split_off, __ATOMIC_ACQUIRE); }
+  ~wb_model() { if (split_flag_host) (void)hipHostFree(split_flag_host); }
   // encoder
   wb::LinearW conv1;   // repacked [240 = ci*3+kk][d]
   wb::LinearW conv2;   // repacked [3d = kk*d+ci][d]
