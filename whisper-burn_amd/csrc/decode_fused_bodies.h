@@ -294,17 +294,17 @@ __device__ __forceinline__ bool dec_mlp_body(const MlpFusedArgs& a, const int jb
     const int npl = a.KSp;
     const int ch = rec ? PCHR : PCH;                 // planes per round
     auto load_weights = [&]() {                      // LayerNorm parameters, bias, the W1 slice, the W2 slice
-      g_own = a.ln_g[own_col]; b_own = a.ln_b[own_col];
-      b1v = a.b1[j0 + (tid & 63)];
+      g_own = gld(a.ln_g + own_col); b_own = gld(a.ln_b + own_col);
+      b1v = gld(a.b1 + j0 + (tid & 63));
       {
         const float* wp = a.W1 + (int64_t)rg * a.ld1 + j0 + c4;
 #pragma unroll
-        for (int i = 0; i < NW1; i++) w1[i] = *reinterpret_cast<const float4*>(wp + (int64_t)(32 * i) * a.ld1);
+        for (int i = 0; i < NW1; i++) w1[i] = ld_w4(wp + (int64_t)(32 * i) * a.ld1);
       }
       {
         const float* wp = a.W2 + (int64_t)(j0 + jb) * d + cf * 4;
 #pragma unroll
-        for (int i = 0; i < RPG; i++) w2[i] = *reinterpret_cast<const float4*>(wp + (int64_t)i * d);
+        for (int i = 0; i < RPG; i++) w2[i] = ld_w4(wp + (int64_t)i * d);
       }
     };
     if constexpr (PS) {
@@ -321,7 +321,7 @@ __device__ __forceinline__ bool dec_mlp_body(const MlpFusedArgs& a, const int jb
       ps_nap<3>();                                  // (the cross-attention blocks have only just started)
       bool rdead[EPT];
 #pragma unroll
-      for (int i = 0; i < EPT; i++) { rdead[i] = ((deadm >> (off[i] / d)) & 1) != 0; acc0[i] = a.pbias[col[i]]; xv_fold[i] = 0.f; }
+      for (int i = 0; i < EPT; i++) { rdead[i] = ((deadm >> (off[i] / d)) & 1) != 0; acc0[i] = gld(a.pbias + col[i]); xv_fold[i] = 0.f; }
       constexpr int GP = EPT <= 3 ? 8 : 4;           // planes per sweep
       unsigned sweeps = 0;
       bool bad = false;
@@ -372,7 +372,7 @@ __device__ __forceinline__ bool dec_mlp_body(const MlpFusedArgs& a, const int jb
       }
     } else {
 #pragma unroll
-    for (int i = 0; i < EPT; i++) { xv_fold[i] = a.x_in[off[i]]; acc0[i] = npl > 0 ? a.pbias[col[i]] : 0.f; }
+    for (int i = 0; i < EPT; i++) { xv_fold[i] = a.x_in[off[i]]; acc0[i] = npl > 0 ? gld(a.pbias + col[i]) : 0.f; }
     float mlv0 = -1.0e30f, mlv1 = 0.f;
     if (rec && tid < MR * npl) {                     // (m, l) of record (row tid / npl, plane tid % npl)
       const float* rp = a.pend + (int64_t)(tid % npl) * plane + (int64_t)(tid / npl) * (d + 2);
@@ -620,7 +620,7 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
   float4 wr[2][RK];
   auto load_round = [&](float4 (&w)[RK], int it) {
 #pragma unroll
-    for (int j = 0; j < RK; j++) w[j] = *reinterpret_cast<const float4*>(wq + (int64_t)(RK * it + j) * a.ldqkv);
+    for (int j = 0; j < RK; j++) w[j] = ld_w4(wq + (int64_t)(RK * it + j) * a.ldqkv);
   };
   float xfold;                                     // this thread's element of x + pending (kept for the final x_out store)
   // LayerNorm parameters of the KW rows of x this wave's QKV rounds multiply: lane l < KW owns row wave KW + l
@@ -659,10 +659,10 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
     const float* pp = a.pend + (int64_t)r * d + c;
     const int64_t plane = (int64_t)a.S * d;
     auto load_weights = [&]() {
-      g_own = a.ln_g[own_col]; b_own = a.ln_b[own_col];
+      g_own = gld(a.ln_g + own_col); b_own = gld(a.ln_b + own_col);
       load_round(wr[0], 0);
       if (NIT > 1) load_round(wr[1], 1);
-      if constexpr (PS) { if (tid < 192) qbias = a.bqkv[(tid >> 6) * d + h * 64 + (tid & 63)]; }
+      if constexpr (PS) { if (tid < 192) qbias = gld(a.bqkv + (tid >> 6) * d + h * 64 + (tid & 63)); }
     };
     if constexpr (PS) {
       // persistent mode: the first weight rounds are in flight (or landed) while the block waits; the wait is a PRE-wake
@@ -680,7 +680,7 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
       const int iplane = a.S * d;
       if (a.KSp > 0) ps_nap<2>();                   // (the previous layer's MLP has only just started)
       constexpr int FP = 4 * DPL;                   // the 4 d / 64 planes of the previous layer's MLP
-      float v = 0.f, accp = a.KSp > 0 ? a.pbias[c] : 0.f;
+      float v = 0.f, accp = a.KSp > 0 ? gld(a.pbias + c) : 0.f;
       unsigned sweeps = 0;
       // (a granule that has arrived is not read again: the retries of the last planes are short round trips)
       Gran gx{0u, 0.f}, g[FP];
@@ -717,7 +717,7 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
     float t[FP];
     float accp = 0.f;
     if (a.KSp > 0) {
-      accp = a.pbias[c];
+      accp = gld(a.pbias + c);
 #pragma unroll
       for (int j = 0; j < FP; j++) t[j] = pp[(int64_t)min(j, a.KSp - 1) * plane];
     }
@@ -782,7 +782,7 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
   {
     const float* wp = a.Wo + (int64_t)(h * 64 + jb) * d + cf * 4;
 #pragma unroll
-    for (int i = 0; i < RPG; i++) wo[i] = *reinterpret_cast<const float4*>(wp + (int64_t)i * d);
+    for (int i = 0; i < RPG; i++) wo[i] = ld_w4(wp + (int64_t)i * d);
   }
   if (seg_ok) *reinterpret_cast<float4*>(&red[wave * 192 + seg * 64 + c4]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
   __syncthreads();
@@ -971,7 +971,7 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
   // scalar load here would stall the next kernel-argument wait, lgkmcnt being one counter): the K stream can then start
   // one round trip after kernel entry instead of two (row -> window -> geometry)
   const int wi8 = min(lane & 7, a.lay.W - 1);
-  const int vC8 = a.win_C[wi8], vR8 = a.win_row0[wi8];
+  const int vC8 = gld(a.win_C + wi8), vR8 = gld(a.win_row0 + wi8);
   // ---- requested first (in order of use): fold operands, LayerNorm parameters, bias, the Wq slice
   float xfold;
   const int rg = tid >> 4, c4 = (tid & 15) * 4;
@@ -985,12 +985,12 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
   const float* Kh; const float* Vh; int C;
   float qbias = 0.f;
   auto load_weights = [&]() {
-    g_own = a.ln_g[own_col]; b_own = a.ln_b[own_col];
-    if constexpr (PS) { if (tid < 64) qbias = a.bq[h * 64 + tid]; }
+    g_own = gld(a.ln_g + own_col); b_own = gld(a.ln_b + own_col);
+    if constexpr (PS) { if (tid < 64) qbias = gld(a.bq + h * 64 + tid); }
     {
       const float* wp = a.Wq + (int64_t)rg * d + h * 64 + c4;
 #pragma unroll
-      for (int i = 0; i < NWQ; i++) wqr[i] = *reinterpret_cast<const float4*>(wp + (int64_t)(32 * i) * d);
+      for (int i = 0; i < NWQ; i++) wqr[i] = ld_w4(wp + (int64_t)(32 * i) * d);
     }
   };
   // the head's cached K, all of it, into the register ring (key = tile * 128 + rg + 32 * slot; quad c4)
@@ -999,7 +999,7 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
     {
       const int ws = __builtin_amdgcn_readfirstlane(w_row);
       if (ws < 8) { C_w = __builtin_amdgcn_readlane(vC8, ws); row0_w = __builtin_amdgcn_readlane(vR8, ws); }
-      else { C_w = a.win_C[ws]; row0_w = a.win_row0[ws]; }
+      else { C_w = gld(a.win_C + ws); row0_w = gld(a.win_row0 + ws); }
     }
     C = min(C_w, CMAX);
     // uniform base + 32-bit per-lane offsets; keys past C re-read row C - 1 (their scores are never stored and their
@@ -1011,7 +1011,7 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
 #pragma unroll
       for (int i = 0; i < SL; i++) {
         const int key = min(t * KT + rg + 32 * i, C - 1);
-        kv[t][i] = *reinterpret_cast<const float4*>(Kh + (key * a.ldkv + c4));
+        kv[t][i] = gld4(Kh + (key * a.ldkv + c4));
       }
   };
   {
@@ -1034,7 +1034,7 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
       const int iplane = a.S * d;
       ps_nap<4>();                                  // (the self-attention blocks have only just started)
       constexpr int FP = 8;                         // <= 8 head planes
-      float v = 0.f, accp = a.pbias[c];
+      float v = 0.f, accp = gld(a.pbias + c);
       unsigned sweeps = 0;
       Gran gx{0u, 0.f}, g[FP];
 #pragma unroll
@@ -1063,7 +1063,7 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
     float t[FP];
     float accp = 0.f;
     if (a.KSp > 0) {
-      accp = a.pbias[c];
+      accp = gld(a.pbias + c);
 #pragma unroll
       for (int j = 0; j < FP; j++) t[j] = pp[(int64_t)min(j, a.KSp - 1) * plane];
     }
@@ -1120,7 +1120,7 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
   {
     const float* wp = a.Wo + (int64_t)(h * 64 + jb) * d + cf * 4;
 #pragma unroll
-    for (int i = 0; i < RPG; i++) wo[i] = *reinterpret_cast<const float4*>(wp + (int64_t)i * d);
+    for (int i = 0; i < RPG; i++) wo[i] = ld_w4(wp + (int64_t)i * d);
   }
   if (tid < 64) {
     float v = 0.f;
@@ -1155,7 +1155,7 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
           s += dpp_f<DPP_ROW_MIRROR, 0xF>(0.f, s);
           if ((tid & 15) == 0 && key < C) sc[key] = s;
           const int lim = p + 1 < NP ? max(C - 1 - (p + 1) * PASS_C, -(p + 1) * PASS_C) : C - 1;   // (clamped rows are never consumed)
-          kv[t][i] = *reinterpret_cast<const float4*>(nxt + (min(k0, lim) * a.ldkv + c4));
+          kv[t][i] = gld4(nxt + (min(k0, lim) * a.ldkv + c4));
         }
       }
     }
@@ -1189,7 +1189,7 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
           const float pk = key < C ? pbuf[key] : 0.f;
           o.x += pk * kv[t][i].x; o.y += pk * kv[t][i].y; o.z += pk * kv[t][i].z; o.w += pk * kv[t][i].w;
           if (p + 1 < NP)                           // the register takes the V row of the next pass's key
-            kv[t][i] = *reinterpret_cast<const float4*>(Vh + (min(key + PASS_C, C - 1) * a.ldkv + c4));
+            kv[t][i] = gld4(Vh + (min(key + PASS_C, C - 1) * a.ldkv + c4));
         }
       }
     }

@@ -64,6 +64,12 @@ __device__ __forceinline__ void st_f(float* p, float v) {
 }
 __device__ __forceinline__ void st_i_sc1(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+#if defined(HIPEMU)
+#define WB_GLOBAL_AS
+#else
+#define WB_GLOBAL_AS __attribute__((address_space(1)))
+#endif
+typedef float hx_f32x4 __attribute__((ext_vector_type(4)));
 // 16-byte accesses go through a raw buffer resource (aux = 16 selects sc1 on gfx950); `base` must be 16-byte aligned
 // and the byte offset < 4 GiB
 struct Buf16 {
@@ -77,20 +83,41 @@ __device__ __forceinline__ float4 ld_f4(const float* base, const Buf16& b, uint3
     const hx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b.r, elem_off * 4u, 0, 16);
     return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
   } else {
-    return *reinterpret_cast<const float4*>(base + elem_off);
+    const hx_f32x4 v = *(const WB_GLOBAL_AS hx_f32x4*)(base + elem_off);
+    return make_float4(v.x, v.y, v.z, v.w);
   }
 }
-// 16-byte load at element offset elem_soff (wave-uniform) + elem_voff, default cache policy
+// 16-byte load at element offset elem_soff (wave-uniform) + elem_voff; AUX = 0: default cache policy, 2: nt (streamed once)
+template <int AUX = 0>
 __device__ __forceinline__ float4 ld_f4_plain(const Buf16& b, uint32_t elem_voff, uint32_t elem_soff) {
-  const hx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b.r, elem_voff * 4u, elem_soff * 4u, 0);
+  const hx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b.r, elem_voff * 4u, elem_soff * 4u, AUX);
   return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
 }
+// ---- loads through an EXPLICITLY global pointer ---------------------------------------------------------------------------
+// The persistent kernel reads its per-layer argument blocks from device memory (PersistArgs::layers), so the compiler cannot
+// know that the pointers inside them are global addresses: every weight / bias / cached-K,V access of the role bodies was a
+// FLAT load (1 208 flat_load_dwordx4 + 144 flat_load_dword in the round-4 ISA of dec_persist_kernel).  A flat access counts
+// on vmcnt AND lgkmcnt, so every wait for an LDS read (s_waitcnt lgkmcnt(0)) also waited for the weight rounds requested for
+// LATER use -- the prefetch could not overlap the role's own LDS phases -- and every address was a 64-bit VGPR pair.  The
+// role bodies therefore load global data through these helpers (global_load: vmcnt only).
+__device__ __forceinline__ float4 gld4(const float* p) {
+#ifdef WB_NT_W
+  const hx_f32x4 v = __builtin_nontemporal_load((const WB_GLOBAL_AS hx_f32x4*)p);
+#else
+  const hx_f32x4 v = *(const WB_GLOBAL_AS hx_f32x4*)p;
+#endif
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float gld(const float* p) { return *(const WB_GLOBAL_AS float*)p; }
+__device__ __forceinline__ int gld(const int* p) { return *(const WB_GLOBAL_AS int*)p; }
+// a 16-byte piece of a decoder weight matrix (experiment switch WB_NT_W: nt policy, MI355X_MICROARCH.md "nt-weights")
+__device__ __forceinline__ float4 ld_w4(const float* p) { return gld4(p); }
 // 4-byte load at base[elem_soff + elem_voff]: `elem_soff` must be wave-uniform (it rides in the instruction's scalar
 // offset, so the per-lane offset register is shared by all planes of a fold)
 template <bool SC1>
 __device__ __forceinline__ float ld_fb(const float* base, const Buf16& b, uint32_t elem_voff, uint32_t elem_soff) {
   if constexpr (SC1) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b.r, elem_voff * 4u, elem_soff * 4u, 16));
-  else return *(base + (int64_t)elem_soff + elem_voff);
+  else return *(const WB_GLOBAL_AS float*)(base + (int64_t)elem_soff + elem_voff);
 }
 template <bool SC1>
 __device__ __forceinline__ void st_f4(float* base, const Buf16& b, uint32_t elem_off, float4 v) {
