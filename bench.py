@@ -291,6 +291,40 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # ---- the same step from HOST PCM (SURVEY 8d words the metric "PCM in host memory -> token ids on host"): the contract's
+    # `value` is measured with the inputs resident in HBM; this leg hands the library the host buffer and lets it upload the
+    # rank's span inside the timed region, so the PCIe-inclusive figure stands next to it
+    from_host = None
+    if args.steps >= 2:
+        host_pcm = np.ascontiguousarray(audio[span[0]:span[1]])
+
+        def decode_local_host(lo, hi):
+            assert (lo, hi) == local_win
+            return wb.waveform_to_tokens(eng, st, host_pcm, sr, params=params, win_begin=0, win_end=hi - lo)[1]
+
+        def hstep():
+            return shard.transcribe_sharded(decode_local_host, wb.stitch_windows, n_win, rank, world, row_stride,
+                                            device=dev if world > 1 else None)
+
+        h_steps = max(2, min(args.steps, 40))
+        htok, _ = hstep()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(h_steps):
+            htok, _ = hstep()
+        barrier()
+        hdt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([hdt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            hdt = float(t.item())
+        assert list(htok) == list(tokens), "host-PCM path decoded different tokens"
+        from_host = {"value": round(args.seconds * world * h_steps / hdt, 2), "unit": "x real-time", "steps": h_steps,
+                     "ms_per_step": round(hdt / h_steps * 1e3, 3),
+                     "h2d_bytes_per_step_per_gpu": int(host_pcm.nbytes),
+                     "note": "identical step, but the PCM starts in pageable HOST memory and its upload is inside the timed "
+                             "region (`value` above: PCM resident in HBM, as the bench contract prescribes)"}
+
     # ---- per-kernel roofline (profiled passes: every decode-step launch carries its own start / stop HIP events on
     # the engine's stream = the dispatch's begin -> end, the quantity `rocprofv3 --kernel-trace` reports) ----
     roofline = None
@@ -370,15 +404,21 @@ def main() -> None:
         cpu_baseline = run_cpu_baseline(weights, st, audio, sr, int(wlen), args.beam, args.max_depth, args.geometry,
                                         args.model)
 
-    # ---- beam-5 leg: the reference's LIVE decode setting (transcribe.rs:232-233: beam_size 5, max_depth 100) on the same model,
-    # audio and windows as the headline figure (greedy = the same code with beam_size 1); `value` stays greedy
+    # ---- beam-5 leg: the reference's LIVE decode setting (transcribe.rs:232-233: beam_size 5, max_depth 100) on the same
+    # model shape, audio and windows as the headline figure (greedy = the same code with beam_size 1).  Beam search
+    # has no length normalisation (beam.rs:9-37), so on the headline checkpoint its beams end on <|endoftext|> after <= 26 tokens
+    # -- a third of the greedy run's decode work (round 4's leg).  The leg therefore runs the parity workload `tiny_beam5`
+    # (tests/workloads.py: the same recipe WITHOUT the EOT ramp): every window runs beam 5 to depth 100.  `value` stays greedy.
     beam5 = None
     if args.beam5_leg == "on" or (args.beam5_leg == "auto" and args.beam == 1 and args.geometry == "reference"):
+        bweights = synth.synth_preset(args.model, eot_beta=0.0)
+        beng = wb.Whisper.from_tensors(bweights, device=local_rank)
+        del bweights
         bparams = wb.decode_params(st, beam_size=5, max_depth=args.max_depth)
 
         def bdecode(lo, hi):
             assert (lo, hi) == local_win
-            return wb.waveform_to_tokens(eng, st, None, sr, params=bparams, win_begin=0, win_end=hi - lo,
+            return wb.waveform_to_tokens(beng, st, None, sr, params=bparams, win_begin=0, win_end=hi - lo,
                                          device_ptr=pcm_dev.data_ptr(), n_samples=n_local)[1]
 
         def bstep():
@@ -398,11 +438,13 @@ def main() -> None:
             t = torch.tensor([bdt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             bdt = float(t.item())
+        beng.close()
         if rank == 0:
             beam5 = {"metric": "real-time factor (audio-sec/wall-sec)",
                      "value": round(args.seconds * world * b_steps / bdt, 2), "unit": "x real-time", "n_gpus": world,
                      "steps": b_steps, "warmup": b_warm, "ms_per_step": round(bdt / b_steps * 1e3, 3), "dtype": args.dtype,
-                     "config": {"workload": f"{args.model}, {args.seconds:g} s of 16 kHz audio per GPU per step, reference windowing "
+                     "config": {"workload": f"{args.model} shape, checkpoint without the <|endoftext|> ramp (parity workload "
+                                            f"tiny_beam5), {args.seconds:g} s of 16 kHz audio per GPU per step, reference windowing "
                                             f"({n_win} windows), beam_size 5, max_depth {args.max_depth} (the reference's live "
                                             f"setting, transcribe.rs:232-233)",
                                 "tokens_out": len(btok),
@@ -417,7 +459,9 @@ def main() -> None:
                                      and args.geometry == "reference" and args.beam == 1):
         eng.close()
         del pcm_dev
-        lw = synth.synth_preset("large-v2")
+        # (checkpoint without the <|endoftext|> ramp: every window decodes max_depth tokens -- the leg's work does not depend
+        # on where the synthetic checkpoint happens to end its rows; rounds 3 / 4 measured the same depth, mean 100.0)
+        lw = synth.synth_preset("large-v2", eot_beta=0.0)
         leng = wb.Whisper.from_tensors(lw, device=local_rank)
         del lw
         leng_split = leng.encoder_gemm() == "f16x3"
@@ -460,7 +504,27 @@ def main() -> None:
         if rank == 0:
             # the leg's own roofline: dominant batch-mode decode kernel of ONE profiled pass (attached HIP events per launch)
             lbuf, lkstats = profiled_passes(lib, _lib, lambda: ldecode(*lwin), 1)
-            lkern = kernel_table(lkstats)
+            # measured HBM bytes per launch of the batch-mode kernels: the two --pmc passes of `bench.py --model large-v2
+            # --seconds 450` (profiles/collect_r05*.sh -> profiles/r05_*_pmc_traffic_large_v2_450s.json), newest round
+            import glob as _glob
+            lcands = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_traffic_large_v2_450s.json")))
+            lpmc = json.load(open(lcands[-1])) if lcands and args.large_v2_seconds == 450.0 else {}
+
+            def lpmc_bytes(cls_name):
+                want = {"batch: split-K MFMA GEMM": "dec_skinny_gemm_kernel", "batch: dec_resolve_ln": "dec_resolve_ln_kernel",
+                        "batch: dec_self_attn": "dec_self_attn_kernel", "batch: dec_cross_attn_stream": "dec_cross_attn_stream_kernel",
+                        "batch: dec_gelu_fold": "dec_gelu_fold_kernel", "batch: dec_topk_rows": "dec_topk_rows_kernel",
+                        "batch: dec_layer": "dec_layer_kernel"}
+                for key, frag in want.items():
+                    if cls_name.startswith(key):
+                        vals = [v for n, v in lpmc.items() if frag in n]
+                        # (several template instances share a class: launches differ in size, take the launch-weighted mean
+                        # when the file carries it, else the largest)
+                        return int(max(vals)) if vals else None
+                return None
+
+            lkern = kernel_table(lkstats, lpmc_bytes)
+            lsrc = os.path.relpath(lcands[-1], ROOT) if lpmc else None
             l_enc_ms, l_ckv_ms, l_dec_ms, l_nsteps = lbuf[1], lbuf[2], lbuf[3], lbuf[4]
             lgen = [max(0, len(r) - 4) for r in lrows[lwin[0]:lwin[1]]]
             lenc_peak = "f16x3" if leng_split else args.dtype
@@ -476,8 +540,9 @@ def main() -> None:
                         "config": {"workload": f"large-v2, {args.large_v2_seconds:g} s of 16 kHz audio per GPU per step, "
                                                f"reference windowing ({ln_win} windows), greedy, max_depth {args.max_depth}",
                                    "windows": ln_win, "tokens_out": len(ltok),
+                                   "checkpoint": "large-v2 shape, synthetic, no <|endoftext|> ramp (every window runs to max_depth)",
                                    "generated_tokens_per_window_mean": round(float(np.mean([len(r) - 4 for r in lrows])), 1)},
-                        "roofline": roofline_of(lkern[0]) if lkern else None,
+                        "roofline": roofline_of(lkern[0], lsrc) if lkern else None,
                         "kernels": lkern,
                         "stages": {"encoder_ms_per_step": round(l_enc_ms, 2), "cross_kv_ms_per_step": round(l_ckv_ms, 2),
                                    "decode_ms_per_step_untraced": round(l_dec_untraced, 2),
@@ -556,6 +621,7 @@ def main() -> None:
             "kernels": kernels,
             "cpu_baseline": cpu_baseline,
             "e2e_roofline": e2e,
+            "from_host_pcm": from_host,
             "mel_frontend": mel_frontend,
             "stages": stages,
             "beam5": beam5,

@@ -2,7 +2,7 @@
 
 The model-parity tests (test_gpu_workloads.py, test_gpu_batchmode.py) hand the HIP log-mel to both sides so that they can
 assert 1e-3 on the model alone; the frontend has its own tests.  Round 4's review asked for the missing composition: nothing
-shared.  Here each side starts from the same f32 PCM of one full reference window (14.9 s):
+shared.  Here each side starts from the same f32 PCM of an 11.9 s clip (the longest the reference treats as ONE window):
 
   hip      wb_waveform_to_tokens / a KV-cached session from PCM: HIP mel -> encoder -> decode steps (C ABI)
   o32      the oracle from PCM with its own f32 frontend (oracle.mel.prep_audio: the reference's dense f32 DFT, audio.rs:284-367)
@@ -29,7 +29,8 @@ from whisper_burn_amd import synth
 pytestmark = pytest.mark.gpu
 
 LOGPROB_TOL = 1e-3
-WLEN = 238559            # one full reference window (max_waveform_samples(1490), transcribe.rs:32-34)
+WLEN = 238559            # max_waveform_samples(1490), transcribe.rs:32-34
+N_CLIP = 190559          # = WLEN - 3 s: the longest clip the reference cuts into ONE window (transcribe.rs:120-128), 11.9 s
 
 
 def _pad(o, mel):
@@ -42,7 +43,7 @@ def test_pcm_to_tokens_and_logprob_rows_with_the_oracles_own_frontend(model, dep
     w = synth.synth_preset(model, eot_beta=0.0)                    # no EOT ramp: the row runs to `depth`
     eng, o = wb.Whisper.from_tensors(w), OracleWhisper(w)
     st = wb.SpecialTokens.for_vocab(eng.dims["n_vocab"])
-    audio = synth.synth_audio(WLEN, seed)
+    audio = synth.synth_audio(N_CLIP, seed)
     # ---- hip, from PCM: the decoded row, then its per-step log-prob rows from a KV-cached session
     _, wins = wb.waveform_to_tokens(eng, st, audio, 16000, 1, depth)
     assert len(wins) == 1

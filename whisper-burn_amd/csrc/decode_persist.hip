@@ -47,9 +47,6 @@ using namespace fused;
 
 constexpr int PS_NT = 512;
 constexpr int PS_CT = 128;      // vocabulary columns per logits tile
-#ifndef WB_ET_AUX
-#define WB_ET_AUX 0   // cache policy of the E^T tile stream (2 = nt)
-#endif
 constexpr int PS_NGO = 16;      // wake-up words of the logits roles (a few hundred pollers: ~13 per word)
 
 // ---- final LayerNorm role: row r of  ln(x + b2 + sum_j P2[j])  (mod.rs:155), once per row ---------------------------------
@@ -129,7 +126,7 @@ __device__ __forceinline__ bool ps_logits_role(const PersistArgs& a, const int t
     const bool col_ok = n0 + c4 < a.vocab_ld;      // lanes past the padded vocabulary re-read the tile's first columns
     const uint32_t vo = (uint32_t)((2 * wave + hh) * NR * a.vocab_ld + n0 + (col_ok ? c4 : 0));
 #pragma unroll
-    for (int i = 0; i < NR; i++) w[i] = ld_f4_plain<WB_ET_AUX>(etb, vo, (uint32_t)(i * a.vocab_ld));
+    for (int i = 0; i < NR; i++) w[i] = ld_f4_plain(etb, vo, (uint32_t)(i * a.vocab_ld));
   };
   // Both tiles of the role are requested BEFORE the wait where the registers allow it: streamed after the wait, the
   // second tile of 203 blocks (40 MB at once, next to everybody's weight prefetch for the next step) took ~20 us

@@ -175,22 +175,8 @@ __global__ __launch_bounds__(NT, WB_F16X3_MIN_WAVES) void gemm_f16x3_kernel(Gemm
         bh[j] = *reinterpret_cast<const f16x8*>(&Bh[buf][wn * TN + j * 32 + li][ks * 16 + lh * 8]);
         bl[j] = *reinterpret_cast<const f16x8*>(&Bl[buf][wn * TN + j * 32 + li][ks * 16 + lh * 8]);
       }
-#ifdef WB_F16X3_TERM_MAJOR
-      // opt-in (to be measured; bit-identical: every accumulator sees its terms in the same order): term-major issue order --
-      // all hi.hi products, then all hi.lo, then all lo.hi, so that no two consecutive MFMAs share an accumulator
-#pragma unroll
-      for (int i = 0; i < RM; i++)
-#pragma unroll
-        for (int j = 0; j < RN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < RM; i++)
-#pragma unroll
-        for (int j = 0; j < RN; j++) acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acl[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < RM; i++)
-#pragma unroll
-        for (int j = 0; j < RN; j++) acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acl[i][j], 0, 0, 0);
-#else
+      // (issue order: a term-major order -- all hi.hi, then all hi.lo, then all lo.hi, no two consecutive MFMAs on one
+      // accumulator -- was measured in round 5 and changes nothing: large-v2 encoder 198.3 vs 198.3 ms, the loop is LDS-bound)
 #pragma unroll
       for (int i = 0; i < RM; i++)
 #pragma unroll
@@ -199,7 +185,6 @@ __global__ __launch_bounds__(NT, WB_F16X3_MIN_WAVES) void gemm_f16x3_kernel(Gemm
           acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acl[i][j], 0, 0, 0);
           acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acl[i][j], 0, 0, 0);
         }
-#endif
     }
     if (t + 1 < nk) store_tile(buf ^ 1);
     __syncthreads();

@@ -87,10 +87,11 @@ __device__ __forceinline__ float4 ld_f4(const float* base, const Buf16& b, uint3
     return make_float4(v.x, v.y, v.z, v.w);
   }
 }
-// 16-byte load at element offset elem_soff (wave-uniform) + elem_voff; AUX = 0: default cache policy, 2: nt (streamed once)
-template <int AUX = 0>
+// 16-byte load at element offset elem_soff (wave-uniform) + elem_voff, default cache policy.  (nt on the E^T tile stream and
+// on the layer weights / cached K,V was measured in round 5: 13.66 -> 13.77 ms and -> 15.6 ms per bench step -- the weights
+// are RE-read every step from the L2 / Infinity Cache, the guide's "nt-weights" row is about a stream read once.)
 __device__ __forceinline__ float4 ld_f4_plain(const Buf16& b, uint32_t elem_voff, uint32_t elem_soff) {
-  const hx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b.r, elem_voff * 4u, elem_soff * 4u, AUX);
+  const hx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b.r, elem_voff * 4u, elem_soff * 4u, 0);
   return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
 }
 // ---- loads through an EXPLICITLY global pointer ---------------------------------------------------------------------------
@@ -101,17 +102,12 @@ __device__ __forceinline__ float4 ld_f4_plain(const Buf16& b, uint32_t elem_voff
 // LATER use -- the prefetch could not overlap the role's own LDS phases -- and every address was a 64-bit VGPR pair.  The
 // role bodies therefore load global data through these helpers (global_load: vmcnt only).
 __device__ __forceinline__ float4 gld4(const float* p) {
-#ifdef WB_NT_W
-  const hx_f32x4 v = __builtin_nontemporal_load((const WB_GLOBAL_AS hx_f32x4*)p);
-#else
   const hx_f32x4 v = *(const WB_GLOBAL_AS hx_f32x4*)p;
-#endif
   return make_float4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ float gld(const float* p) { return *(const WB_GLOBAL_AS float*)p; }
 __device__ __forceinline__ int gld(const int* p) { return *(const WB_GLOBAL_AS int*)p; }
-// a 16-byte piece of a decoder weight matrix (experiment switch WB_NT_W: nt policy, MI355X_MICROARCH.md "nt-weights")
-__device__ __forceinline__ float4 ld_w4(const float* p) { return gld4(p); }
+__device__ __forceinline__ float4 ld_w4(const float* p) { return gld4(p); }     // a 16-byte piece of a decoder weight matrix
 // 4-byte load at base[elem_soff + elem_voff]: `elem_soff` must be wave-uniform (it rides in the instruction's scalar
 // offset, so the per-lane offset register is shared by all planes of a fold)
 template <bool SC1>

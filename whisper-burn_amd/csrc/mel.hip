@@ -51,70 +51,17 @@ __device__ __forceinline__ cpx cmul(cpx a, float wr, float wi) {
   return {a.re * wr - a.im * wi, a.re * wi + a.im * wr};
 }
 
-// 20-point forward DFT (e^{-i...}) in registers: 5 radix-4 butterflies, twiddles W20^{bc},
-// 4 radix-5 butterflies.  n = 5a+b, k = c+4e.
-__device__ __forceinline__ void dft20(cpx (&x)[20]) {
-  constexpr float C1 = 0.30901699437494742f;    // cos(2pi/5)
-  constexpr float C2 = -0.80901699437494742f;   // cos(4pi/5)
-  constexpr float S1 = 0.95105651629515357f;    // sin(2pi/5)
-  constexpr float S2 = 0.58778525229247313f;    // sin(4pi/5)
-  // W20^j = cos(2pi j/20) - i sin(2pi j/20), j = 0..9
-  constexpr float WR[10] = {1.f, 0.95105651629515357f, 0.80901699437494742f, 0.58778525229247313f,
-                            0.30901699437494742f, 0.f, -0.30901699437494742f, -0.58778525229247313f,
-                            -0.80901699437494742f, -0.95105651629515357f};
-  constexpr float WI[10] = {0.f, -0.30901699437494742f, -0.58778525229247313f, -0.80901699437494742f,
-                            -0.95105651629515357f, -1.f, -0.95105651629515357f, -0.80901699437494742f,
-                            -0.58778525229247313f, -0.30901699437494742f};
-  cpx u[5][4];
-#pragma unroll
-  for (int b = 0; b < 5; b++) {
-    cpx x0 = x[b], x1 = x[5 + b], x2 = x[10 + b], x3 = x[15 + b];
-    cpx s02 = {x0.re + x2.re, x0.im + x2.im}, d02 = {x0.re - x2.re, x0.im - x2.im};
-    cpx s13 = {x1.re + x3.re, x1.im + x3.im}, d13 = {x1.re - x3.re, x1.im - x3.im};
-    cpx t0 = {s02.re + s13.re, s02.im + s13.im};
-    cpx t2 = {s02.re - s13.re, s02.im - s13.im};
-    // t1 = d02 - i*d13 ; t3 = d02 + i*d13
-    cpx t1 = {d02.re + d13.im, d02.im - d13.re};
-    cpx t3 = {d02.re - d13.im, d02.im + d13.re};
-    u[b][0] = t0;
-    if (b == 0) {
-      u[b][1] = t1; u[b][2] = t2; u[b][3] = t3;
-    } else {
-      u[b][1] = cmul(t1, WR[b], WI[b]);
-      u[b][2] = cmul(t2, WR[2 * b], WI[2 * b]);
-      // W20^{3b}, 3b up to 12: W20^{j+10} = -W20^j
-      int j = 3 * b;
-      float wr = j < 10 ? WR[j] : -WR[j - 10], wi = j < 10 ? WI[j] : -WI[j - 10];
-      u[b][3] = cmul(t3, wr, wi);
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < 4; c++) {
-    cpx u0 = u[0][c], u1 = u[1][c], u2 = u[2][c], u3 = u[3][c], u4 = u[4][c];
-    cpx a1 = {u1.re + u4.re, u1.im + u4.im}, a2 = {u2.re + u3.re, u2.im + u3.im};
-    cpx b1 = {u1.re - u4.re, u1.im - u4.im}, b2 = {u2.re - u3.re, u2.im - u3.im};
-    cpx p1 = {u0.re + C1 * a1.re + C2 * a2.re, u0.im + C1 * a1.im + C2 * a2.im};
-    cpx p2 = {u0.re + C2 * a1.re + C1 * a2.re, u0.im + C2 * a1.im + C1 * a2.im};
-    cpx q1 = {S1 * b1.re + S2 * b2.re, S1 * b1.im + S2 * b2.im};
-    cpx q2 = {S2 * b1.re - S1 * b2.re, S2 * b1.im - S1 * b2.im};
-    x[c] = {u0.re + a1.re + a2.re, u0.im + a1.im + a2.im};
-    x[c + 4] = {p1.re + q1.im, p1.im - q1.re};     // p1 - i q1
-    x[c + 16] = {p1.re - q1.im, p1.im + q1.re};    // p1 + i q1
-    x[c + 8] = {p2.re + q2.im, p2.im - q2.re};
-    x[c + 12] = {p2.re - q2.im, p2.im + q2.re};
-  }
-}
-
 #ifndef WB_MEL_MIN_BLOCKS
 #define WB_MEL_MIN_BLOCKS 4
 #endif
 
-#ifdef WB_MEL_PK_DFT
-// ---- opt-in (-DWB_MEL_PK_DFT; built and checked on the functional model in round 4, NOT yet measured or run on a GPU):
-// the same 20-point DFT with every complex value held as one 64-bit register pair and every butterfly written as ONE packed
-// instruction, the half-swaps and sign flips of "multiply by -i" / complex multiplication expressed through the VOP3P
-// op_sel / neg modifiers instead of register moves.  The compiler's own SLP packing of dft20() above leaves ~400 v_mov next
-// to ~380 packed operations (it builds the swapped pairs with moves); this form needs ~136 packed instructions per transform.
+// ---- 20-point forward DFT (e^{-i...}) in registers: 5 radix-4 butterflies, twiddles W20^{bc}, 4 radix-5 butterflies
+// (n = 5a + b, k = c + 4e).  Every complex value is ONE 64-bit register pair and every butterfly ONE packed instruction: the
+// half-swaps and sign flips of "multiply by -i" / complex multiplication by a constant ride in the VOP3P op_sel / neg
+// modifiers instead of register moves.  (The plain-C form of rounds 1-4 left the packing to the compiler's SLP pass, which
+// built the swapped pairs with moves: 892 VALU instructions for the two transforms of a thread, 197 of them v_mov, against
+// 572 / 54 here.  Measured in round 5 on one box, alternating: 1.14 -> 1.21 G frames/s, with the plain v_fmac filterbank
+// sums below 1.30 -- profiles/r05_a_variants.txt.)
 typedef float f2 __attribute__((ext_vector_type(2)));
 #if defined(HIPEMU)
 // functional model: the helpers by their arithmetic (mul then fma, as the two-instruction forms below round)
@@ -175,8 +122,7 @@ __device__ __forceinline__ f2 pk_mul_hi(f2 a, f2 c) {
 }
 #endif
 
-// Same decomposition and operation order as dft20(): 5 radix-4 butterflies, twiddles W20^{bc}, 4 radix-5 butterflies.
-__device__ __forceinline__ void dft20_pk(cpx (&xc)[20]) {
+__device__ __forceinline__ void dft20(cpx (&xc)[20]) {
   // W20^j = (cos(2 pi j / 20), -sin(2 pi j / 20)), j = 0..12 as (re, im) pairs
   const f2 W[13] = {{1.f, 0.f}, {0.95105651629515357f, -0.30901699437494742f}, {0.80901699437494742f, -0.58778525229247313f},
                     {0.58778525229247313f, -0.80901699437494742f}, {0.30901699437494742f, -0.95105651629515357f}, {0.f, -1.f},
@@ -216,10 +162,6 @@ __device__ __forceinline__ void dft20_pk(cpx (&xc)[20]) {
 #pragma unroll
   for (int i = 0; i < 20; i++) xc[i] = cpx{x[i].x, x[i].y};
 }
-#define WB_DFT20 dft20_pk
-#else
-#define WB_DFT20 dft20
-#endif
 
 __global__ __launch_bounds__(MEL_THREADS, WB_MEL_MIN_BLOCKS) void mel_spectrogram_kernel(
     const float* __restrict__ pcm, const MelWindow* __restrict__ wins, const MelTables* __restrict__ tabs,
@@ -314,7 +256,7 @@ __global__ __launch_bounds__(MEL_THREADS, WB_MEL_MIN_BLOCKS) void mel_spectrogra
     const float hw = tabs->hann[20 * n1 + q];   // periodic Hann (audio.rs:272-278); L1-resident, same for every block
     z[n1] = {reg[20 * n1 + q] * hw, reg[FROW + 20 * n1 + q] * hw};
   }
-  WB_DFT20(z);
+  dft20(z);
   __syncthreads();   // everyone has consumed the frame rows; region becomes U[k1][n2]
   float2* U = reinterpret_cast<float2*>(reg);
 #pragma unroll
@@ -330,7 +272,7 @@ __global__ __launch_bounds__(MEL_THREADS, WB_MEL_MIN_BLOCKS) void mel_spectrogra
     float2 v = U[q * UROW + n2];
     z[n2] = {v.x, v.y};
   }
-  WB_DFT20(z);
+  dft20(z);
   __syncthreads();
   float2* Z = reinterpret_cast<float2*>(reg);   // Z[k], k = 0..399
 #pragma unroll
@@ -402,9 +344,9 @@ __global__ __launch_bounds__(MEL_THREADS, WB_MEL_MIN_BLOCKS) void mel_spectrogra
         const float* tw = lds + (m / 5) * 2 * FROW + TAP_OFF + (m % 5) * MEL_MAX_TAPS;
         const float4 w4 = *reinterpret_cast<const float4*>(tw + 4 * c);
         const float* pp = Pf + s0v[r] + 4 * c;
-#if defined(WB_MEL_FMAC_ASM) && !defined(HIPEMU)
-        // opt-in (to be measured): plain v_fmac -- the compiler SLP-packs the sums of two rows into v_pk_fma_f32 and builds
-        // each operand pair with two or three v_mov (16 packed + ~40 moves per chunk against 32 scalar FMAs)
+#if !defined(HIPEMU)
+        // plain v_fmac: left to itself the compiler SLP-packs the sums of two rows into v_pk_fma_f32 and builds each operand
+        // pair with two or three v_mov (16 packed + ~40 moves per chunk against 32 scalar FMAs); same operation order
         asm("v_fmac_f32 %0, %1, %2" : "+v"(accv[r]) : "v"(w4.x), "v"(pp[0]));
         asm("v_fmac_f32 %0, %1, %2" : "+v"(accv[r]) : "v"(w4.y), "v"(pp[1]));
         asm("v_fmac_f32 %0, %1, %2" : "+v"(accv[r]) : "v"(w4.z), "v"(pp[2]));
