@@ -438,6 +438,14 @@ def main() -> None:
             t = torch.tensor([bdt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             bdt = float(t.item())
+        bkern, bstages = None, None
+        if rank == 0:
+            # where the beam path's time goes: one profiled pass (attached HIP events per launch), like the other legs
+            bbuf, bkstats = profiled_passes(lib, _lib, lambda: bdecode(*local_win), 1)
+            bkern = kernel_table(bkstats)
+            bstages = {"encoder_ms": round(bbuf[1], 3), "cross_kv_ms": round(bbuf[2], 3), "decode_ms_profiled_pass": round(bbuf[3], 3),
+                       "decode_steps": bbuf[4], "decode_kernel_ms_sum": round(sum(k["total_ms"] for k in bkstats), 3),
+                       "launches": int(sum(k["calls"] for k in bkstats))}
         beng.close()
         if rank == 0:
             beam5 = {"metric": "real-time factor (audio-sec/wall-sec)",
@@ -449,6 +457,7 @@ def main() -> None:
                                             f"setting, transcribe.rs:232-233)",
                                 "tokens_out": len(btok),
                                 "generated_tokens_per_window": [max(0, len(r) - 4) for r in brows],
+                                "stages_profiled_pass": bstages, "kernels": bkern,
                                 "path": "host-driven beam search (beam.rs restated in C++) over KV-cached session steps: fused "
                                         "sublayer kernels while <= 8 beams are live, batch mode above; the persistent kernel "
                                         "serves greedy only"}}

@@ -159,10 +159,13 @@ def test_persistent_decode_falls_back_to_the_chain(emu_lib, env):
     assert not os.path.exists(env["WHISPER_HIP_PS_STAMPS"]), "the persistent kernel ran although it was made to fail"
 
 
-@pytest.mark.parametrize("which,env", [("beam_batch", {}), ("beam_batch", {"WHISPER_HIP_SK_PAIR": "1"}),
+@pytest.mark.parametrize("which,env", [("beam_batch", {}), ("beam_batch", {"WHISPER_HIP_DECODER_SPLIT": "0"}),
+                                       ("beam_batch", {"WHISPER_HIP_DECODER_SPLIT": "0", "WHISPER_HIP_SK_PAIR": "1"}),
                                        ("chain_eot_batch", {"WHISPER_HIP_CROSS_STREAM_FUSE": "0"})])
 def test_batch_mode_skinny_gemm_and_fused_streaming_blocks(emu_lib, which, env):
-    """decode_batch.hip under the functional model: the skinny split-K GEMM on v_mfma_f32_16x16x4_f32 with 36 live rows
+    """decode_batch.hip under the functional model: the skinny split-K GEMM -- the split-precision default on
+    v_mfma_f32_16x16x32_f16 (fp16 hi / lo weight tiles) and, with WHISPER_HIP_DECODER_SPLIT=0, the exact-f32 one on
+    v_mfma_f32_16x16x4_f32 -- with 36 live rows
     (three row tiles; 9 windows x 4 beams, chunked cross-attention; also with the opt-in pairwise meeting of the waves'
     partial tiles), and the streaming cross-attention blocks without
     their fused front (fold + cross_attn_ln + Wq; the default at this width is fused, and the tiled GEMM the skinny one

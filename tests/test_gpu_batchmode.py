@@ -100,16 +100,19 @@ def test_large_v2_10_windows_depth_100_batch_mode(large_v2):
     print(f"large-v2 10 windows: {n_tok} teacher-forced decisions, smallest oracle top-2 gap {gap:.3e}")
 
 
-def _session_logprob_rows(eng, o, st, audio, use_windows, max_beams, n_steps, fork_at, seed):
+def _session_logprob_rows(eng, o, st, audio, use_windows, max_beams, n_steps, fork_at, seed, check=None):
     """Drive a KV-cached session over `use_windows` with up to `max_beams` beams per window for `n_steps` positions and
     return the largest (and the rms over rows of the per-row largest) |session log-prob row - stateless oracle row| over
     the compared beams and steps.  Beams fork once at step `fork_at` (when max_beams > 1); every beam continues with a
-    random pick among its own top-5, so rows depend on the whole history."""
+    random pick among its own top-5, so rows depend on the whole history.  `check`: positions in `use_windows` whose rows are
+    compared (default: all) -- every window is decoded (the batch composition is what selects the kernels), the oracle side
+    (one encoder pass + one teacher-forced decoder pass per sequence, the test's cost at large-v2) runs for those only."""
     starts, lens = wb.window_extents(len(audio), 16000, WLEN)
     sess = wb.Session.begin(eng, audio, starts[use_windows], lens[use_windows], max_beams=max_beams)
     sess.set_special_mask(st.is_special)
     mels = pu.window_mels(o, audio, frontend=wb.prep_audio)
-    encs = [o.forward_encoder(mels[i])[0] for i in use_windows]
+    check = set(range(len(use_windows))) if check is None else set(check)
+    encs = {wdx: o.forward_encoder(mels[use_windows[wdx]])[0] for wdx in sorted(check)}
     prompt = [st.start_of_transcript, st.language, st.transcribe, st.no_timestamps]
     K = 5
     nw = len(use_windows)
@@ -129,7 +132,7 @@ def _session_logprob_rows(eng, o, st, audio, use_windows, max_beams, n_steps, fo
             continue
         # compare a rotating third of the rows each step (every row is covered many times; V floats per row cross PCIe)
         for slot, (seq, wdx) in enumerate(beams):
-            if (slot + step) % 3 == 0 or step >= n_steps - 12:
+            if wdx in check and ((slot + step) % 3 == 0 or step >= n_steps - 12):
                 got = sess.last_logprobs(slot)
                 order = np.lexsort((np.arange(got.shape[0]), -got.astype(np.float64)))[:K]
                 assert ids[slot].tolist() == order.tolist(), (step, slot)
@@ -177,7 +180,7 @@ def test_large_v2_batch_mode_beams_logprob_rows(large_v2):
     eng, o = large_v2
     st = wb.SpecialTokens.for_vocab(51865)
     audio = synth.synth_audio(1900000, 1240)
-    res = _session_logprob_rows(eng, o, st, audio, [0, 2, 4, 6, 9], 2, 20, 3, 11)
+    res = _session_logprob_rows(eng, o, st, audio, [0, 2, 4, 6, 9], 2, 20, 3, 11, check=(0, 2, 4))
     assert res["n_live"] == 10 and res["longest"] >= 20
     print(f"large-v2 5 x 2 beams: {res}")
     _assert_rows(res)
@@ -189,7 +192,7 @@ def test_large_v2_batch_mode_streaming_logprob_rows(large_v2):
     eng, o = large_v2
     st = wb.SpecialTokens.for_vocab(51865)
     audio = synth.synth_audio(1900000, 1240)
-    res = _session_logprob_rows(eng, o, st, audio, list(range(9)), 1, 24, -1, 21)
+    res = _session_logprob_rows(eng, o, st, audio, list(range(9)), 1, 24, -1, 21, check=(0, 3, 5, 8))
     assert res["n_live"] == 9 and res["longest"] >= 24
     print(f"large-v2 9 x 1 beam: {res}")
     _assert_rows(res)

@@ -37,7 +37,10 @@ SWITCHES = [{}, {"WHISPER_HIP_FUSE_X": "0"}, {"WHISPER_HIP_FUSE_SUB": "0"}, {"WH
             # client): the session falls back to the chain instead of failing
             {"WHISPER_HIP_PERSIST_INJECT_FAIL": "launch"},
             # the prompt prefill as host-driven steps in front of the persistent launch instead of forced steps inside it
-            {"WHISPER_HIP_PERSIST_PREFILL": "0"}]
+            {"WHISPER_HIP_PERSIST_PREFILL": "0"},
+            # batch-mode decode (the beam-5 leg: 15 live rows): the exact-f32 skinny weight-stream GEMM instead of the
+            # split-precision fp16 one (decode_batch.hip: dec_skinny_f16x3_kernel, the default since round 5)
+            {"WHISPER_HIP_DECODER_SPLIT": "0"}]
 
 
 _CACHE = {}

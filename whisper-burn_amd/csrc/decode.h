@@ -177,7 +177,13 @@ struct SkinnyArgs {
   const float* B = nullptr; int ldb = 0;          // weight [K][N] row-major (Linear: [d_in, d_out])
   int M = 0, N = 0, K = 0, ksplit = 1;            // M <= 64, N % 64 == 0, K % (32 ksplit) == 0
   float* P = nullptr; int plane = 0;              // split-K planes out: P[z * plane + r * N + n]  (plane in elements)
+  // split-precision variant: the weight as fp16 hi / lo (x 2^11) pieces in MFMA tiles (LinearW::th / tl); null = exact f32
+  const uint16_t* Bh = nullptr; const uint16_t* Bl = nullptr;
+  int* range_flag = nullptr;                      // raised (mapped host word) when a result of a LIVE row is not finite
+  const int* st = nullptr;                        // step state (st[ST_N] = live rows: rows past it hold stale activations); null: all M
 };
+// W [K][N] f32 -> hi, lo tiles [N / 16][K / 32][4][16][8] fp16 (K % 32 == 0, N % 16 == 0)
+void launch_split_weight_f16_tiles(hipStream_t st, const float* W, int K, int N, uint16_t* hi, uint16_t* lo);
 int skinny_ksplit(int K, int N, int max_ks, int max_rows);   // 0: shape not served
 bool skinny_supported(int M, int K, int N);
 int launch_dec_skinny_gemm(hipStream_t st, const SkinnyArgs& a);

@@ -174,6 +174,165 @@ __global__ __launch_bounds__(SK_NT, MT <= 2 ? 2 : 1) void dec_skinny_gemm_kernel
   }
 }
 
+
+// ---- split-precision variant (round 5): the same launch geometry, planes and consumers, arithmetic on the 16-bit matrix path
+//
+// At 33 - 64 rows the exact-f32 MFMA is the launch's longest phase, not the weight stream: a wave issues LDW x MT x 4 =
+// 240 v_mfma_f32_16x16x4_f32 (32 clk each) at three row tiles, two waves share a SIMD: 15 360 clk = 6.4 us of matrix-pipe time
+// per block inside a launch of 10.5 us on average (large-v2, 38 rows: profiles/r04_e_bench_default.json).  Here the weight
+// arrives as fp16 hi / lo (x 2^11) pieces -- the same 4 bytes per element, so the stream is what it was -- and the
+// activations are split on their way into LDS (A = A_hi + 2^-11 A_lo, as gemm_f16x3.hip):
+//   A W  ~=  A_hi W_hi + 2^-11 (A_hi W_lo + A_lo W_hi)        three v_mfma_f32_16x16x32_f16 (16 clk each) per 32-deep tile
+// i.e. 108 MFMAs of half the duration per wave: 1.4 us.  f32 accumulation, 22-bit operands: f32-grade (and each output's K
+// chain is 8x shorter than the f32 kernel's, which is what set the distance to the exact result in round 4, LABLOG R4.1).
+//
+// Weight layout (LinearW::th / tl, made at load by split_weight_f16_tiles): [n / 16][k / 32][kg = (k % 32) / 8][j = n % 16][8]
+// -- the B operand of lane l = 16 kg + j for one (16-column, 32-deep) tile is the 16 bytes at l x 16 of a 1 KB block: every
+// load instruction of a wave is one fully coalesced kilobyte.  Activations in LDS the same way ([row tile][k / 32][kg][i][8]),
+// so the A operand is one conflict-free ds_read_b128.  A wave owns the strip's four 16-column tiles over its share of the
+// block's 32-deep K tiles (the block's <= 20 tiles dealt 3 / 2 to the eight waves), all of them requested before the first use.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+constexpr int SKH_MAXCH = 3;        // 32-deep K tiles per wave (kchunk <= 640 = 20 tiles over 8 waves)
+constexpr float SKH_LO_SCALE = 2048.f, SKH_LO_UNSCALE = 1.f / 2048.f;
+
+__device__ __forceinline__ void skh_split4(const float4 v, uint2& hi, uint2& lo) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  u16 h[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const _Float16 hh = (_Float16)x[i];
+    h[i] = __builtin_bit_cast(u16, hh);
+    l[i] = __builtin_bit_cast(u16, (_Float16)((x[i] - (float)hh) * SKH_LO_SCALE));
+  }
+  hi = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+  lo = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+}
+
+template <int MT>
+__global__ __launch_bounds__(SK_NT, MT <= 2 ? 2 : 1) void dec_skinny_f16x3_kernel(SkinnyArgs a) {
+  // one region, two lives: the activations of the block's K slice as fp16 pieces (hi then lo: MT x kchunk x 16 halves each),
+  // then the 8 waves' partial tiles (8 x MT x 16 x 64 floats)
+  constexpr int LDW = sk_ldw(MT);
+  constexpr int WORDS = MT * 512 * LDW > MT * 8192 ? MT * 512 * LDW : MT * 8192;
+  __shared__ __attribute__((aligned(16))) float smem[WORDS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int strip = blockIdx.x, z = blockIdx.y;
+  const int kchunk = a.K / a.ksplit;                 // host: K % (32 ksplit) == 0, kchunk <= 32 LDW
+  const int nch = kchunk >> 5;                       // 32-deep tiles of the block
+  const int kb = z * kchunk;
+  const int n0 = strip * 64;
+  const int kg = lane >> 4, j = lane & 15;
+  u16* As_hi = reinterpret_cast<u16*>(smem);
+  u16* As_lo = As_hi + MT * kchunk * 16;
+
+  // ---- requested first (loads return in order): the activations of the K slice (rows past M are zeros) ...
+  constexpr int AQ = (MT * 16 * (32 * LDW / 4) + SK_NT - 1) / SK_NT;    // float4 quads per thread, at most
+  const int nq = kchunk >> 2;
+  float4 av4[AQ];
+#pragma unroll
+  for (int i = 0; i < AQ; i++) {
+    const int idx = tid + i * SK_NT, r = idx % (MT * 16), kq = idx / (MT * 16);
+    av4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kq < nq && r < a.M) av4[i] = *reinterpret_cast<const float4*>(a.A + (int64_t)r * a.lda + kb + 4 * kq);
+  }
+  // ---- ... then the wave's weight tiles: every one requested now (1 KB per instruction, linear in the lane)
+  const int c0 = wave * nch / 8, c1 = (wave + 1) * nch / 8;
+  f16x8 bh[SKH_MAXCH][4], bl[SKH_MAXCH][4];
+  {
+    const int64_t ktiles = a.K >> 5;
+#pragma unroll
+    for (int t = 0; t < SKH_MAXCH; t++)
+      if (c0 + t < c1) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const int64_t off = (((int64_t)(n0 / 16 + c) * ktiles + (kb >> 5) + c0 + t) * 64 + lane) * 8;
+          bh[t][c] = *reinterpret_cast<const f16x8*>(a.Bh + off);
+          bl[t][c] = *reinterpret_cast<const f16x8*>(a.Bl + off);
+        }
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < AQ; i++) {
+    const int idx = tid + i * SK_NT, r = idx % (MT * 16), kq = idx / (MT * 16);
+    if (kq < nq) {
+      const int k = 4 * kq;                          // k within the slice: tile k / 32, octet (k % 32) / 8, half k % 8 in {0, 4}
+      const int o = ((((r >> 4) * nch + (k >> 5)) * 4 + ((k & 31) >> 3)) * 16 + (r & 15)) * 8 + (k & 7);
+      uint2 hi, lo;
+      skh_split4(av4[i], hi, lo);
+      *reinterpret_cast<uint2*>(As_hi + o) = hi;
+      *reinterpret_cast<uint2*>(As_lo + o) = lo;
+    }
+  }
+  __syncthreads();
+  f32x4 acc[MT][4], acl[MT][4];                      // hi.hi, and hi.lo + lo.hi (scaled by 2^11)
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+    for (int c = 0; c < 4; c++) { acc[mt][c] = f32x4{0.f, 0.f, 0.f, 0.f}; acl[mt][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int t = 0; t < SKH_MAXCH; t++)
+    if (c0 + t < c1) {
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++) {
+        const int o = ((mt * nch + c0 + t) * 64 + lane) * 8;
+        const f16x8 ah = *reinterpret_cast<const f16x8*>(As_hi + o);
+        const f16x8 al = *reinterpret_cast<const f16x8*>(As_lo + o);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          acc[mt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[t][c], acc[mt][c], 0, 0, 0);
+          acl[mt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[t][c], acl[mt][c], 0, 0, 0);
+          acl[mt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[t][c], acl[mt][c], 0, 0, 0);
+        }
+      }
+    }
+  __syncthreads();                                   // the activations are consumed: the region takes the partial tiles
+  // red[wave][mt][i][col]: register v of lane l is row i = 4 (l / 16) + v, column 16 c + l % 16 of the strip
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+      for (int v = 0; v < 4; v++)
+        smem[((wave * MT + mt) * 16 + 4 * kg + v) * 64 + 16 * c + j] = acc[mt][c][v] + acl[mt][c][v] * SKH_LO_UNSCALE;
+  __syncthreads();
+  // ---- the block's plane: (row, column quad) items over the block's 512 threads, each sums the waves in order
+  const int n_live = a.st ? a.st[ST_N] : a.M;        // (rows past the live count are launched with whatever their buffers hold)
+  bool bad = false;
+#pragma unroll
+  for (int e0 = 0; e0 < MT * 256; e0 += SK_NT) {
+    const int e = e0 + tid, row = e >> 4, j4 = e & 15;
+    if (e < MT * 256 && row < a.M) {
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int w = 0; w < 8; w++) {
+        const float4 t = *reinterpret_cast<const float4*>(smem + ((w * MT * 16 + row) * 16 + j4) * 4);
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+      }
+      if (row < n_live)
+        bad |= !(fabsf(s.x) < 3.0e38f) || !(fabsf(s.y) < 3.0e38f) || !(fabsf(s.z) < 3.0e38f) || !(fabsf(s.w) < 3.0e38f);
+      *reinterpret_cast<float4*>(a.P + (int64_t)z * a.plane + (int64_t)row * a.N + n0 + 4 * j4) = s;
+    }
+  }
+  // range guard (an activation left fp16's range: inf / NaN): the host fails the decode call and switches the model to the
+  // exact-f32 kernel above (session.cpp: dec_split_check)
+  if (bad && a.range_flag) __hip_atomic_fetch_or(a.range_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// W [K][N] f32 -> hi, lo tiles [N / 16][K / 32][(k % 32) / 8][n % 16][k % 8]: one block per (16 columns, 32 K-rows) tile
+__global__ __launch_bounds__(256) void split_weight_f16_tiles_kernel(const float* __restrict__ W, int K, int N,
+                                                                     u16* __restrict__ hi, u16* __restrict__ lo) {
+  const int tn = blockIdx.x, tk = blockIdx.y;
+  for (int e = threadIdx.x; e < 512; e += 256) {
+    const int kk = e >> 4, jj = e & 15;              // reads: 16 consecutive columns of one K-row
+    const float x = W[(int64_t)(tk * 32 + kk) * N + tn * 16 + jj];
+    const _Float16 h = (_Float16)x;
+    const int64_t o = ((int64_t)tn * (K >> 5) + tk) * 512 + (((kk >> 3) * 16 + jj) * 8 + (kk & 7));
+    hi[o] = __builtin_bit_cast(u16, h);
+    lo[o] = __builtin_bit_cast(u16, (_Float16)((x - (float)h) * SKH_LO_SCALE));
+  }
+}
+
 }  // namespace
 
 // K-splits of the skinny GEMM: slices a block's 8 waves can share in multiples of 4 rows (K % (32 ks) == 0), at most
@@ -201,6 +360,15 @@ int launch_dec_skinny_gemm(hipStream_t st, const SkinnyArgs& a) {
   if (a.K / a.ksplit / 32 > sk_ldw((a.M + 15) / 16)) return -1;
   const int MT = (a.M + 15) / 16;
   const dim3 grid(a.N / 64, a.ksplit), block(SK_NT);
+  if (a.Bh && a.Bl) {                                // split-precision variant: same geometry, same planes
+    switch (MT) {
+      case 1: WB_KLAUNCH((dec_skinny_f16x3_kernel<1>), grid, block, 0, st, a); break;
+      case 2: WB_KLAUNCH((dec_skinny_f16x3_kernel<2>), grid, block, 0, st, a); break;
+      case 3: WB_KLAUNCH((dec_skinny_f16x3_kernel<3>), grid, block, 0, st, a); break;
+      default: WB_KLAUNCH((dec_skinny_f16x3_kernel<4>), grid, block, 0, st, a); break;
+    }
+    return 0;
+  }
   static const bool pair = []() { const char* e = getenv("WHISPER_HIP_SK_PAIR"); return e && e[0] == '1'; }();
 #define WB_SK(MT_)                                                                              \
   do {                                                                                          \
@@ -215,6 +383,10 @@ int launch_dec_skinny_gemm(hipStream_t st, const SkinnyArgs& a) {
   }
 #undef WB_SK
   return 0;
+}
+
+void launch_split_weight_f16_tiles(hipStream_t st, const float* W, int K, int N, uint16_t* hi, uint16_t* lo) {
+  hipLaunchKernelGGL(split_weight_f16_tiles_kernel, dim3(N / 16, K / 32), dim3(256), 0, st, W, K, N, hi, lo);
 }
 
 }  // namespace wb

@@ -12,6 +12,7 @@
 
 #include "wb_internal.h"
 #include "kernels.h"
+#include "decode.h"
 
 namespace wb { void session_pool_register(wb_model* m); }
 
@@ -412,6 +413,39 @@ int build_model(TensorMap& tm, int device, int compute_dtype, wb_model** out) {
       WB_HIP(hipGetLastError());
     }
     WB_HIP(hipDeviceSynchronize());
+  }
+  // ---- fp16 hi / lo TILES of the decoder-side Linear weights for the batch-mode skinny GEMM (decode_batch.hip,
+  // dec_skinny_f16x3_kernel: the decoder's weight stream on the 16-bit matrix path, f32-grade results).  The f32 copies stay:
+  // the <= 8-row kernels (fused sublayers, persistent decode) and the stateless decoder use them.
+  // WHISPER_HIP_DECODER_SPLIT=0 keeps the exact-f32 skinny kernel.
+  static const bool dec_split_enabled = []() { const char* e = getenv("WHISPER_HIP_DECODER_SPLIT"); return !(e && e[0] == '0'); }();
+  if (dec_split_enabled && compute_dtype == WB_F32) {
+    std::vector<LinearW*> ws;
+    const float* arena_dev = m->arena.as<float>();
+    for (int i = 0; i < D.n_text_layer; i++)
+      for (LinearW* l : {&m->dec[i].qkv, &m->dec[i].out, &m->dec[i].cq, &m->dec[i].cout, &m->dec[i].mlp1, &m->dec[i].mlp2}) {
+        if (l->k % 32 != 0 || l->n % 64 != 0) continue;
+        const float* hw = B.host.data() + (l->w - arena_dev);
+        bool ok = true;
+        for (size_t j = 0, n = (size_t)l->k * l->n; j < n && ok; j++) ok = std::fabs(hw[j]) < 65000.f;
+        if (ok) ws.push_back(l);
+      }
+    size_t total = 0;
+    for (LinearW* l : ws) total += (size_t)l->k * l->n;
+    if (total && ws.size() == (size_t)D.n_text_layer * 6) {            // all or nothing: one arithmetic per decode step
+      WB_HIP(hipHostMalloc((void**)&m->dec_flag_host, 64, hipHostMallocMapped));        // freed by ~wb_model
+      *m->dec_flag_host = 0;
+      WB_HIP(hipHostGetDevicePointer((void**)&m->dec_flag_dev, m->dec_flag_host, 0));
+      WB_TRY(m->arena_dec_split.alloc(total * 2 * 2));
+      uint16_t* p = m->arena_dec_split.as<uint16_t>();
+      for (LinearW* l : ws) {
+        const size_t n = (size_t)l->k * l->n;
+        l->th = p; l->tl = p + n; p += 2 * n;
+        launch_split_weight_f16_tiles(nullptr, l->w, l->k, l->n, l->th, l->tl);
+        WB_HIP(hipGetLastError());
+      }
+      WB_HIP(hipDeviceSynchronize());
+    }
   }
   *out = m.release();
   session_pool_register(*out);

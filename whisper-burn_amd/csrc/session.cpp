@@ -416,6 +416,23 @@ int wb_session_set_special_mask(wb_session* s, const uint8_t* is_special) {
 // ids, parents, lengths, the live-beam count, table parity) is read by the kernels from the step
 // state, so for a given (row bucket, k, mask, fuse) the launch sequence is identical every step and
 // can be captured once into a hipGraph and replayed.
+// Range guard of the split-precision decoder GEMM (decode_batch.hip): called wherever a decode has just synchronised with
+// the host.  The kernel raises the model's mapped flag word when a result is not finite (an activation outside fp16's
+// range, |x| >= 65504: attention outputs and GELU hidden units are the only GEMM inputs that are not LayerNorm outputs).
+// The call that observes it fails loudly, the model switches to the exact-f32 skinny kernel for good and this session's
+// captured step graphs are dropped, so the caller's retry decodes with f32 GEMMs.  (The flag is per model: a session may
+// observe a flag raised by another session's step -- its call then fails although its own rows were fine; conservative.)
+static int dec_split_check(wb_session* s) {
+  wb_model* m = s->m;
+  if (!m->dec_flag_host || __atomic_load_n(m->dec_flag_host, __ATOMIC_ACQUIRE) == 0) return WB_OK;
+  __atomic_store_n(m->dec_flag_host, 0, __ATOMIC_RELEASE);
+  __atomic_store_n(&m->dec_split_off, 1, __ATOMIC_RELEASE);
+  s->clear_graphs();
+  WB_REQUIRE(false, WB_ERR_STATE, "a decoder activation left fp16's range under the split-precision decode GEMM: this call's "
+             "rows are invalid; the model now uses the exact-f32 decoder GEMMs -- decode again");
+  return WB_OK;
+}
+
 static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool fuse_ln, int max_nb, bool timed,
                         bool chained = false, int eot = -1) {
   wb_model* m = s->m;
@@ -485,10 +502,12 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
     static const bool skinny_enabled = []() { const char* e = getenv("WHISPER_HIP_BATCH_SKINNY"); return !(e && e[0] == '0'); }();
     const bool skinny = skinny_enabled && n <= 64 && s->sk_qkv > 0 && s->sk_o > 0 &&
                         s->sk_1 > 0 && s->sk_2 > 0;
+    const bool dec_split = m->dec_split_active();
     auto thin = [&](const LinearW& w, int ks, const float* A, float* P) -> int {
       SkinnyArgs g;
       g.A = A; g.lda = w.k; g.B = w.w; g.ldb = w.n; g.M = n; g.N = w.n; g.K = w.k; g.ksplit = ks;
       g.P = P; g.plane = S * w.n;
+      if (dec_split && w.th && w.tl) { g.Bh = w.th; g.Bl = w.tl; g.range_flag = m->dec_flag_dev; g.st = dst; }   // 16-bit matrix path, f32-grade
       prof_tag(KC_B_GEMM, wsz * (double)w.k * w.n + 4.0 * n * ((double)w.k + (double)ks * w.n));
       WB_REQUIRE(launch_dec_skinny_gemm(st, g) == 0, WB_ERR_SHAPE, "skinny gemm: unsupported shape M=%d N=%d K=%d ks=%d", n,
                  w.n, w.k, ks);
@@ -1197,6 +1216,7 @@ int session_greedy_chain(wb_session* s, const int32_t* prompt, int eot, int max_
   WB_HIP(hipMemcpyAsync(toks.data(), s->gtok.p, toks.size() * 4, hipMemcpyDeviceToHost, st));
   WB_HIP(hipStreamSynchronize(st));
   tm.collect();
+  WB_TRY(dec_split_check(s));
   for (int w = 0; w < W; w++) {
     int len = ctl[GC_HDR + 2 * S + w];                 // prompt + generated (through EOT if it came)
     if (len < prompt_len) len = prompt_len;
@@ -1291,6 +1311,7 @@ int wb_session_step(wb_session* s, const int32_t* new_tokens, const int32_t* par
   WB_TRY(launch_step(s, n_launch, k, use_mask, fuse_ln, max_nb, graphs_enabled && !profiling, false, -1));
   tm_step.stop();
   WB_HIP(hipStreamSynchronize(st));   // results land in mapped host memory; state_host is reused by the next step
+  WB_TRY(dec_split_check(s));
   s->last_had_logits = 0;
   if (k > 0) {
     for (int i = 0; i < n; i++)

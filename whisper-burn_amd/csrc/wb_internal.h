@@ -88,6 +88,9 @@ struct LayerNormW { float* g = nullptr; float* b = nullptr; float eps = 1e-5f; }
 struct LinearW {
   float* w = nullptr; float* b = nullptr; int k = 0, n = 0;   // w: [k][n] row-major f32
   uint16_t* sh = nullptr; uint16_t* sl = nullptr;   // split-precision path: fp16 hi / lo * 2^11, [n][k] (encoder-side weights)
+  // decoder-side weights, batch-mode decode (decode_batch.hip, dec_skinny_f16x3_kernel): the same two pieces in MFMA tiles,
+  // [n / 16][k / 32][(k % 32) / 8][n % 16][k % 8] -- a wave's B operand of one (16-column, 32-deep) tile is 1 KB contiguous
+  uint16_t* th = nullptr; uint16_t* tl = nullptr;
 };
 
 struct EncBlockW {
@@ -142,7 +145,16 @@ struct wb_model {
   int* split_flag_host = nullptr; int* split_flag_dev = nullptr; int split_off = 0;
   std::mutex split_mu;
   bool split_active() const { return arena_split.p && !__atomic_load_n(&split_off, __ATOMIC_ACQUIRE); }
-  ~wb_model() { if (split_flag_host) (void)hipHostFree(split_flag_host); }
+  // decoder side (batch-mode skinny GEMM on fp16 hi / lo tiles): its own arena, flag word and off switch.  The flag is
+  // checked wherever a decode synchronises with the host (session.cpp: dec_split_check): a trip fails THAT call loudly and
+  // switches the model to the exact-f32 decoder GEMMs, so the caller's retry succeeds.
+  wb::DevMem arena_dec_split;
+  int* dec_flag_host = nullptr; int* dec_flag_dev = nullptr; int dec_split_off = 0;
+  bool dec_split_active() const { return arena_dec_split.p && !__atomic_load_n(&dec_split_off, __ATOMIC_ACQUIRE); }
+  ~wb_model() {
+    if (split_flag_host) (void)hipHostFree(split_flag_host);
+    if (dec_flag_host) (void)hipHostFree(dec_flag_host);
+  }
   // encoder
   wb::LinearW conv1;   // repacked [240 = ci*3+kk][d]
   wb::LinearW conv2;   // repacked [3d = kk*d+ci][d]

@@ -141,7 +141,7 @@ extern thread_local ThreadCtx* g_tc;   // the running fiber's coordinates
 void* dyn_shared();
 void syncthreads();
 enum Op { OP_WAVE_BARRIER = 1, OP_READFIRSTLANE, OP_READLANE, OP_DPP, OP_PERMLANE32_SWAP, OP_PERMLANE16_SWAP,
-          OP_MFMA_F32_32X32X2, OP_MFMA_BF16_32X32X16, OP_MFMA_F32_16X16X4, OP_SHFL, OP_SHFL_XOR, OP_BALLOT };
+          OP_MFMA_F32_32X32X2, OP_MFMA_BF16_32X32X16, OP_MFMA_F32_16X16X4, OP_MFMA_F16_16X16X32, OP_SHFL, OP_SHFL_XOR, OP_BALLOT };
 // hands the calling lane's operands to the wave and returns when the collective has been executed
 void wave_op(int op, const void* in0, const void* in1, const void* in2, void* out, int i0, int i1, int i2, int i3);
 void enqueue(hipStream_t st, std::function<void()> body, dim3 grid, dim3 block, size_t shmem, hipEvent_t e0, hipEvent_t e1,
@@ -292,6 +292,15 @@ static inline hipemu_f32x16 hipemu_mfma_f32_32x32x16_f16(hipemu_f16x8 a, hipemu_
   for (int i = 0; i < 16; i++) d[i] = co[i];
   return d;
 }
+static inline hipemu_f32x4 hipemu_mfma_f32_16x16x32_f16(hipemu_f16x8 a, hipemu_f16x8 b, hipemu_f32x4 c, int, int, int) {
+  float ai[8], bi[8], ci[4], co[4];
+  for (int i = 0; i < 8; i++) { ai[i] = (float)a[i]; bi[i] = (float)b[i]; }
+  for (int i = 0; i < 4; i++) ci[i] = c[i];
+  hipemu::wave_op(hipemu::OP_MFMA_F16_16X16X32, ai, bi, ci, co, 0, 0, 0, 0);
+  hipemu_f32x4 d;
+  for (int i = 0; i < 4; i++) d[i] = co[i];
+  return d;
+}
 static inline hipemu_f32x16 hipemu_mfma_f32_32x32x16_bf16(hipemu_bf16x8 a, hipemu_bf16x8 b, hipemu_f32x16 c, int, int, int) {
   float ai[8], bi[8], ci[16], co[16];
   for (int i = 0; i < 8; i++) { ai[i] = (float)a[i]; bi[i] = (float)b[i]; }
@@ -326,3 +335,4 @@ static inline unsigned long long __ballot(int pred) {
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_f32_16x16x4f32
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 hipemu_mfma_f32_32x32x16_bf16
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16 hipemu_mfma_f32_32x32x16_f16
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16 hipemu_mfma_f32_16x16x32_f16

@@ -277,6 +277,26 @@ static void run_collective(Fiber** lane, int n_lanes) {
         }
       }
     } break;
+    case OP_MFMA_F16_16X16X32: {
+      // v_mfma_f32_16x16x32_f16: A: lane l holds A[i = l % 16][k = 8 (l / 16) + t], t = 0..7; B: B[k = 8 (l / 16) + t][j = l % 16];
+      // D: register v of lane l is D[i = 4 (l / 16) + v][j = l % 16]
+      static float A[16][32], B[32][16];
+      for (int l = 0; l < 64; l++) {
+        if (!active[l]) die("MFMA with inactive lanes");
+        const float* a = (const float*)lane[l]->in0; const float* b = (const float*)lane[l]->in1;
+        for (int t = 0; t < 8; t++) { A[l & 15][8 * (l >> 4) + t] = a[t]; B[8 * (l >> 4) + t][l & 15] = b[t]; }
+      }
+      for (int l = 0; l < 64; l++) {
+        const float* c = (const float*)lane[l]->in2; float* d = (float*)lane[l]->out;
+        const int j = l & 15;
+        for (int v = 0; v < 4; v++) {
+          const int i = 4 * (l >> 4) + v;
+          float acc = c[v];
+          for (int k = 0; k < 32; k++) acc = fmaf(A[i][k], B[k][j], acc);
+          d[v] = acc;
+        }
+      }
+    } break;
     default: die("unknown wave collective");
   }
   for (int l = 0; l < n_lanes && l < 64; l++) if (lane[l]->state == AT_WAVE) lane[l]->state = RUNNABLE;
