@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 #include "kernels.h"
 
@@ -62,7 +64,18 @@ __device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& 
 #ifndef WB_F16X3_MIN_WAVES
 #define WB_F16X3_MIN_WAVES 2
 #endif
-template <int BM, int BN, int WGM, int WGN>
+#ifndef WB_F16X3_PF_SMALL
+#define WB_F16X3_PF_SMALL 4      // k-tiles in flight of the small-tile configurations (see gemm_f16x3_kernel)
+#endif
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+// PF: k-tiles requested ahead in registers.  The small-tile configurations serve the shapes with FEWER blocks than the chip has
+// CUs (tiny.en's 3-window encoder: 174 blocks of 64 x 64): one block per CU, nothing to overlap a tile's memory round trip
+// with, and a k-loop of 12 tiles cost 12 round trips (23 us per GEMM for 8 us of MFMA work).  They have registers to spare
+// (110 of 256), so they keep PF = 4 tiles in flight; the 128 x 128 configuration (246 VGPRs, two blocks per CU) keeps PF = 1.
+template <int BM, int BN, int WGM, int WGN, int PF>
 __global__ __launch_bounds__(NT, WB_F16X3_MIN_WAVES) void gemm_f16x3_kernel(GemmArgs g, const u16* __restrict__ Wh,
                                                                             const u16* __restrict__ Wl, int ldwt) {
   constexpr int TM = BM / WGM, TN = BN / WGN;
@@ -100,9 +113,10 @@ __global__ __launch_bounds__(NT, WB_F16X3_MIN_WAVES) void gemm_f16x3_kernel(Gemm
     }
   }
   // A stays f32 in registers until store_tile: converting here would wait for the load right behind its issue
-  float4 ra_lo[A_IT], ra_hi[A_IT];
-  uint4 rbh[B_IT], rbl[B_IT];
-  auto load_tile = [&](int k0) {
+  float4 ra_lo[PF][A_IT], ra_hi[PF][A_IT];
+  uint4 rbh[PF][B_IT], rbl[PF][B_IT];
+  auto load_tile = [&](auto slot_c, int k0) {
+    constexpr int sl = decltype(slot_c)::value;
 #pragma unroll
     for (int i = 0; i < A_IT; i++) {
       const int idx = tid + i * NT, k = k0 + (idx % (BK / 8)) * 8;
@@ -114,23 +128,24 @@ __global__ __launch_bounds__(NT, WB_F16X3_MIN_WAVES) void gemm_f16x3_kernel(Gemm
         lo = *reinterpret_cast<const float4*>(a_row[i] + k);
         hi = *reinterpret_cast<const float4*>(a_row[i] + k + 4);
       }
-      ra_lo[i] = lo; ra_hi[i] = hi;
+      ra_lo[sl][i] = lo; ra_hi[sl][i] = hi;
     }
 #pragma unroll
     for (int i = 0; i < B_IT; i++) {
       const int idx = tid + i * NT, r = idx / (BK / 8), k = k0 + (idx % (BK / 8)) * 8, n = n0 + r;
       const bool ok = r < BN && n < N;
-      rbh[i] = ok ? *reinterpret_cast<const uint4*>(Wh + (int64_t)n * ldwt + k) : make_uint4(0, 0, 0, 0);
-      rbl[i] = ok ? *reinterpret_cast<const uint4*>(Wl + (int64_t)n * ldwt + k) : make_uint4(0, 0, 0, 0);
+      rbh[sl][i] = ok ? *reinterpret_cast<const uint4*>(Wh + (int64_t)n * ldwt + k) : make_uint4(0, 0, 0, 0);
+      rbl[sl][i] = ok ? *reinterpret_cast<const uint4*>(Wl + (int64_t)n * ldwt + k) : make_uint4(0, 0, 0, 0);
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](auto slot_c, int buf) {
+    constexpr int sl = decltype(slot_c)::value;
 #pragma unroll
     for (int i = 0; i < A_IT; i++) {
       const int idx = tid + i * NT, r = idx / (BK / 8), ko = (idx % (BK / 8)) * 8;
       if (r < BM) {
         uint4 hi, lo;
-        split8(ra_lo[i], ra_hi[i], hi, lo);
+        split8(ra_lo[sl][i], ra_hi[sl][i], hi, lo);
         *reinterpret_cast<uint4*>(&Ah[buf][r][ko]) = hi;
         *reinterpret_cast<uint4*>(&Al[buf][r][ko]) = lo;
       }
@@ -139,8 +154,8 @@ __global__ __launch_bounds__(NT, WB_F16X3_MIN_WAVES) void gemm_f16x3_kernel(Gemm
     for (int i = 0; i < B_IT; i++) {
       const int idx = tid + i * NT, r = idx / (BK / 8), ko = (idx % (BK / 8)) * 8;
       if (r < BN) {
-        *reinterpret_cast<uint4*>(&Bh[buf][r][ko]) = rbh[i];
-        *reinterpret_cast<uint4*>(&Bl[buf][r][ko]) = rbl[i];
+        *reinterpret_cast<uint4*>(&Bh[buf][r][ko]) = rbh[sl][i];
+        *reinterpret_cast<uint4*>(&Bl[buf][r][ko]) = rbl[sl][i];
       }
     }
   };
@@ -154,14 +169,7 @@ __global__ __launch_bounds__(NT, WB_F16X3_MIN_WAVES) void gemm_f16x3_kernel(Gemm
       for (int r = 0; r < 16; r++) { acc[i][j][r] = 0.f; acl[i][j][r] = 0.f; }
 
   const int nk = max(0, kend - kbeg) / BK;
-  if (nk > 0) {
-    load_tile(kbeg);
-    store_tile(0);
-  }
-  __syncthreads();
-  for (int t = 0; t < nk; t++) {
-    const int buf = t & 1;
-    if (t + 1 < nk) load_tile(kbeg + (t + 1) * BK);
+  auto compute_tile = [&](int buf) {
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ks++) {
       f16x8 ah[RM], al[RM], bh[RN], bl[RN];
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(NT, WB_F16X3_MIN_WAVES) void gemm_f16x3_kernel(Gemm
         bl[j] = *reinterpret_cast<const f16x8*>(&Bl[buf][wn * TN + j * 32 + li][ks * 16 + lh * 8]);
       }
       // (issue order: a term-major order -- all hi.hi, then all hi.lo, then all lo.hi, no two consecutive MFMAs on one
-      // accumulator -- was measured in round 5 and changes nothing: large-v2 encoder 198.3 vs 198.3 ms, the loop is LDS-bound)
+      // accumulator -- was measured in round 5 and changes nothing: large-v2 encoder 198.3 vs 198.3 ms)
 #pragma unroll
       for (int i = 0; i < RM; i++)
 #pragma unroll
@@ -186,8 +194,46 @@ __global__ __launch_bounds__(NT, WB_F16X3_MIN_WAVES) void gemm_f16x3_kernel(Gemm
           acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acl[i][j], 0, 0, 0);
         }
     }
-    if (t + 1 < nk) store_tile(buf ^ 1);
+  };
+  using S0 = std::integral_constant<int, 0>;
+  if constexpr (PF == 1) {
+    if (nk > 0) {
+      load_tile(S0{}, kbeg);
+      store_tile(S0{}, 0);
+    }
     __syncthreads();
+    for (int t = 0; t < nk; t++) {
+      const int buf = t & 1;
+      if (t + 1 < nk) load_tile(S0{}, kbeg + (t + 1) * BK);
+      compute_tile(buf);
+      if (t + 1 < nk) store_tile(S0{}, buf ^ 1);
+      __syncthreads();
+    }
+  } else {
+    // tile j travels through register slot j % PF: tiles 0 .. PF - 1 are requested up front; a slot is refilled with tile
+    // j + PF right after tile j has gone to LDS (loads return in order: storing tile j waits for tile j only)
+    static_for<PF>([&](auto u) { if (decltype(u)::value < nk) load_tile(u, kbeg + decltype(u)::value * BK); });
+    if (nk > 0) {
+      store_tile(S0{}, 0);
+      if (PF < nk) load_tile(S0{}, kbeg + PF * BK);
+    }
+    __syncthreads();
+    for (int t0 = 0; t0 < nk; t0 += PF) {
+      static_for<PF>([&](auto u) {
+        constexpr int uu = decltype(u)::value;
+        const int t = t0 + uu;
+        if (t < nk) {                                // (block-uniform)
+          const int buf = t & 1;
+          compute_tile(buf);
+          if (t + 1 < nk) {
+            using SN = std::integral_constant<int, (uu + 1) % PF>;     // slot of tile t + 1 (t0 is a multiple of PF)
+            store_tile(SN{}, buf ^ 1);
+            if (t + 1 + PF < nk) load_tile(SN{}, kbeg + (t + 1 + PF) * BK);
+          }
+          __syncthreads();
+        }
+      });
+    }
   }
 
   // epilogue: batched residual / positional reads from clamped addresses, then arithmetic, then predicated stores
@@ -235,10 +281,10 @@ __global__ __launch_bounds__(NT, WB_F16X3_MIN_WAVES) void gemm_f16x3_kernel(Gemm
   if (bad && g.range_flag) __hip_atomic_fetch_or(g.range_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int PF>
 void launch_cfg(hipStream_t st, const GemmArgs& a, const u16* Wh, const u16* Wl, int ldwt) {
   dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.ksplit > 1 ? a.ksplit : 1);
-  WB_KLAUNCH((gemm_f16x3_kernel<BM, BN, WGM, WGN>), grid, dim3(NT), 0, st, a, Wh, Wl, ldwt);
+  WB_KLAUNCH((gemm_f16x3_kernel<BM, BN, WGM, WGN, PF>), grid, dim3(NT), 0, st, a, Wh, Wl, ldwt);
 }
 
 // W [K][N] f32 -> hi, lo [N][K] fp16 (K-contiguous), through a 32 x 32 LDS tile
@@ -273,9 +319,9 @@ int launch_gemm_f16x3(hipStream_t st, const GemmArgs& a, const uint16_t* Wh, con
   if (a.ksplit > 1 && (a.bias || a.residual || a.aux || a.act != ACT_NONE || a.col_scale_period > 0)) return -1;
   auto blocks = [&](int bm, int bn) { return (int64_t)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
   static const int force_tile = []() { const char* e = getenv("WHISPER_HIP_SPLIT_TILE"); return e ? atoi(e) : 0; }();   // developer A/B
-  if (a.M <= 32) launch_cfg<32, 128, 1, 4>(st, a, Wh, Wl, ldwt);
-  else if (force_tile == 64 || (force_tile != 128 && (a.ksplit > 1 || blocks(128, 128) < 384))) launch_cfg<64, 64, 2, 2>(st, a, Wh, Wl, ldwt);
-  else launch_cfg<128, 128, 2, 2>(st, a, Wh, Wl, ldwt);
+  if (a.M <= 32) launch_cfg<32, 128, 1, 4, WB_F16X3_PF_SMALL>(st, a, Wh, Wl, ldwt);
+  else if (force_tile == 64 || (force_tile != 128 && (a.ksplit > 1 || blocks(128, 128) < 384))) launch_cfg<64, 64, 2, 2, WB_F16X3_PF_SMALL>(st, a, Wh, Wl, ldwt);
+  else launch_cfg<128, 128, 2, 2, 1>(st, a, Wh, Wl, ldwt);
   return 0;
 }
 
