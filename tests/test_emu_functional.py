@@ -174,6 +174,14 @@ def test_batch_mode_skinny_gemm_and_fused_streaming_blocks(emu_lib, which, env):
     assert p.returncode == 0 and f"EMU_CHECK_OK {which}" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
+def test_decoder_split_range_guard_fails_loudly_and_falls_back(emu_lib):
+    """A decoder activation outside fp16's range under the split-precision skinny GEMM: the observing call returns
+    WB_ERR_STATE, the model switches to the exact-f32 kernel, the retry decodes the rows of an engine that never used the split
+    kernel (tests/emu_checks.py dec_split_range)."""
+    p = _run(emu_lib, "dec_split_range", {})
+    assert p.returncode == 0 and "EMU_CHECK_OK dec_split_range" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
 def test_production_key_ring_under_the_functional_model(emu_lib_prod):
     """The micro-model library compiles a 384-key ring so that small fixtures reach both of its code paths; the PRODUCT
     compiles 768 keys.  This runs the product's constant (`make prod`) at the real window lengths: C = 745 keys in one
