@@ -238,6 +238,25 @@ def main(which):
         got, _ = wb.waveform_to_tokens(eng, st, a, 16000, 3, 6)
         ref = otr.waveform_to_tokens(o, pu.ost(st), a, 16000, 3, 6)
         assert got == ref, (got, ref)
+    elif which == "beam16":
+        # 9 - 16 live rows on the FUSED sublayer path (round 5): 3 windows x beam 5 = 15 rows -- the reference's live setting on
+        # a 30 s chunk -- attention / cross-attention blocks per (head, row), the MLP block and the logits GEMV as two row
+        # groups of 8 (grid.y / grid.z); WHISPER_HIP_FUSE16=0 sends the same rows through batch mode.  d = 128 and d = 384.
+        a = synth.synth_audio(16000 * 31, 29)
+        got, wins = wb.waveform_to_tokens(eng, st, a, 16000, 5, 6)
+        ref, rw = otr.waveform_to_tokens(o, pu.ost(st), a, 16000, 5, 6, return_windows=True)
+        assert len(rw) == 3, len(rw)
+        assert wins == rw and got == ref, (wins, rw)
+        dims = synth.micro_dims(n_state=384, n_head=6, n_layer=1, n_vocab=2053, n_audio_ctx=400)
+        w2 = synth.synth_weights(dims, seed=61)
+        e2, o2 = wb.Whisper.from_tensors(w2), OracleWhisper(w2)
+        s2 = wb.SpecialTokens.for_vocab(2053)
+        a2 = synth.synth_audio(16000 * 9, 47)            # n_audio_ctx = 400: windows of 3.9 s -> 9 windows; decode 3 of them
+        p5 = wb.decode_params(s2, beam_size=5, max_depth=5)
+        _, w2rows = wb.waveform_to_tokens(e2, s2, a2, 16000, params=p5, win_begin=2, win_end=5)
+        _, r2rows = otr.waveform_to_tokens(o2, pu.ost(s2), a2, 16000, 5, 5, return_windows=True)
+        assert w2rows == r2rows[2:5], (w2rows, r2rows[2:5])
+        e2.close()
     elif which == "forward":
         a = synth.synth_audio(16000, 5)
         mel = np.concatenate([wb.prep_audio(a[None]), np.zeros((1, 80, 10), np.float32)], 2)

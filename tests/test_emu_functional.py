@@ -174,6 +174,15 @@ def test_batch_mode_skinny_gemm_and_fused_streaming_blocks(emu_lib, which, env):
     assert p.returncode == 0 and f"EMU_CHECK_OK {which}" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
+@pytest.mark.parametrize("env", [{}, {"WHISPER_HIP_FUSE16": "0"}], ids=["fused16", "batch"])
+def test_nine_to_sixteen_live_rows_on_the_fused_sublayer_path(emu_lib, env):
+    """beam 5 over three windows = 15 live rows (the reference's live setting on a 30 s chunk): the fused sublayer kernels with
+    the MLP block and the logits GEMV as two row groups of 8, and the same rows through batch mode; d = 128 and d = 384;
+    token-exact against the oracle's beam search (tests/emu_checks.py beam16)."""
+    p = _run(emu_lib, "beam16", env)
+    assert p.returncode == 0 and "EMU_CHECK_OK beam16" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
 def test_decoder_split_range_guard_fails_loudly_and_falls_back(emu_lib):
     """A decoder activation outside fp16's range under the split-precision skinny GEMM: the observing call returns
     WB_ERR_STATE, the model switches to the exact-f32 kernel, the retry decodes the rows of an engine that never used the split

@@ -40,7 +40,9 @@ SWITCHES = [{}, {"WHISPER_HIP_FUSE_X": "0"}, {"WHISPER_HIP_FUSE_SUB": "0"}, {"WH
             {"WHISPER_HIP_PERSIST_PREFILL": "0"},
             # batch-mode decode (the beam-5 leg: 15 live rows): the exact-f32 skinny weight-stream GEMM instead of the
             # split-precision fp16 one (decode_batch.hip: dec_skinny_f16x3_kernel, the default since round 5)
-            {"WHISPER_HIP_DECODER_SPLIT": "0"}]
+            {"WHISPER_HIP_DECODER_SPLIT": "0"},
+            # 9 - 16 live rows (beam 5 x 3 windows = 15): batch mode instead of the fused sublayer kernels with row groups
+            {"WHISPER_HIP_FUSE16": "0"}]
 
 
 _CACHE = {}

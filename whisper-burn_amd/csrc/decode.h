@@ -144,6 +144,9 @@ struct MlpFusedArgs {
   const float* W2 = nullptr;                                             // [4d][d]
   float* P = nullptr;                                                    // out: planes [4d / 64][S][d] (lin2 bias NOT added)
   unsigned long long* stamps = nullptr;                                  // developer probe (-DWB_STAMPS): phase clock of block 0
+  // row groups (9 - 16 live rows on the fused sublayer path): group g = blockIdx.y handles rows [8 g, 8 g + 8); the kernel
+  // wrapper sets row0 and shifts x_in / pend / x_out / P by row0 rows (plain planes only, not the record mode)
+  int row0 = 0;
   // persistent mode only: the same streams / planes as 8-byte {tag, value} granules (handoff.h)
   const void* g_x_in = nullptr; const void* g_pend = nullptr; void* g_x_out = nullptr; void* g_P = nullptr;
 };

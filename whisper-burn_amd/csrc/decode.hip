@@ -237,14 +237,17 @@ __global__ __launch_bounds__(256, (MR >= 8 && DPL >= 16) ? 1 : 2) void dec_gemv_
                              // scalar state load must not sit in front of the weight stream)
 
   {
-    constexpr int r0 = 0;     // the host picks MR >= the live row count: one pass over the rows
+    // the host picks MR >= the live row count (one pass over the rows), or -- 9 - 16 live rows on the fused sublayer path --
+    // row groups of MR in grid.z: group g stages and multiplies rows [g MR, g MR + MR)
+    const int r0 = blockIdx.z * MR;
+    if (r0 >= n_rows) return;
     // ---- prologue: stage in[0..MR)[k0..k0+kn) ----
     if constexpr (LN) {
       const int d = a.K;      // a multiple of 64 (session_reserve): lane + 64 i < d is wave-uniform
       const bool writer = (blockIdx.x == 0 && blockIdx.y == 0);
 #pragma unroll 1
       for (int r = wave; r < MR; r += 4) {
-        const int row = r;
+        const int row = r0 + r;
         if (row >= n_rows) {   // padding row (wave-uniform)
           for (int c = lane; c < kn; c += 64) xbuf[r * XLD + c] = 0.f;
           continue;
@@ -1328,7 +1331,7 @@ static void launch_gemv_dpl(hipStream_t st, dim3 grid, const GemvArgs& a) {
 
 void launch_dec_gemv(hipStream_t st, const GemvArgs& a, int n_rows_hint, bool stats) {
   const int ct = a.ct > 0 ? a.ct : (stats ? GV_CT_LOGITS : GV_CT);
-  dim3 grid((a.N + ct - 1) / ct, a.KS);
+  dim3 grid((a.N + ct - 1) / ct, a.KS, n_rows_hint > 8 ? (n_rows_hint + 7) / 8 : 1);   // (z: row groups of 8)
   const bool ln = a.pro == PRO_LN;
   if (stats) {   // logits: LN prologue over whole rows + tile statistics; rows chunked by <= 8
     if (n_rows_hint <= 4) launch_gemv_dpl<4, DMAX, true, true>(st, grid, a);

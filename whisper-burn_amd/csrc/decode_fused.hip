@@ -27,6 +27,12 @@ using namespace fused;
 // one launch per sublayer: grid = the roles of that sublayer, the step state comes from a.st
 template <int MR, int DPL, bool REC>
 __global__ __launch_bounds__(512) void dec_mlp_fused_kernel(MlpFusedArgs a) {
+  if (blockIdx.y > 0) {                            // row group g: rows [g MR, g MR + MR) (9 - 16 live rows; plain planes only)
+    const int r0 = blockIdx.y * MR;
+    const int64_t sh = (int64_t)r0 * a.d;
+    a.row0 = r0; a.x_in += sh; a.x_out += sh; a.P += sh;
+    if (a.pend) a.pend += sh;
+  }
   dec_mlp_body<MR, DPL, REC, false>(a, blockIdx.x, PsStep());
 }
 // grid = (8, rows): workgroups go round-robin over the 8 XCDs by linear id, so x = head puts every beam's block of
@@ -46,7 +52,8 @@ bool dec_fused_supported(int d) { return d == 128 || d == 384 || d == 512; }
 int dec_mlp_fused_planes(int d) { return 4 * d / 64; }
 
 void launch_dec_mlp_fused(hipStream_t st, const MlpFusedArgs& a, int n_rows_hint) {
-  const dim3 grid(4 * a.d / 64), block(512);
+  // more than 8 rows: row groups of 8 in grid.y (the caller guarantees plain planes: n_chunks == 0)
+  const dim3 grid(4 * a.d / 64, n_rows_hint > 8 ? (n_rows_hint + 7) / 8 : 1), block(512);
 #define WB_MLP(MR_, DPL_)                                                                          \
   do {                                                                                             \
     if (a.n_chunks > 0) WB_KLAUNCH((dec_mlp_fused_kernel<MR_, DPL_, true>), grid, block, 0, st, a); \

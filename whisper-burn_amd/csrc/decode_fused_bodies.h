@@ -439,8 +439,8 @@ __device__ __forceinline__ bool dec_mlp_body(const MlpFusedArgs& a, const int jb
     }
   }
   int n_rows;
-  if constexpr (PS) n_rows = ps.n_rows; else n_rows = a.st[ST_N];
-  if (n_rows == 0) return true;                    // chained decode, every window finished (block-uniform)
+  if constexpr (PS) n_rows = ps.n_rows; else n_rows = min(MR, a.st[ST_N] - a.row0);   // (row group: rows [row0, row0 + MR))
+  if (n_rows <= 0) return true;                    // chained decode, every window finished / an empty row group (block-uniform)
   WB_STAMP(1);
   __syncthreads();
   if constexpr (PS) { if (!ps_sweeps_ok(ps)) return false; }

@@ -1299,9 +1299,19 @@ int wb_session_step(wb_session* s, const int32_t* new_tokens, const int32_t* par
     hs[L.win_slots + window[i] * MAX_BEAMS + nb] = i;
     nb++;
   }
-  // launch shape: bucketed so that the same captured graph serves every step of a decode
-  const int n_launch = n <= 4 ? std::min(4, S) : n <= 8 ? std::min(8, S) : S;
-  const bool fuse_ln = n_launch <= 8;             // LayerNorm in the GEMV prologue (redundant per block) vs its own launch
+  // launch shape: bucketed so that the same captured graph serves every step of a decode.  9 - 16 live rows (the reference's
+  // live setting: beam 5 over a 30 s chunk = 15 rows, transcribe.rs:232-233) stay on the fused sublayer kernels where those
+  // exist (d <= 512): the attention / cross-attention blocks are per (head, row) anyway, the MLP block and the logits GEMV
+  // run their 8-row tiles as two row groups -- 16 launches per step instead of batch mode's 54 (WHISPER_HIP_FUSE16=0: batch mode)
+  static const bool fuse16_enabled = []() {
+    const char* e = getenv("WHISPER_HIP_FUSE16"); const char* f = getenv("WHISPER_HIP_FUSE_SUB"); const char* x = getenv("WHISPER_HIP_FUSE_X");
+    const char* c = getenv("WHISPER_HIP_FUSE_CO");
+    return !(e && e[0] == '0') && !(f && f[0] == '0') && !(x && x[0] == '0') && !(c && c[0] == '1');
+  }();
+  const bool g16 = fuse16_enabled && n > 8 && n <= 16 && S >= 9 && dec_fused_supported(D.n_text_state) &&
+                   D.n_text_state == 64 * D.n_text_head && s->maxC <= CROSS_FUSED_MAX_PASSES * CROSS_FUSED_MAX_C;
+  const int n_launch = n <= 4 ? std::min(4, S) : n <= 8 ? std::min(8, S) : g16 ? std::min(16, S) : S;
+  const bool fuse_ln = n_launch <= 8 || g16;      // LayerNorm in the GEMV prologue (redundant per block) vs its own launch
   const int max_nb = s->max_beams <= 1 ? 1 : s->max_beams <= 2 ? 2 : s->max_beams <= 4 ? 4 : 8;
   const int use_mask = apply_special_mask ? 1 : 0;
   hipStream_t st = s->st;
