@@ -1333,6 +1333,15 @@ void launch_dec_gemv(hipStream_t st, const GemvArgs& a, int n_rows_hint, bool st
   const int ct = a.ct > 0 ? a.ct : (stats ? GV_CT_LOGITS : GV_CT);
   dim3 grid((a.N + ct - 1) / ct, a.KS, n_rows_hint > 8 ? (n_rows_hint + 7) / 8 : 1);   // (z: row groups of 8)
   const bool ln = a.pro == PRO_LN;
+  static const bool mr16_enabled = []() { const char* e = getenv("WHISPER_HIP_LOGITS_MR16"); return !(e && e[0] == '0'); }();
+  if (stats && n_rows_hint > 8 && n_rows_hint <= 16 && a.K <= 512 && mr16_enabled) {
+    // 9 - 16 live rows on the fused sublayer path (d <= 512): ONE 16-row pass -- two row groups of 8 stream E^T twice
+    // (52.7 us per step for tiny.en's 80 MB against 18 us at <= 8 rows: profiles/r05_d_beam5_fused16.txt)
+    grid.z = 1;
+    if (a.K <= 384) launch_gemv_k(dec_gemv_kernel<16, 512, 6, true, true, GV_CT_LOGITS>, st, grid, a);
+    else launch_gemv_k(dec_gemv_kernel<16, 512, 8, true, true, GV_CT_LOGITS>, st, grid, a);
+    return;
+  }
   if (stats) {   // logits: LN prologue over whole rows + tile statistics; rows chunked by <= 8
     if (n_rows_hint <= 4) launch_gemv_dpl<4, DMAX, true, true>(st, grid, a);
     else launch_gemv_dpl<8, DMAX, true, true>(st, grid, a);
