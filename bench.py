@@ -538,13 +538,13 @@ def main() -> None:
             lpmc = json.load(open(lcands[-1])) if lcands and args.large_v2_seconds == 450.0 else {}
 
             def lpmc_bytes(cls_name):
-                want = {"batch: split-K MFMA GEMM": "dec_skinny_gemm_kernel", "batch: dec_resolve_ln": "dec_resolve_ln_kernel",
-                        "batch: dec_self_attn": "dec_self_attn_kernel", "batch: dec_cross_attn_stream": "dec_cross_attn_stream_kernel",
-                        "batch: dec_gelu_fold": "dec_gelu_fold_kernel", "batch: dec_topk_rows": "dec_topk_rows_kernel",
-                        "batch: dec_layer": "dec_layer_kernel"}
-                for key, frag in want.items():
+                want = {"batch: split-K MFMA GEMM": ("dec_skinny_f16x3_kernel", "dec_skinny_gemm_kernel"),
+                        "batch: dec_resolve_ln": ("dec_resolve_ln_kernel",), "batch: dec_self_attn": ("dec_self_attn_kernel",),
+                        "batch: dec_cross_attn_stream": ("dec_cross_attn_stream_kernel",),
+                        "batch: dec_gelu_fold": ("dec_gelu_fold_kernel",), "batch: dec_topk_rows": ("dec_topk_rows_kernel",)}
+                for key, frags in want.items():
                     if cls_name.startswith(key):
-                        vals = [v for n, v in lpmc.items() if frag in n]
+                        vals = [v for n, v in lpmc.items() if any(f in n for f in frags)]
                         # (several template instances share a class: launches differ in size, take the launch-weighted mean
                         # when the file carries it, else the largest)
                         return int(max(vals)) if vals else None
