@@ -319,6 +319,9 @@ int launch_gemm_f16x3(hipStream_t st, const GemmArgs& a, const uint16_t* Wh, con
   if (a.ksplit > 1 && (a.bias || a.residual || a.aux || a.act != ACT_NONE || a.col_scale_period > 0)) return -1;
   auto blocks = [&](int bm, int bn) { return (int64_t)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
   static const int force_tile = []() { const char* e = getenv("WHISPER_HIP_SPLIT_TILE"); return e ? atoi(e) : 0; }();   // developer A/B
+  // (measured in round 5 and not kept: 128 x 64 tiles with three / four k-tiles in flight -- half the accumulators buy the
+  // registers for a deeper queue -- large-v2 encoder 226 / 225 ms against 195.6 for 128 x 128 with one: the large shapes are not
+  // bound by bytes in flight; the extra operand traffic and A-split work per flop cost more: profiles/r05_i_k12_tiles.txt)
   if (a.M <= 32) launch_cfg<32, 128, 1, 4, WB_F16X3_PF_SMALL>(st, a, Wh, Wl, ldwt);
   else if (force_tile == 64 || (force_tile != 128 && (a.ksplit > 1 || blocks(128, 128) < 384))) launch_cfg<64, 64, 2, 2, WB_F16X3_PF_SMALL>(st, a, Wh, Wl, ldwt);
   else launch_cfg<128, 128, 2, 2, 1>(st, a, Wh, Wl, ldwt);
