@@ -500,6 +500,7 @@ def main() -> None:
         # -- which one fixed warm-up step does not outlast.  Untimed steps run until two consecutive ones agree within 3 %
         # with the fastest seen so far, at most 60 s; every warm-up step's time is listed next to the timed ones.
         l_steps, l_warm, l_warm_s = 5, 0, []
+        warm_cap_s = float(os.environ.get("WHISPER_BENCH_LARGE_WARMUP_S", "60"))     # (tools/bench_dry_run.py: 0 = one warm-up step)
         tw0 = time.perf_counter()
         while True:
             t1 = time.perf_counter()
@@ -508,7 +509,7 @@ def main() -> None:
             l_warm_s.append(time.perf_counter() - t1)
             l_warm += 1
             settled = l_warm >= 3 and max(l_warm_s[-2:]) <= 1.03 * min(l_warm_s)
-            stop = 1.0 if (settled or time.perf_counter() - tw0 > 60.0 or l_warm >= 64) else 0.0
+            stop = 1.0 if (settled or time.perf_counter() - tw0 > warm_cap_s or l_warm >= 64) else 0.0
             if world > 1:                                   # every rank leaves the warm-up together
                 tflag = torch.tensor([stop], dtype=torch.float64, device=dev)
                 dist.all_reduce(tflag, op=dist.ReduceOp.MIN)

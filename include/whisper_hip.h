@@ -212,7 +212,11 @@ int wb_session_set_special_mask(wb_session* s, const uint8_t* is_special);
  * that occupied slot parent[i] in the previous step (-1: a fresh, empty beam) of window
  * window[i], and appends new_tokens[i].  If k > 0 the k best continuations of each beam
  * by (log-prob descending, token id ascending) are returned: log_softmax over the
- * (optionally special-masked, transcribe.rs:271-275) logits of the last position. */
+ * (optionally special-masked, transcribe.rs:271-275) logits of the last position.
+ * WB_ERR_STATE with "... left fp16's range ..." in wb_last_error(): with more than 8 live rows (16 at d <= 512) the decoder's
+ * Linear layers run on fp16 hi / lo weight pieces (f32-grade results); an activation of |x| >= 65504 there makes this
+ * step's rows invalid.  The call says so, the model switches to the exact-f32 kernels for good, and decoding again
+ * (a new session, or wb_waveform_to_tokens again) succeeds.  Whisper's decoder activations are O(10): a backstop. */
 int wb_session_step(wb_session* s, const int32_t* new_tokens, const int32_t* parent,
                     const int32_t* window, int n, int apply_special_mask, int k, int32_t* top_ids,
                     float* top_logprobs);

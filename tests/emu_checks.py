@@ -197,32 +197,30 @@ def main(which):
             w2 = dict(w)
             w2["decoder/block_0/mlp/mlp1/bias"] = np.asarray(w["decoder/block_0/mlp/mlp1/bias"], np.float32) + np.float32(1.0e5)
             e0 = wb.Whisper.from_tensors(w2)
-            a = synth.synth_audio(16000 * 100, 33)
-            _, wins0 = wb.waveform_to_tokens(e0, st, a, 16000, 4, 3)
+            a = synth.synth_audio(16000 * 31, 33)
+            _, wins0 = wb.waveform_to_tokens(e0, st, a, 16000, 6, 2)
             e0.close()
             print("ROWS " + repr(wins0))
         else:
             w2 = dict(w)
             w2["decoder/block_0/mlp/mlp1/bias"] = np.asarray(w["decoder/block_0/mlp/mlp1/bias"], np.float32) + np.float32(1.0e5)
             e2 = wb.Whisper.from_tensors(w2)
-            a = synth.synth_audio(16000 * 100, 33)           # 9 windows x 4 beams: batch mode, skinny GEMM
+            a = synth.synth_audio(16000 * 31, 33)            # 3 windows x 6 beams = 18 live rows: batch mode, skinny GEMM
             failed = False
             try:
-                wb.waveform_to_tokens(e2, st, a, 16000, 4, 3)
+                wb.waveform_to_tokens(e2, st, a, 16000, 6, 2)
             except Exception as ex:                           # the binding raises on a negative status
                 failed = "fp16" in str(ex) and "decode again" in str(ex)
                 assert failed, str(ex)
             assert failed, "the range guard of the split-precision decoder GEMM did not trip"
-            _, wins2 = wb.waveform_to_tokens(e2, st, a, 16000, 4, 3)      # the retry: exact-f32 decoder GEMMs
+            _, wins2 = wb.waveform_to_tokens(e2, st, a, 16000, 6, 2)      # the retry: exact-f32 decoder GEMMs
             e2.close()
             env = dict(os.environ); env["WHISPER_HIP_DECODER_SPLIT"] = "0"
             p = subprocess.run([sys.executable, os.path.abspath(__file__), "dec_split_range"], env=env, capture_output=True, text=True)
             assert p.returncode == 0, p.stderr[-2000:]
             ref = eval([l for l in p.stdout.splitlines() if l.startswith("ROWS ")][-1][5:])
             assert wins2 == ref, (wins2, ref)
-            # an ordinary model is untouched by the guard
-            _, w3 = wb.waveform_to_tokens(eng, st, a, 16000, 4, 3)
-            assert len(w3) == 9
+            assert len(wins2) == 3
     elif which == "beam_batch":
         # batch mode with MORE than 32 live rows: 9 windows x 4 beams = 36 rows -> three 16-row tiles of the skinny
         # weight-stream GEMM (decode_batch.hip: v_mfma_f32_16x16x4_f32, split-K planes; with three or four tiles a thread

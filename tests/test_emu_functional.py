@@ -90,6 +90,8 @@ _PLAN = {
     "test_sanitizer_and_reversed_schedule": lambda p: [(p["which"], {"HIPEMU_GUARD": "1", "HIPEMU_SEGV_TRACE": "1",
                                                                      "HIPEMU_ORDER": "reverse"})],
     "test_outputs_are_bitwise_independent_of_the_schedule": lambda p: [("bitwise", {}), ("bitwise", {"HIPEMU_ORDER": "reverse"})],
+    "test_nine_to_sixteen_live_rows_on_the_fused_sublayer_path": lambda p: [("beam16", p["env"])],
+    "test_decoder_split_range_guard_fails_loudly_and_falls_back": lambda p: [("dec_split_range", {})],
 }
 
 

@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 PKG = os.path.join(ROOT, "whisper-burn_amd")
 os.environ.setdefault("WHISPER_HIP_LIB", os.path.join(PKG, "lib", "libwhisper_hip_emu.so"))
 os.environ["WHISPER_HIP_ALLOW_EMU"] = "1"
+os.environ.setdefault("WHISPER_BENCH_LARGE_WARMUP_S", "0")     # the large-v2 leg's settled warm-up: one step under the emulator
 sys.path[:0] = [ROOT, PKG]
 
 import torch  # noqa: E402
