@@ -304,7 +304,11 @@ int wb_shard_partition(int64_t n_windows, int rank, int world, int64_t* lo, int6
 /* waveform_to_text (transcribe.rs:23-74) without the tokenizer, sharded: this rank decodes its block of windows of the
  * WHOLE waveform `pcm` (host memory, or device memory of the model's GPU when pcm_on_device != 0), all-gathers the
  * rows and stitches.  On return EVERY rank holds all K per-window rows (win_tokens [K][row_stride], win_lens [K],
- * K <= win_cap) and the stitched stream.  world == 1 needs no all-gather (allgather may be NULL). */
+ * K <= win_cap) and the stitched stream.  world == 1 needs no all-gather (allgather may be NULL).
+ * Failure: a rank whose local decode fails (out of memory, a HIP error) STILL enters the all-gather -- its rows carry a
+ * sentinel -- so no rank is left blocked in the collective; every rank then returns an error (the failing rank its own
+ * status, the others WB_ERR_STATE naming the rank).  Argument errors are reported before the collective on the rank that
+ * has them: validate identically on every rank. */
 int wb_waveform_to_tokens_sharded(wb_model* m, const float* pcm, int pcm_on_device, int64_t n, int sample_rate,
                                   const wb_decode_params* p, const uint8_t* is_special, int rank, int world,
                                   wb_allgather_fn allgather, void* user, int32_t* win_tokens, int32_t row_stride,
