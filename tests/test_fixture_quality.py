@@ -83,3 +83,42 @@ def test_bench_workload_literal_oracle_matches_golden():
     assert wins == rows_of("tiny_bench")
     g = np.load(GOLD)
     assert toks == g["tiny_bench_stitched"].tolist()
+
+
+def test_deep_fixtures_are_well_conditioned():
+    """Round 5's depth normalisation (synth.synth_weights): at `small` (12 + 12 layers, full 14.9 s window) the f32 oracle sits
+    within 2e-4 of the f64 evaluation of the same operators over a 40-token top-5 walk (measured 4e-5 - 8e-5; before the
+    normalisation 7.8e-4, and 2e-2 at large-v2, where two correct f32 evaluations could not be held to the north star's 1e-3).
+    This is the property that lets the GPU tests assert |hip - oracle_f32| <= 1e-3 outright at every size; large-v2 itself is
+    too heavy for the CPU suite (its walk is recorded in LABLOG R5.1: 1.3e-5 over 101 rows)."""
+    import torch
+    from oracle import mel as omel
+    from oracle.model import log_softmax
+    from whisper_burn_amd import synth
+    w = synth.synth_preset("small", eot_beta=0.0)
+    o32, o64 = OracleWhisper(w), OracleWhisper(w, dtype=torch.float64)
+    st = SpecialTokens.for_vocab(o32.dims.n_vocab)
+    audio = synth.synth_audio(160 * 1490 + 100, 1240)
+    mel = omel.prep_audio(torch.from_numpy(audio[:160 * 1490])[None], 16000.0)
+    mel = torch.cat([mel, torch.zeros(1, 80, 10)], 2)
+    xa32, xa64 = o32.forward_encoder(mel), o64.forward_encoder(mel)
+    assert float((xa32.double() - xa64).abs().max()) < 5e-5
+    maskv = torch.tensor(np.where(np.asarray(st.is_special).astype(bool), -np.inf, 0.0))
+    seq = [st.start_of_transcript, st.language, st.transcribe, st.no_timestamps]
+    rng = np.random.default_rng(5)
+    L = 44
+    while len(seq) < L:
+        lg = o32.forward_decoder(torch.tensor([seq]), xa32)[0, -1].double()
+        if len(seq) <= 5:
+            lg = lg + maskv
+        seq.append(int(torch.topk(lg, 5).indices[int(rng.integers(0, 5))]))
+    toks = torch.tensor([seq])
+    l32, l64 = o32.forward_decoder(toks, xa32)[0], o64.forward_decoder(toks, xa64)[0]
+    worst = 0.0
+    for p in range(3, L):
+        m = maskv if p + 1 <= 5 else 0.0
+        a, b = log_softmax(l32[p].double() + m, 0), log_softmax(l64[p] + m, 0)
+        fin = torch.isfinite(b)
+        worst = max(worst, float((a[fin] - b[fin]).abs().max()))
+    assert worst <= 2e-4, worst
+    assert len(set(seq[4:])) >= (L - 4) // 2          # ... and the walk is not a fixed point
