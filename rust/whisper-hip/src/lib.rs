@@ -171,6 +171,10 @@ pub enum SpecialToken<L> {
 
 /// transcribe.rs:23-29, same argument order and result: `(text, tokens)`; tokens include each window's prompt and
 /// EOT exactly as the reference's stitch leaves them (transcribe.rs:56-63).
+///
+/// One error is worth a retry: `WB_ERR_STATE` whose message says a decoder activation "left fp16's range" (the
+/// split-precision decoder GEMM's range guard, include/whisper_hip.h at `wb_session_step`).  The library has by then
+/// switched this model to its exact-f32 decoder kernels, so calling again succeeds.
 pub fn waveform_to_text<T: Tokenizer>(whisper: &Whisper, bpe: &T, lang: T::Lang, waveform: Vec<f32>,
                                       sample_rate: usize) -> Result<(String, Vec<usize>)> {
     let mut p = ffi::wb_decode_params::default();
