@@ -128,6 +128,35 @@ def run_cpu_baseline(weights, st, audio, sr, wlen, beam, depth, geometry, model_
             "host_cpus": os.cpu_count()}
 
 
+GOLDEN_NPZ = os.path.join(ROOT, "tests", "golden", "oracle_outputs.npz")
+
+
+def check_against_golden(rows, name, world, select=None):
+    """Compare a leg's per-window token rows with the committed oracle rows of parity workload `name`
+    (tests/golden/oracle_outputs.npz: frozen outputs of the oracle's LITERAL decode loop from raw PCM, tests/workloads.py;
+    data, not oracle code -- nothing under oracle/ is imported here).  Runs OUTSIDE every timed region.  `select`: the window
+    indices the golden holds (None = all).  A mismatch raises: a fast run that decodes other tokens is not a result.
+    The goldens are rows of the 1-GPU audio (synth_audio is not prefix-stable, so the N-GPU clip is another signal): at
+    N > 1 the leg reports tokens_checked = null."""
+    if world != 1:
+        return {"tokens_checked": None, "why": "golden rows exist for the 1-GPU clip only (tests/workloads.py)"}
+    g = np.load(GOLDEN_NPZ)
+    toks, lens = g[f"{name}_tokens"], g[f"{name}_lens"]
+    want = [toks[i, :lens[i]].tolist() for i in range(len(lens))]
+    sel = list(range(len(rows))) if select is None else list(select)
+    assert len(sel) == len(want), (name, len(sel), len(want))
+    n_tok = 0
+    for wi, ref in zip(sel, want):
+        got = [int(t) for t in rows[wi]]
+        if got != ref:
+            bad = next((j for j, (a, b) in enumerate(zip(got, ref)) if a != b), min(len(got), len(ref)))
+            raise SystemExit(f"bench.py: leg `{name}` window {wi} differs from the oracle's committed row at position {bad} "
+                             f"(got {got[bad:bad + 4]}, oracle {ref[bad:bad + 4]}): not reporting a figure for wrong tokens")
+        n_tok += len(ref)
+    return {"tokens_checked": True, "golden": f"tests/golden/oracle_outputs.npz:{name}", "windows_compared": sel,
+            "tokens_compared": n_tok}
+
+
 def kernel_table(kstats, pmc_bytes=lambda name: None):
     """Per-kernel-class rows of the profiled passes (attached HIP events per launch + algorithmic bytes): sorted by total
     time; the first row is the dominant kernel."""
@@ -291,6 +320,17 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # what the process group actually looks like (so the driver's first SCALE line is self-checking): world size as
+    # torch.distributed reports it, and every rank's device
+    if world > 1:
+        mine = torch.tensor([rank, local_rank, torch.cuda.current_device()], dtype=torch.int64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        ranks_observed = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                          "rank_local_rank_device": [[int(x) for x in t.tolist()] for t in allr]}
+    else:
+        ranks_observed = {"backend": None, "world_size": 1, "rank_local_rank_device": [[0, local_rank, torch.cuda.current_device()]]}
+
     # ---- the same step from HOST PCM (SURVEY 8d words the metric "PCM in host memory -> token ids on host"): the contract's
     # `value` is measured with the inputs resident in HBM; this leg hands the library the host buffer and lets it upload the
     # rank's span inside the timed region, so the PCIe-inclusive figure stands next to it
@@ -367,7 +407,7 @@ def main() -> None:
         stages = {"mel_ms_per_step": round(mel_ms / n_prof, 4), "encoder_ms_per_step": round(enc_ms / n_prof, 4),
                   "cross_kv_ms_per_step": round(ckv_ms / n_prof, 4), "decode_ms_per_step": round(dec_ms / n_prof, 4),
                   "decode_steps_per_step": n_steps / n_prof,
-                  "decode_kernels_per_token": round(sum(k["calls"] for k in kstats) / max(n_steps, 1), 2),
+                  "decode_launches_per_step": round(sum(k["calls"] for k in kstats) / n_prof, 2),
                   "mel_frames_per_s": round(n_frames_local / (mel_ms / n_prof * 1e-3), 1) if mel_ms > 0 else None,
                   "mel_GBps_algorithmic": round(960.0 * n_frames_local / (mel_ms / n_prof * 1e-3) / 1e9, 2) if mel_ms > 0 else None}
 
@@ -448,6 +488,9 @@ def main() -> None:
                        "launches": int(sum(k["calls"] for k in bkstats))}
         beng.close()
         if rank == 0:
+            standard = args.model in ("tiny.en", "tiny_en") and args.seconds == 30.0 and args.max_depth == 100 and args.geometry == "reference"
+            bcheck = check_against_golden(brows, "tiny_beam5", world) if standard else \
+                {"tokens_checked": None, "why": "no committed golden for this non-default workload"}
             beam5 = {"metric": "real-time factor (audio-sec/wall-sec)",
                      "value": round(args.seconds * world * b_steps / bdt, 2), "unit": "x real-time", "n_gpus": world,
                      "steps": b_steps, "warmup": b_warm, "ms_per_step": round(bdt / b_steps * 1e3, 3), "dtype": args.dtype,
@@ -455,7 +498,7 @@ def main() -> None:
                                             f"tiny_beam5), {args.seconds:g} s of 16 kHz audio per GPU per step, reference windowing "
                                             f"({n_win} windows), beam_size 5, max_depth {args.max_depth} (the reference's live "
                                             f"setting, transcribe.rs:232-233)",
-                                "tokens_out": len(btok),
+                                "tokens_out": len(btok), **bcheck,
                                 "generated_tokens_per_window": [max(0, len(r) - 4) for r in brows],
                                 "stages_profiled_pass": bstages, "kernels": bkern,
                                 "path": "host-driven beam search (beam.rs restated in C++) over KV-cached session steps: fused "
@@ -560,6 +603,9 @@ def main() -> None:
                                   leng.max_mel_frames() - lparams.padding, gen_lens=lgen, encoder_peak=lenc_peak)
             lwork = lrl.pop("_work")
             l_step_ms = ldt / l_steps * 1e3
+            lcheck = check_against_golden(lrows, "large_leg", world, select=(0, ln_win - 1)) \
+                if args.large_v2_seconds == 450.0 and args.max_depth == 100 and args.geometry == "reference" else \
+                {"tokens_checked": None, "why": "no committed golden for this non-default workload"}
             l_dec_untraced = l_step_ms - l_enc_ms - l_ckv_ms - lbuf[0]
             large_v2 = {"metric": "real-time factor (audio-sec/wall-sec)",
                         "value": round(args.large_v2_seconds * world * l_steps / ldt, 2), "unit": "x real-time",
@@ -567,7 +613,7 @@ def main() -> None:
                         "dtype": args.dtype,
                         "config": {"workload": f"large-v2, {args.large_v2_seconds:g} s of 16 kHz audio per GPU per step, "
                                                f"reference windowing ({ln_win} windows), greedy, max_depth {args.max_depth}",
-                                   "windows": ln_win, "tokens_out": len(ltok),
+                                   "windows": ln_win, "tokens_out": len(ltok), **lcheck,
                                    "checkpoint": "large-v2 shape, synthetic, no <|endoftext|> ramp (every window runs to max_depth)",
                                    "generated_tokens_per_window_mean": round(float(np.mean([len(r) - 4 for r in lrows])), 1)},
                         "roofline": roofline_of(lkern[0], lsrc) if lkern else None,
@@ -611,6 +657,9 @@ def main() -> None:
             stages["decode_GBps_algorithmic"] = round(work["decode_bytes"] / (dec_ms * 1e-3) / 1e9, 1) if dec_ms > 0 else None
             stages["decode_frac_of_hbm_peak"] = round(work["decode_bytes"] / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dec_ms > 0 else None
         rtf = audio_s / dt
+        hstandard = args.model in ("tiny.en", "tiny_en") and args.seconds == 30.0 and args.max_depth == 100 and args.beam == 1
+        hcheck = check_against_golden(per_window, "tiny_bench" if args.geometry == "reference" else "tiny_whisper30", world) \
+            if hstandard else {"tokens_checked": None, "why": "no committed golden for this non-default workload"}
         rl_rtf = args.seconds / (rl["total"] * 1e-3)
         e2e = {"roofline_rtf": round(rl_rtf, 1), "frac": round((rtf / world) / rl_rtf, 4),
                "roofline_ms_per_step": {k: round(v, 4) for k, v in rl.items()},
@@ -618,7 +667,8 @@ def main() -> None:
                "note": "per-GPU roofline of the same step: algorithmic bytes over 8 TB/s (mel, decode) and FLOPs over "
                        "the dense MFMA peak of the path's dtype (encoder, cross-K/V); decode bytes are the NECESSARY ones "
                        "(weights once per step while any window is live, a window's cached K/V only while it is live); "
-                       "decode is latency-bound at this size (stages.decode_kernels_per_token dependent launches per token)"}
+                       "decode is latency-bound at this size: the whole decode of a window batch is ONE persistent launch "
+                       "(stages.decode_launches_per_step) whose 12 dependent roles per token hand planes over between CUs"}
         out = {
             "metric": "real-time factor (audio-sec/wall-sec)",
             "value": round(audio_s / dt, 2),
@@ -644,7 +694,8 @@ def main() -> None:
                                                  "accumulate (f32-grade results; WHISPER_HIP_ENCODER_SPLIT=0 selects exact-f32 MFMA)",
                                         "f32": "exact-f32 MFMA"}[enc_gemm],
                        "encoder_gemm_after_the_run": enc_gemm_after,
-                       "tokens_out": len(tokens) if tokens is not None else 0,
+                       "tokens_out": len(tokens) if tokens is not None else 0, **hcheck,
+                       "ranks_observed": ranks_observed,
                        "parallelism": f"windows sharded over {world} GPU(s), 1 token all-gather"},
             "roofline": roofline,
             "kernels": kernels,

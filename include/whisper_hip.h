@@ -108,6 +108,15 @@ int wb_model_set_frame_limit(wb_model* m, int whisper_geometry);
  * Replaces nothing in the reference (its Linear is Burn's, mod.rs:377-379); a caller reports it next to its timings. */
 int wb_model_encoder_gemm(const wb_model* m);
 
+/* Arithmetic of the decoder's Linear layers in BATCH MODE (more than 8 -- at d <= 512: 16 -- live rows per step):
+ *   0 = exact-f32 MFMA (v_mfma_f32_16x16x4_f32)
+ *   1 = split precision on fp16 hi / lo weight tiles (v_mfma_f32_16x16x32_f16 x 3, f32 accumulation; default for f32 models;
+ *       WHISPER_HIP_DECODER_SPLIT=0 at load time selects 0).  1 can turn into 0 ONCE: when a decoder activation leaves fp16's
+ *       range the decode call that observes it fails with WB_ERR_STATE (its rows are invalid), the model switches to 0 and
+ *       the caller's retry succeeds.  The guard word is per SESSION: only the session whose rows were invalid fails.
+ * Replaces nothing in the reference (mod.rs:345-350 runs Burn's Linear). */
+int wb_model_decoder_gemm(const wb_model* m);
+
 /* ---- stateless, reference-shaped entry points (the parity surface) -------------- */
 
 /* max_waveform_samples(n_frame_max), src/audio.rs:12-17 */

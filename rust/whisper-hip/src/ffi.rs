@@ -68,6 +68,7 @@ extern "C" {
     pub fn wb_model_free(m: *mut wb_model);
     pub fn wb_model_set_frame_limit(m: *mut wb_model, whisper_geometry: c_int) -> c_int;
     pub fn wb_model_encoder_gemm(m: *const wb_model) -> c_int;
+    pub fn wb_model_decoder_gemm(m: *const wb_model) -> c_int;
     pub fn wb_max_waveform_samples(n_frame_max: i64) -> i64;
     pub fn wb_prep_audio(device: c_int, pcm: *const c_float, n: i64, sample_rate: c_double, mel: *mut c_float,
                          n_frames: *mut i64) -> c_int;

@@ -120,6 +120,8 @@ impl Whisper {
     /// Arithmetic of the encoder-side Linear layers: 0 = exact-f32 MFMA, 1 = split precision (three fp16 MFMAs per
     /// product, f32-grade; the default).
     pub fn encoder_gemm(&self) -> i32 { unsafe { ffi::wb_model_encoder_gemm(self.raw) as i32 } }
+    /// 1 = split-precision fp16 MFMA decoder GEMMs in batch mode (default), 0 = exact f32 (also after a range-guard trip).
+    pub fn decoder_gemm(&self) -> i32 { unsafe { ffi::wb_model_decoder_gemm(self.raw) as i32 } }
 
     /// mod.rs:52-54: `[B, 80, T]` -> `[B, C, d]`, `C = (T - 1) / 2 + 1`; T > n_audio_ctx is the reference's panic.
     pub fn forward_encoder(&self, mel: &Tensor) -> Result<Tensor> {

@@ -221,6 +221,63 @@ def main(which):
             ref = eval([l for l in p.stdout.splitlines() if l.startswith("ROWS ")][-1][5:])
             assert wins2 == ref, (wins2, ref)
             assert len(wins2) == 3
+    elif which in ("guard_chain", "guard_enc_deferred", "guard_session"):
+        # tests/test_gpu_guard.py's checkpoints on the functional model: one MLP hidden unit pushed to 1e5 with an all-zero
+        # row in the second matrix (exact result = the ordinary one; the fp16 pieces overflow: inf * 0 = NaN)
+        def guarded(where):
+            w2 = {k: np.array(v, copy=True) for k, v in synth.synth_weights(dims, seed=4242, eot_beta=0.0).items()}
+            pfx = ("encoder" if where == "enc" else "decoder") + "/block_1/mlp"
+            j = 4 * 128 - 1
+            w2[pfx + "/mlp1/weight"][:, j] = 0.0
+            w2[pfx + "/mlp1/bias"][j] = 1.0e5
+            w2[pfx + "/mlp2/weight"][j, :] = 0.0
+            return w2
+        if which == "guard_enc_deferred":
+            # wb_waveform_to_tokens defers the encoder guard to the decode's own synchronisation and decodes the batch again
+            w2 = guarded("enc")
+            e2, o2 = wb.Whisper.from_tensors(w2), OracleWhisper(w2)
+            assert e2.encoder_gemm() == "f16x3"
+            a = synth.synth_audio(16000 * 4, 77)
+            ref, rw = otr.waveform_to_tokens(o2, pu.ost(st), a, 16000, 1, 6, return_windows=True)
+            got, wins = wb.waveform_to_tokens(e2, st, a, 16000, 1, 6)
+            assert e2.encoder_gemm() == "f32"
+            assert got == ref and wins == rw, (got, ref)
+            got, wins = wb.waveform_to_tokens(e2, st, a, 16000, 1, 6)       # (pooled session, guard word clear again)
+            assert got == ref
+            e2.close()
+        else:
+            w2 = guarded("dec")
+            e2, o2 = wb.Whisper.from_tensors(w2), OracleWhisper(w2)
+            assert e2.decoder_gemm() == "f16x3"
+            n_win, wl = 18, 4000                                            # 18 live rows at d = 128: batch mode
+            a = synth.synth_audio(wl * n_win, 78)
+            starts = np.arange(n_win, dtype=np.int64) * wl
+            lens = np.full(n_win, wl, dtype=np.int64)
+            params = wb.decode_params(st, beam_size=1, max_depth=4)
+
+            def decode():
+                sess = wb.Session.begin(e2, a, starts, lens, max_beams=1)
+                try:
+                    sess.set_special_mask(st.is_special)
+                    return sess.decode(params)
+                finally:
+                    sess.close()
+            other = wb.Session.begin(e2, a, starts[:2], lens[:2], max_beams=1)      # bystander: 2 rows, never on the split kernel
+            other.set_special_mask(st.is_special)
+            failed = None
+            try:
+                decode()
+            except Exception as ex:
+                failed = ex
+            assert failed is not None and getattr(failed, "status", 0) == -6 and "fp16" in str(failed), repr(failed)
+            assert e2.decoder_gemm() == "f32"
+            assert other.decode(params) is not None                         # not failed by the first session's trip
+            other.close()
+            rows = decode()                                                 # retry: exact-f32 decoder GEMMs
+            for wi in (0, 17):
+                mel = torch.from_numpy(wb.prep_audio(a[None, wi * wl:(wi + 1) * wl]))
+                assert rows[wi] == otr.mels_to_tokens(o2, pu.ost(st), mel, 10, 1, 4), wi
+            e2.close()
     elif which == "beam_batch":
         # batch mode with MORE than 32 live rows: 9 windows x 4 beams = 36 rows -> three 16-row tiles of the skinny
         # weight-stream GEMM (decode_batch.hip: v_mfma_f32_16x16x4_f32, split-K planes; with three or four tiles a thread

@@ -92,6 +92,7 @@ _PLAN = {
     "test_outputs_are_bitwise_independent_of_the_schedule": lambda p: [("bitwise", {}), ("bitwise", {"HIPEMU_ORDER": "reverse"})],
     "test_nine_to_sixteen_live_rows_on_the_fused_sublayer_path": lambda p: [("beam16", p["env"])],
     "test_decoder_split_range_guard_fails_loudly_and_falls_back": lambda p: [("dec_split_range", {})],
+    "test_range_guard_words_are_per_session_and_the_encoder_check_is_deferred": lambda p: [(p["which"], {})],
 }
 
 
@@ -193,6 +194,17 @@ def test_decoder_split_range_guard_fails_loudly_and_falls_back(emu_lib):
     assert p.returncode == 0 and "EMU_CHECK_OK dec_split_range" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
+@pytest.mark.parametrize("which", ["guard_chain", "guard_enc_deferred"])
+def test_range_guard_words_are_per_session_and_the_encoder_check_is_deferred(emu_lib, which):
+    """Round 6: the range-guard words belong to the session (no model-wide lock, no cross-session false trips).
+    guard_chain: the DEVICE-CHAINED greedy path in batch mode with NaN rows -- the row's top-1 must not become an embedding
+    index (it ends on <|endoftext|>), the call fails with WB_ERR_STATE, a bystander session of the same model is not failed,
+    the retry is token-exact.  guard_enc_deferred: wb_waveform_to_tokens resolves the encoder's guard behind the decode's own
+    synchronisation and decodes the batch again on the exact-f32 kernel (tests/emu_checks.py)."""
+    p = _run(emu_lib, which, {})
+    assert p.returncode == 0 and f"EMU_CHECK_OK {which}" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
 def test_production_key_ring_under_the_functional_model(emu_lib_prod):
     """The micro-model library compiles a 384-key ring so that small fixtures reach both of its code paths; the PRODUCT
     compiles 768 keys.  This runs the product's constant (`make prod`) at the real window lengths: C = 745 keys in one
@@ -285,8 +297,9 @@ def test_bench_main_runs_to_its_json_line(emu_lib, extra):
     assert 0 <= out["roofline"]["frac"] and out["roofline"]["peak"] == 8000.0 and out["roofline"]["unit"] == "GB/s"
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and set(cb["stages_s"]) == {"mel", "encoder", "decode", "total"}
-    assert out["mel_frontend"]["windows"] >= 2 and out["stages"]["decode_kernels_per_token"] > 0
+    assert out["mel_frontend"]["windows"] >= 2 and out["stages"]["decode_launches_per_step"] > 0
     assert len(cb["runs_s"]) == 3
+    assert out["config"]["tokens_checked"] is None and out["config"]["ranks_observed"]["world_size"] == 1     # (micro checkpoint: no golden)
     assert out["config"]["encoder_gemm"].startswith("exact-f32" if "--encoder" in extra else "split precision")
     assert cb["depth"] == 4 and cb["depth32"]["depth"] == 4 and cb["depth32"]["value"] > 0
     if "--beam" not in extra and "--beam5-leg" not in extra:   # the greedy reference-geometry line carries the live beam-5 setting too

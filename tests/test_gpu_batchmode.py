@@ -23,10 +23,13 @@ the same operators at `small` and large-v2 (/tmp study recorded in LABLOG R5.1),
 assertion with an order of magnitude of headroom.  Token parity of the batch-mode path is pinned separately and exactly by the
 two depth-100 greedy tests.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
 
+import parity_log
 import parity_util as pu
 import whisper_burn_amd as wb
 import workloads
@@ -35,17 +38,21 @@ from whisper_burn_amd import synth
 
 pytestmark = pytest.mark.gpu
 
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_outputs.npz")
 LOGPROB_TOL = 1e-3      # north_star: logits within 1e-3 (fp32) -- asserted outright on every compared row
 WLEN = 238559           # max_waveform_samples(1500 - 10), transcribe.rs:32-34
 
 
-def _check_rows_are_oracle_greedy(o, st, audio, wins, depth, sample_rate=16000):
-    """Every per-window row is the oracle's greedy chain given the same log-mel (parity_util.window_mels feeds both
-    sides the HIP log-mel; the frontend has its own tests).  Returns (#tokens checked, smallest top-2 gap seen)."""
+def _check_rows_are_oracle_greedy(o, st, audio, wins, depth, sample_rate=16000, only=None):
+    """Every per-window row (`only`: these window indices) is the oracle's greedy chain given the same log-mel
+    (parity_util.window_mels feeds both sides the HIP log-mel; the frontend has its own tests).
+    Returns (#tokens checked, smallest top-2 gap seen)."""
     mels = pu.window_mels(o, audio, sample_rate, frontend=wb.prep_audio)
     assert len(mels) == len(wins)
     n_tok, gap_min = 0, np.inf
     for wi, row in enumerate(wins):
+        if only is not None and wi not in only:
+            continue
         assert len(row) >= 5 and row[:4] == [st.start_of_transcript, st.language, st.transcribe, st.no_timestamps], (wi, row[:6])
         enc = o.forward_encoder(mels[wi])[0]
         lp = pu.teacher_forced_logprobs(o, st, enc, row)
@@ -98,6 +105,46 @@ def test_large_v2_10_windows_depth_100_batch_mode(large_v2):
     n_tok, gap = _check_rows_are_oracle_greedy(o, st, audio, wins, 100)
     assert n_tok >= 10 * 20, n_tok
     print(f"large-v2 10 windows: {n_tok} teacher-forced decisions, smallest oracle top-2 gap {gap:.3e}")
+
+
+@pytest.fixture(scope="module")
+def large_v2_leg():
+    """bench.py's large-v2 leg, exactly: the checkpoint without the EOT ramp and 450 s of the leg's own audio."""
+    wl = workloads.WORKLOADS["large_leg"]
+    w = wl.weights()
+    eng, o = wb.Whisper.from_tensors(w), OracleWhisper(w)
+    yield eng, o, wl.audio()
+    eng.close()
+
+
+def test_large_v2_leg_38_windows_tokens(large_v2_leg):
+    """The configuration the bench's large-v2 figure is TIMED on (round 5's review: it had no parity check): 450 s = 38
+    windows in ONE batch, i.e. 38 live rows = dec_skinny_f16x3_kernel<3> (three 16-row tiles) at d = 1280, 32 layers, greedy
+    to depth 100.  First and last window against the oracle's committed LITERAL rows from raw PCM (golden `large_leg`:
+    the rows bench.py checks its leg against), four windows spread over the batch teacher-forced position by position."""
+    eng, o, audio = large_v2_leg
+    st = wb.SpecialTokens.for_vocab(51865)
+    assert len(wb.window_extents(len(audio), 16000, WLEN)[0]) == 38
+    _, wins = wb.waveform_to_tokens(eng, st, audio, 16000, 1, 100)
+    assert len(wins) == 38
+    g = np.load(GOLD)
+    gold = [g["large_leg_tokens"][i, :g["large_leg_lens"][i]].tolist() for i in range(2)]
+    assert wins[0] == gold[0] and wins[37] == gold[1]
+    n_tok, gap = _check_rows_are_oracle_greedy(o, st, audio, wins, 100, only=(0, 12, 25, 37))
+    assert n_tok == 4 * 100, n_tok
+    assert len({tuple(r[4:]) for r in wins}) >= 34                   # the windows decode to different text
+    print(f"large-v2 leg, 38 windows: {n_tok} teacher-forced decisions, smallest oracle top-2 gap {gap:.3e}")
+
+
+def test_large_v2_leg_38_rows_logprob_rows(large_v2_leg):
+    """... and the same 38-row batch as a session: 16 positions, the log-prob rows of four windows spread over the batch
+    (first tile, both middle tiles, the ragged last tile of 6 rows) within 1e-3 of the f32 oracle's stateless rows."""
+    eng, o, audio = large_v2_leg
+    st = wb.SpecialTokens.for_vocab(51865)
+    res = _session_logprob_rows(eng, o, st, audio, list(range(38)), 1, 16, -1, 31, check=(0, 12, 25, 37))
+    assert res["n_live"] == 38 and res["longest"] >= 16
+    print(f"large-v2 38 x 1 beam: {res}")
+    _assert_rows(res, "large_v2_leg_38x1_streaming")
 
 
 def _session_logprob_rows(eng, o, st, audio, use_windows, max_beams, n_steps, fork_at, seed, check=None):
@@ -156,19 +203,22 @@ def _session_logprob_rows(eng, o, st, audio, use_windows, max_beams, n_steps, fo
         lp = pu.teacher_forced_logprobs(o, st, encs[wdx], list(seq))
         for n in range(4, len(seq) + 1):
             rows.setdefault((seq[:n], wdx), lp[n - 4])
-    worst32, sq = 0.0, 0.0
+    worst32, sq, mag = 0.0, 0.0, 0.0
     for seq, wdx, got in records:
         ref = rows[(seq, wdx)]
         fin = np.isfinite(ref)
         assert (np.isfinite(got) == fin).all()
         e = float(np.abs(got[fin] - ref[fin]).max())
         worst32 = max(worst32, e); sq += e * e
+        mag = max(mag, float(np.abs(ref[fin]).max()))
     return {"hip_o32": worst32, "rms_hip_o32": (sq / max(len(records), 1)) ** 0.5, "n_live": n_live, "n_rows": len(records),
-            "longest": max(len(r[0]) for r in records)}
+            "longest": max(len(r[0]) for r in records), "max_abs_logprob": mag}
 
 
-def _assert_rows(res):
+def _assert_rows(res, name):
     """north_star: every compared log-prob row within 1e-3 of the reference-style f32 evaluation (module docstring)."""
+    parity_log.record("batchmode::" + name, res["hip_o32"], LOGPROB_TOL, res["max_abs_logprob"], rms=res["rms_hip_o32"],
+                      n_rows=res["n_rows"], n_live=res["n_live"], longest=res["longest"])
     assert res["n_rows"] >= 30, res
     assert res["hip_o32"] <= LOGPROB_TOL, res
 
@@ -183,7 +233,7 @@ def test_large_v2_batch_mode_beams_logprob_rows(large_v2):
     res = _session_logprob_rows(eng, o, st, audio, [0, 2, 4, 6, 9], 2, 20, 3, 11, check=(0, 2, 4))
     assert res["n_live"] == 10 and res["longest"] >= 20
     print(f"large-v2 5 x 2 beams: {res}")
-    _assert_rows(res)
+    _assert_rows(res, "large_v2_5x2_beams")
 
 
 def test_large_v2_batch_mode_streaming_logprob_rows(large_v2):
@@ -195,7 +245,7 @@ def test_large_v2_batch_mode_streaming_logprob_rows(large_v2):
     res = _session_logprob_rows(eng, o, st, audio, list(range(9)), 1, 24, -1, 21, check=(0, 3, 5, 8))
     assert res["n_live"] == 9 and res["longest"] >= 24
     print(f"large-v2 9 x 1 beam: {res}")
-    _assert_rows(res)
+    _assert_rows(res, "large_v2_9x1_streaming")
 
 
 @pytest.mark.parametrize("mode", ["stream_9x1", "chunked_5x2"])
@@ -217,4 +267,4 @@ def test_small_batch_mode_session_past_the_second_self_attention_tile(mode):
     eng.close()
     assert res["longest"] >= 122
     print(f"small {mode}: {res}")
-    _assert_rows(res)
+    _assert_rows(res, "small_122_positions_" + mode)

@@ -24,6 +24,7 @@ import pytest
 import torch
 
 import whisper_burn_amd as wb
+import parity_log
 import workloads
 from oracle import mel as omel
 from oracle.model import OracleWhisper
@@ -79,9 +80,12 @@ def test_pcm_to_logprob_budget_tiny_en(clip):
     r64 = _rows(o64, st, omel.prep_audio_f64(audio)[None], row, torch.float64)
     fin = np.isfinite(r64)
     assert (np.isfinite(hip) == fin).all() and (np.isfinite(r32) == fin).all()
-    d_hip_exact = float(np.abs(hip - r64)[fin].max())
-    d_o32_exact = float(np.abs(r32 - r64)[fin].max())
-    d_hip_o32 = float(np.abs(hip - r32)[fin].max())
+    with np.errstate(invalid="ignore"):          # (-inf - -inf at the masked special tokens: excluded by `fin`)
+        d_hip_exact = float(np.abs(hip - r64)[fin].max())
+        d_o32_exact = float(np.abs(r32 - r64)[fin].max())
+        d_hip_o32 = float(np.abs(hip - r32)[fin].max())
+    parity_log.record(f"budget::pcm_to_logprob_tiny_en[{clip}] hip vs exact (f64, from PCM)", d_hip_exact, EXACT_TOL,
+                      float(np.abs(r64[fin]).max()), n_rows=hip.shape[0], oracle_f32_vs_exact=d_o32_exact, hip_vs_oracle_f32=d_hip_o32)
     print(f"{clip}: rows {hip.shape[0]}, max |log-prob| {np.abs(r64[fin]).max():.1f}; hip-exact {d_hip_exact:.3e}, "
           f"oracle_f32-exact {d_o32_exact:.3e}, hip-oracle_f32 {d_hip_o32:.3e}")
     assert d_hip_exact <= EXACT_TOL, d_hip_exact

@@ -20,6 +20,7 @@ import numpy as np
 import pytest
 import torch
 
+import parity_log
 import parity_util as pu
 import whisper_burn_amd as wb
 from oracle import mel as omel
@@ -78,5 +79,9 @@ def test_pcm_to_tokens_and_logprob_rows_with_the_oracles_own_frontend(model, dep
         d_front = float(np.abs(rows["o32"] - rows["o32x"])[fin].max())
     print(f"{model}: {hip.shape[0]} rows from PCM; hip vs oracle(exact frontend) {d_x:.3e}, hip vs oracle(f32 frontend) {d_32:.3e}, "
           f"oracle f32 frontend vs exact frontend {d_front:.3e}")
+    mag = float(np.abs(rows["o32x"][fin]).max())
+    parity_log.record(f"e2e::pcm_to_logprob_rows[{model}] hip vs oracle(exact frontend)", d_x, LOGPROB_TOL, mag, n_rows=hip.shape[0])
+    parity_log.record(f"e2e::pcm_to_logprob_rows[{model}] hip vs oracle(f32 frontend)", d_32, LOGPROB_TOL + d_front, mag,
+                      n_rows=hip.shape[0], oracle_f32_frontend_vs_exact=d_front)
     assert d_x <= LOGPROB_TOL, d_x
     assert d_32 <= LOGPROB_TOL + d_front, (d_32, d_front)

@@ -6,6 +6,8 @@ token ids; mel within 2e-4 of the reference's own f32 recipe (whose dense-DFT an
 """
 import numpy as np
 import pytest
+
+import parity_log
 import torch
 
 import whisper_burn_amd as wb
@@ -114,6 +116,7 @@ def test_forward_decoder_micro(micro):
     got = eng.forward_decoder(tokens, enc)
     ref = oracle.forward_decoder(torch.from_numpy(tokens), torch.from_numpy(enc)).numpy()
     assert got.shape == ref.shape == (3, 17, 1031)
+    parity_log.record("parity::forward_decoder_micro", np.abs(got - ref).max(), LOGIT_TOL, np.abs(ref).max(), n_rows=51, quantity="logits")
     assert np.abs(got - ref).max() < LOGIT_TOL, np.abs(got - ref).max()
     assert (got.argmax(-1) == ref.argmax(-1)).all()
 
@@ -151,5 +154,7 @@ def test_tiny_en_forward_real_shape(tiny):
     logits = eng.forward(mel, tokens)
     ref = oracle.forward(torch.from_numpy(mel), torch.from_numpy(tokens)).numpy()
     assert logits.shape == (1, 7, 51864)
+    parity_log.record("parity::tiny_en_forward_real_shape encoder", np.abs(enc - ref_enc).max(), ENC_TOL * 2, np.abs(ref_enc).max(), quantity="encoder output")
+    parity_log.record("parity::tiny_en_forward_real_shape logits", np.abs(logits - ref).max(), LOGIT_TOL, np.abs(ref).max(), n_rows=7, quantity="logits")
     assert np.abs(logits - ref).max() < LOGIT_TOL, np.abs(logits - ref).max()
     assert (logits.argmax(-1) == ref.argmax(-1)).all()

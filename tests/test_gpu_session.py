@@ -2,6 +2,8 @@
 as-written restatement (full-prefix decoder re-run per step, transcribe.rs:253-307)."""
 import numpy as np
 import pytest
+
+import parity_log
 import torch
 
 import whisper_burn_amd as wb
@@ -56,6 +58,7 @@ def test_session_steps_match_stateless_decoder(micro):
     # scripted beams: (tokens, window); every step extends / forks beams of the previous step
     beams = [([5], 0), ([7], 1)]
     parents = [-1, -1]
+    worst, mag, n_rows = 0.0, 0.0, 0
     for step in range(9):
         toks = [b[0][-1] for b in beams]
         wins = [b[1] for b in beams]
@@ -69,6 +72,7 @@ def test_session_steps_match_stateless_decoder(micro):
             got = sess.last_logprobs(slot)
             fin = np.isfinite(ref)
             assert (np.isfinite(got) == fin).all()
+            worst, mag, n_rows = max(worst, float(np.abs(got[fin] - ref[fin]).max())), max(mag, float(np.abs(ref[fin]).max())), n_rows + 1
             assert np.abs(got[fin] - ref[fin]).max() < LOGPROB_TOL, (step, slot)
             assert ids[slot].tolist() == _topk_ref(got, 4).tolist()
             assert np.allclose(lps[slot], got[ids[slot]], atol=1e-6)
@@ -92,6 +96,7 @@ def test_session_steps_match_stateless_decoder(micro):
         beams = [new_beams[i] for i in keep]
         parents = [new_parents[i] for i in keep]
     sess.close()
+    parity_log.record("session::scripted_beams_micro_9_steps", worst, LOGPROB_TOL, mag, n_rows=n_rows)
 
 
 @pytest.mark.parametrize("beam_size", [1, 5])

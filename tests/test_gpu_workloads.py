@@ -22,6 +22,7 @@ import numpy as np
 import pytest
 import torch
 
+import parity_log
 import parity_util as pu
 import whisper_burn_amd as wb
 import workloads
@@ -89,7 +90,7 @@ def test_bench_workload_greedy_chain_and_logprobs_live():
     # replay the three rows through the KV-cached session step by step (rows that ended early keep being fed
     # their last token: their later log-probs are not compared)
     n_pos = max(len(r) for r in wins)
-    worst = 0.0
+    worst, mag, n_rows = 0.0, 0.0, 0
     for p in range(n_pos - 1):
         toks = [r[min(p, len(r) - 1)] for r in wins]
         par = [-1] * 3 if p == 0 else [0, 1, 2]
@@ -104,6 +105,8 @@ def test_bench_workload_greedy_chain_and_logprobs_live():
                 fin = np.isfinite(ref)
                 assert (np.isfinite(got) == fin).all()
                 worst = max(worst, float(np.abs(got[fin] - ref[fin]).max()))
+                mag, n_rows = max(mag, float(np.abs(ref[fin]).max())), n_rows + 1
+    parity_log.record("workloads::bench_workload_logprobs_live[tiny.en 3 windows depth 100]", worst, LOGPROB_TOL, mag, n_rows=n_rows)
     assert worst < LOGPROB_TOL, worst
     sess.close()
     eng.close()
@@ -121,6 +124,8 @@ def test_small_forward_real_shape_logits():
     logits = eng.forward(mel, tokens)
     ref = o.forward(torch.from_numpy(mel), torch.from_numpy(tokens)).numpy()
     assert logits.shape == (1, tokens.shape[1], 51865)
+    parity_log.record("workloads::small_forward_real_shape_logits", np.abs(logits - ref).max(), LOGIT_TOL, np.abs(ref).max(),
+                      n_rows=tokens.shape[1], quantity="logits")
     assert np.abs(logits - ref).max() < LOGIT_TOL, np.abs(logits - ref).max()
     assert (logits.argmax(-1) == ref.argmax(-1)).all()
     eng.close()
@@ -194,10 +199,13 @@ def test_session_logprobs_tiny_real_shape_134_positions():
         lp = pu.teacher_forced_logprobs(o, st, encs[wdx], list(seq))       # rows for prefixes of length 4 .. len
         for n in range(4, len(seq) + 1):
             rows.setdefault((seq[:n], wdx), lp[n - 4])
-    worst = 0.0
+    worst, mag, sq = 0.0, 0.0, 0.0
     for seq, wdx, got in records:
         ref = rows[(seq, wdx)]
         fin = np.isfinite(ref)
         assert (np.isfinite(got) == fin).all()
-        worst = max(worst, float(np.abs(got[fin] - ref[fin]).max()))
+        e = float(np.abs(got[fin] - ref[fin]).max())
+        worst, mag, sq = max(worst, e), max(mag, float(np.abs(ref[fin]).max())), sq + e * e
+    parity_log.record("workloads::session_logprobs_tiny_real_shape_134_positions", worst, LOGPROB_TOL, mag,
+                      rms=(sq / len(records)) ** 0.5, n_rows=len(records))
     assert worst < LOGPROB_TOL, worst

@@ -50,6 +50,10 @@ WORKLOADS = {
     "small_10min": Workload("small", 9600000, 1238, 1, 32, (0, 12, 25, 38, 50)),
     # config #5: large-v2, one full 14.9 s window, literal loop to depth 16
     "large_window": Workload("large-v2", 238559, 1239, 1, 16),
+    # bench.py's large-v2 leg (450 s per GPU = 38 windows = one GPU's share of config #5's hour, checkpoint without the EOT
+    # ramp): the FIRST and LAST window of the leg's own audio, literal loop to the leg's depth 100 -- the rows bench.py
+    # checks its leg against outside the timed region, and tests/test_gpu_batchmode.py its 38-row batch
+    "large_leg": Workload("large-v2", 7200000, synth.BENCH_AUDIO_SEED + 5, 1, 100, (0, 37), NO_EOT),
     # config #2(b), the "perf geometry" of SURVEY 8d: ONE window of T = 2990 (+10 zero) frames, C = 1500 encoder
     # positions -- Whisper's own 30 s chunk, which the reference cannot run (mod.rs:236-241 bounds the FRAMES by
     # n_audio_ctx); opt-in on both sides (wb_model_set_frame_limit / OracleWhisper(frame_limit_x2=True))

@@ -113,6 +113,11 @@ int wb_model_encoder_gemm(const wb_model* m) {
   return m->split_active() ? 1 : 0;        // (0 as well once the range guard of the split kernel has tripped)
 }
 
+int wb_model_decoder_gemm(const wb_model* m) {
+  if (!m) return WB_ERR_ARG;
+  return m->dec_split_active() ? 1 : 0;    // (0 as well once a session's decoder range guard has tripped)
+}
+
 void wb_model_free(wb_model* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);

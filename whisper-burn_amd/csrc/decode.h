@@ -24,7 +24,8 @@ constexpr int KS_MAX = 16;       // most K-split partials any consumer folds
 // mapped pinned memory; dec_prepare_kernel copies it to device memory for the rest of the step.
 enum { ST_N = 0, ST_STEP = 1, ST_HDR = 4 };
 // Device control block of the chained greedy decode (ints): step, then cur_tok[S], done[S], out_len[S].
-enum { GC_STEP = 0, GC_NDONE = 1, GC_ALLDONE = 2, GC_HDR = 4 };   // [1]: windows finished so far, [2]: all of them
+enum { GC_STEP = 0, GC_NDONE = 1, GC_ALLDONE = 2, GC_BAD = 3, GC_HDR = 4 };   // [1]: windows finished so far, [2]: all of them,
+                                                                          // [3]: a row had no finite log-prob (top1_or_eot)
 struct StepLayout {
   int S = 0, W = 0;                                  // slot capacity, windows
   int tok = 0, parent = 0, len = 0, win = 0;         // offsets of int[S] arrays

@@ -417,6 +417,15 @@ __global__ __launch_bounds__(256, (MR >= 8 && DPL >= 16) ? 1 : 2) void dec_gemv_
 // `len`, `finished` and `step` are the row's state words as read at kernel entry (before any block of this launch has
 // written state): the update itself is stores only -- three dependent global reads by one thread used to sit between the
 // top-1 and the next step's embedding gather.
+// A top-1 without a finite candidate keeps the candidate lists' initial id 0x7fffffff: the row's logits were NaN (an
+// activation left the range of a 16-bit GEMM path and the range guard is about to fail the call, or the weights are not
+// finite).  That id must never become an embedding index (dec_prepare_kernel / the merge kernel's next-step gather read
+// E + tok * d): the row ends on <|endoftext|> instead and GC_BAD makes the host fail the call loudly (session_greedy_chain).
+__device__ __forceinline__ int top1_or_eot(int gi, int eot, int* gctl) {
+  if ((unsigned)gi >= 0x7fffffffu) { gctl[GC_BAD] = 1; return eot; }
+  return gi;
+}
+
 __device__ __forceinline__ int chained_update(int* st, const StepLayout& lay, int* gctl, int* gtok, int Lmax,
                                               int eot, int r, int gi, int len, int finished, int step) {
   if (!finished) {
@@ -552,6 +561,8 @@ __global__ __launch_bounds__(256) void dec_topk_merge_kernel(int* __restrict__ s
     float gv = redv[0]; int gi = redi[0];
     for (int j = 1; j < 4; j++)
       if (better(redv[j], redi[j], gv, gi)) { gv = redv[j]; gi = redi[j]; }
+    const int gi_list = gi;                    // (what the candidate lists hold: the pop below compares with it)
+    if (gctl && round == 0) gi = top1_or_eot(gi, eot, gctl);
     if (tid == 0) {
       out_id[r * TOPK_MAX + round] = gi;
       out_lp[r * TOPK_MAX + round] = (gv - M) - lse;   // log_softmax, transcribe.rs:276
@@ -561,7 +572,7 @@ __global__ __launch_bounds__(256) void dec_topk_merge_kernel(int* __restrict__ s
       }
     }
     if (round == 0) first = gi;
-    if (ti[0] == gi) {   // the winner pops its head
+    if (ti[0] == gi_list) {   // the winner pops its head
 #pragma unroll
       for (int j = 0; j < TOPK_MAX - 1; j++) { tv[j] = tv[j + 1]; ti[j] = ti[j + 1]; }
       tv[TOPK_MAX - 1] = -INFINITY; ti[TOPK_MAX - 1] = 0x7fffffff;
@@ -1257,10 +1268,11 @@ __global__ __launch_bounds__(1024) void dec_topk_rows_kernel(int* __restrict__ s
     for (int j = 1; j < 16; j++)
       if (better(redv[j], redi[j], gv, gi)) { gv = redv[j]; gi = redi[j]; }
     if (tid == 0) {
-      out_id[r * TOPK_MAX + round] = gi;
+      const int tok = (gctl && round == 0) ? top1_or_eot(gi, eot, gctl) : gi;
+      out_id[r * TOPK_MAX + round] = tok;
       out_lp[r * TOPK_MAX + round] = (gv - M) - lse;
       if (gctl && round == 0)
-        chained_update(st, lay, gctl, gtok, Lmax, eot, r, gi, st[lay.len + r], gctl[GC_HDR + lay.S + r], st[ST_STEP]);
+        chained_update(st, lay, gctl, gtok, Lmax, eot, r, tok, st[lay.len + r], gctl[GC_HDR + lay.S + r], st[ST_STEP]);
     }
     if (ti[0] == gi) {
 #pragma unroll

@@ -290,6 +290,8 @@ __device__ __forceinline__ bool ps_merge_role(const PersistArgs& a, const int r,
 #pragma unroll
     for (int j = 1; j < 8; j++)
       if (better(redv[j], redi[j], gv, gi)) { gv = redv[j]; gi = redi[j]; }
+    // no finite candidate (NaN logits): never an embedding index -- the row ends, the host fails the call (decode.hip: top1_or_eot)
+    if ((unsigned)gi >= 0x7fffffffu) { gi = a.eot; if (tid == 0) a.gctl[GC_BAD] = 1; }
   }
   const int finished = fin_now || (gi == a.eot && e >= a.n_forced);
   const int tok_next = fin_now ? tok_prev : gi;     // a finished row keeps its last token (its later argmax is stale)

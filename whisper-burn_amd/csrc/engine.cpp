@@ -35,12 +35,24 @@ static int upload(hipStream_t st, DevMem& dst, const void* src, size_t bytes) {
 
 // Dispatch: the split-precision fp16 MFMA kernel when the weight carries split copies (sh, sl: [N][ldwt] fp16) and the shape
 // fits it, else the exact-f32 MFMA kernel (the conv1 gather, split-K launches, decoder-side weights).
+// The range-flag word of the guarded pass THIS thread is enqueueing (device-visible address of a mapped host word; null:
+// no guarded pass -> the exact-f32 kernel).  A pass is enqueued synchronously by one host thread, so a thread-local scope
+// reaches every gemm_dispatch of the pass without threading a pointer through the whole call tree.
+static thread_local int* tl_split_flag = nullptr;
+namespace {
+struct SplitFlagScope {
+  int* prev;
+  explicit SplitFlagScope(int* f) : prev(tl_split_flag) { tl_split_flag = f; }
+  ~SplitFlagScope() { tl_split_flag = prev; }
+};
+}  // namespace
+
 int gemm_dispatch(const wb_model* m, hipStream_t st, const GemmArgs& a, int ldwt, const uint16_t* sh, const uint16_t* sl) {
   // exact-f32 models: encoder-side weights that carry a split copy go through the three-product fp16 kernel
-  if (m->split_active() && sh && sl && a.conv1_tstride == 0 && a.K % 32 == 0 && ldwt % 8 == 0 && a.ksplit <= 1 &&
+  if (m->split_active() && tl_split_flag && sh && sl && a.conv1_tstride == 0 && a.K % 32 == 0 && ldwt % 8 == 0 && a.ksplit <= 1 &&
       (a.a_desc == nullptr || a.a_mask_align % 8 == 0)) {
     GemmArgs g = a;
-    g.range_flag = m->split_flag_dev;
+    g.range_flag = tl_split_flag;
     WB_REQUIRE(launch_gemm_f16x3(st, g, sh, sl, ldwt) == 0, WB_ERR_SHAPE, "split gemm: unsupported shape M=%d N=%d K=%d", a.M,
                a.N, a.K);
     return WB_OK;
@@ -52,22 +64,39 @@ int gemm_dispatch(const wb_model* m, hipStream_t st, const GemmArgs& a, int ldwt
 
 // Run `body` (a pass that may use the split-precision kernel); if that kernel raised its range flag -- an activation left
 // fp16's range, so some outputs are inf / NaN -- switch the model to the exact-f32 kernel for good and run the pass again.
-// Costs one stream synchronisation per pass while the split kernel is in use.  The flag word is per model and sessions of
-// one model may run on different streams from different threads: guarded passes hold the model's split_mu from the first
-// launch to the read of the flag, so a pass can neither see nor clear a flag raised by another session's pass (it would
-// otherwise return that session's inf / NaN output as WB_OK).  A pass that started on the split kernel while another
-// thread's pass tripped the guard simply runs to its end on the kernel it started with and is checked like any other.
-int split_guarded(wb_model* m, hipStream_t st, const std::function<int()>& body) {
-  if (!m->split_active()) return body();
-  std::unique_lock<std::mutex> lk(m->split_mu);
-  if (!m->split_active()) { lk.unlock(); return body(); }     // tripped while this thread waited for the lock
-  WB_TRY(body());
+// The flag word belongs to the PASS (`flag_host` / `flag_dev`: a session's own mapped word, or the model's for the
+// stateless entry points, which api.cpp serialises): sessions of one model on different streams and threads share
+// nothing here -- no lock, and a pass can neither see nor clear a flag another pass raised.  split_off is the only shared
+// state (0 -> 1, once, atomic): a pass that is being enqueued while another one trips the guard runs the rest of its GEMMs
+// on the exact-f32 kernel, which is valid in any mix, and is judged by its own flag.
+// `deferred` (null: check now, at the cost of one stream synchronisation): the pass is enqueued and *deferred = true;
+// the caller reads the flag at its next natural synchronisation with split_guard_resolve() and repeats the work itself.
+int split_guarded(wb_model* m, hipStream_t st, int* flag_host, int* flag_dev, bool* deferred,
+                  const std::function<int()>& body) {
+  if (deferred) *deferred = false;
+  if (!m->split_active() || !flag_host || !flag_dev) { SplitFlagScope off(nullptr); return body(); }
+  int rc;
+  { SplitFlagScope on(flag_dev); rc = body(); }
+  if (rc != WB_OK) {
+    // kernels of the failed pass may still raise the flag: drain them and leave the word clear for the next pass
+    (void)hipStreamSynchronize(st);
+    __atomic_store_n(flag_host, 0, __ATOMIC_RELEASE);
+    return rc;
+  }
+  if (deferred) { *deferred = true; return WB_OK; }
   WB_HIP(hipStreamSynchronize(st));
-  if (__atomic_load_n(m->split_flag_host, __ATOMIC_ACQUIRE) == 0) return WB_OK;
-  __atomic_store_n(m->split_flag_host, 0, __ATOMIC_RELEASE);
-  __atomic_store_n(&m->split_off, 1, __ATOMIC_RELEASE);
-  lk.unlock();
+  if (!split_guard_resolve(m, flag_host)) return WB_OK;
+  SplitFlagScope off(nullptr);
   return body();
+}
+
+// After the stream the guarded pass ran on has been synchronised: did the pass raise its flag?  If so the word is cleared,
+// the model leaves the split-precision kernel for good and the caller must repeat the pass (and whatever consumed its output).
+bool split_guard_resolve(wb_model* m, int* flag_host) {
+  if (!flag_host || __atomic_load_n(flag_host, __ATOMIC_ACQUIRE) == 0) return false;
+  __atomic_store_n(flag_host, 0, __ATOMIC_RELEASE);
+  __atomic_store_n(&m->split_off, 1, __ATOMIC_RELEASE);
+  return true;
 }
 
 // GEMM against a model weight: `w` supplies the split copies (null: f32 kernel only).
@@ -107,7 +136,9 @@ static GemmArgs linear_args(const float* A, int M, const LinearW& w, float* C) {
 }
 
 int run_encoder(wb_model* m, hipStream_t st, Workspace& ws, const MelBatch& mb, float* out_dev, EncoderOut* eo) {
-  return split_guarded(m, st, [&]() { return run_encoder_unguarded(m, st, ws, mb, out_dev, eo); });
+  // (stateless entry: the model's own flag word; api.cpp serialises these calls)
+  return split_guarded(m, st, m->split_flag_host, m->split_flag_dev, nullptr,
+                       [&]() { return run_encoder_unguarded(m, st, ws, mb, out_dev, eo); });
 }
 
 int run_encoder_unguarded(wb_model* m, hipStream_t st, Workspace& ws, const MelBatch& mb, float* out_dev, EncoderOut* eo) {
@@ -212,7 +243,8 @@ static int run_decoder_stateless_body(wb_model* m, hipStream_t st, Workspace& ws
 int run_decoder_stateless(wb_model* m, hipStream_t st, Workspace& ws, const int32_t* tokens_dev, int n, int L,
                           const float* enc_dev, int C, float* logits_dev) {
   // (guarded: the cross-K/V projection of every layer, ckv_all, runs on the split-precision kernel here too)
-  return split_guarded(m, st, [&]() { return run_decoder_stateless_body(m, st, ws, tokens_dev, n, L, enc_dev, C, logits_dev); });
+  return split_guarded(m, st, m->split_flag_host, m->split_flag_dev, nullptr,
+                       [&]() { return run_decoder_stateless_body(m, st, ws, tokens_dev, n, L, enc_dev, C, logits_dev); });
 }
 
 static int run_decoder_stateless_body(wb_model* m, hipStream_t st, Workspace& ws, const int32_t* tokens_dev, int n, int L,

@@ -27,9 +27,13 @@ struct EncoderOut {
 int run_encoder(wb_model* m, hipStream_t st, Workspace& ws, const MelBatch& mb, float* out_dev, EncoderOut* eo);
 int run_encoder_unguarded(wb_model* m, hipStream_t st, Workspace& ws, const MelBatch& mb, float* out_dev, EncoderOut* eo);
 
-// Run `body` (a pass that may use the split-precision GEMM, gemm_f16x3.hip); if that kernel raised its range flag -- an
-// activation outside fp16's range -- the model switches to the exact-f32 kernel for good and the pass runs again.
-int split_guarded(wb_model* m, hipStream_t st, const std::function<int()>& body);
+// Run `body` (a pass that may use the split-precision GEMM, gemm_f16x3.hip) under the range-flag word `flag_host` /
+// `flag_dev` (one mapped host word per pass owner: session or model); if the kernel raised it -- an activation outside
+// fp16's range -- the model switches to the exact-f32 kernel for good and the pass runs again.  `deferred` non-null: no
+// synchronisation here; the caller resolves the flag at its next one (split_guard_resolve) and repeats the work itself.
+int split_guarded(wb_model* m, hipStream_t st, int* flag_host, int* flag_dev, bool* deferred,
+                  const std::function<int()>& body);
+bool split_guard_resolve(wb_model* m, int* flag_host);
 
 // TextDecoder::forward (mod.rs:131-157), stateless: tokens_dev [n*L], enc_dev [n*C][d] -> logits_dev [n*L][V].
 int run_decoder_stateless(wb_model* m, hipStream_t st, Workspace& ws, const int32_t* tokens_dev, int n, int L,

@@ -433,9 +433,6 @@ int build_model(TensorMap& tm, int device, int compute_dtype, wb_model** out) {
     size_t total = 0;
     for (LinearW* l : ws) total += (size_t)l->k * l->n;
     if (total && ws.size() == (size_t)D.n_text_layer * 6) {            // all or nothing: one arithmetic per decode step
-      WB_HIP(hipHostMalloc((void**)&m->dec_flag_host, 64, hipHostMallocMapped));        // freed by ~wb_model
-      *m->dec_flag_host = 0;
-      WB_HIP(hipHostGetDevicePointer((void**)&m->dec_flag_dev, m->dec_flag_host, 0));
       WB_TRY(m->arena_dec_split.alloc(total * 2 * 2));
       uint16_t* p = m->arena_dec_split.as<uint16_t>();
       for (LinearW* l : ws) {

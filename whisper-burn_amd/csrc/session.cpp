@@ -141,7 +141,15 @@ int session_create(wb_model* m, int n_windows, int max_beams, int padding, wb_se
     s->device = m->device;
     hipError_t e = hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking);
     if (e != hipSuccess) { delete s; set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); return WB_ERR_HIP; }
+    e = hipHostMalloc((void**)&s->guard_host, 64, hipHostMallocMapped);
+    if (e == hipSuccess) { memset(s->guard_host, 0, 64); e = hipHostGetDevicePointer((void**)&s->guard_dev, s->guard_host, 0); }
+    if (e != hipSuccess) { delete s; set_error("session guard words: %s", hipGetErrorString(e)); return WB_ERR_HIP; }
+  } else if (s->enc_guard_pending || s->guard_host[0] || s->guard_host[1]) {
+    // a previous user left an unresolved guard behind (its call failed before the check): drain and clear
+    (void)hipStreamSynchronize(s->st);
+    s->guard_host[0] = s->guard_host[1] = 0;
   }
+  s->enc_guard_pending = false;
   s->W = n_windows; s->max_beams = max_beams; s->S = n_windows * max_beams; s->padding = padding;
   s->T.assign(n_windows, 0); s->C.clear(); s->row0.clear();
   s->prev_len.clear(); s->prev_win.clear(); s->prev_n = 0; s->step = 0;
@@ -151,7 +159,7 @@ int session_create(wb_model* m, int n_windows, int max_beams, int padding, wb_se
   return WB_OK;
 }
 
-static int session_finish_encode(wb_session* s, const MelBatch& mb) {
+static int session_finish_encode(wb_session* s, const MelBatch& mb, bool defer_guard = false) {
   wb_model* m = s->m;
   const int d = m->dims.n_audio_state, NL = m->dims.n_text_layer;
   int rows = 0;
@@ -161,8 +169,10 @@ static int session_finish_encode(wb_session* s, const MelBatch& mb) {
   const int rows_all = rows;
   const int ldkv_all = NL * 2 * d;
   WB_TRY(s->ckv.ensure((size_t)rows_all * ldkv_all * 4));
-  // encoder + cross-K/V projection under ONE range guard of the split-precision kernel (engine.cpp: split_guarded)
-  WB_TRY(split_guarded(m, s->st, [&]() -> int {
+  // encoder + cross-K/V projection under ONE range guard of the split-precision kernel (engine.cpp: split_guarded), on
+  // this session's own flag word; deferred: no synchronisation here, the decode's own resolves it
+  bool deferred = false;
+  WB_TRY(split_guarded(m, s->st, s->guard_host, s->guard_dev, defer_guard && !profile().on ? &deferred : nullptr, [&]() -> int {
   {
     ScopedTimer tm(s->st, 1);
     WB_TRY(run_encoder_unguarded(m, s->st, s->ws, mb, s->enc_out.as<float>(), &eo));
@@ -181,6 +191,8 @@ static int session_finish_encode(wb_session* s, const MelBatch& mb) {
   }
   return WB_OK;
   }));
+  s->enc_guard_pending = deferred;
+  if (deferred) s->enc_mb = mb;
   s->C = eo.C; s->row0 = eo.row0; s->enc_rows = eo.rows;
   s->maxC = 0;
   for (int c : s->C) s->maxC = std::max(s->maxC, c);
@@ -200,8 +212,25 @@ static int session_finish_encode(wb_session* s, const MelBatch& mb) {
   return WB_OK;
 }
 
+void session_rewind(wb_session* s) {
+  s->prev_len.clear(); s->prev_win.clear(); s->prev_n = 0; s->step = 0;
+  s->last_had_logits = 0; s->last_use_mask = 0; s->prof_step_off = 0;
+}
+
+// After s->st was synchronised behind a deferred encode pass: if the split-precision kernel raised this session's flag, the
+// model has left that kernel and the pass is repeated here on the exact-f32 one (*reencoded = true: the encoder output and
+// the cached cross K/V changed under whatever was decoded from them -- decode again).
+int session_enc_guard_resolve(wb_session* s, bool* reencoded) {
+  *reencoded = false;
+  if (!s->enc_guard_pending) return WB_OK;
+  s->enc_guard_pending = false;
+  if (!split_guard_resolve(s->m, s->guard_host)) return WB_OK;
+  *reencoded = true;
+  return session_finish_encode(s, s->enc_mb, false);
+}
+
 int session_encode_pcm(wb_session* s, const float* pcm, int64_t n_pcm, const int64_t* starts, const int64_t* lens,
-                       bool pcm_on_device) {
+                       bool pcm_on_device, bool defer_guard) {
   wb_model* m = s->m;
   const int clip = m->max_mel_frames() - s->padding;   // transcribe.rs:171-177
   int64_t lo = n_pcm, hi = 0;
@@ -254,7 +283,7 @@ int session_encode_pcm(wb_session* s, const float* pcm, int64_t n_pcm, const int
   WB_HIP(hipGetLastError());
   MelBatch mb;
   mb.mel = s->mel.as<float>(); mb.win_stride = (int64_t)80 * Ts; mb.row_stride = Ts; mb.T = s->T;
-  return session_finish_encode(s, mb);
+  return session_finish_encode(s, mb, defer_guard);
 }
 
 int session_reserve(wb_session* s, int max_len) {
@@ -327,6 +356,7 @@ void wb_session::clear_graphs() {
 wb_session::~wb_session() {
   clear_graphs();
   if (host_block) (void)hipHostFree(host_block);
+  if (guard_host) (void)hipHostFree(guard_host);
   if (ev_seg) (void)hipEventDestroy(ev_seg);
   if (st2) (void)hipStreamDestroy(st2);
   if (st) (void)hipStreamDestroy(st);
@@ -420,12 +450,13 @@ int wb_session_set_special_mask(wb_session* s, const uint8_t* is_special) {
 // the host.  The kernel raises the model's mapped flag word when a result is not finite (an activation outside fp16's
 // range, |x| >= 65504: attention outputs and GELU hidden units are the only GEMM inputs that are not LayerNorm outputs).
 // The call that observes it fails loudly, the model switches to the exact-f32 skinny kernel for good and this session's
-// captured step graphs are dropped, so the caller's retry decodes with f32 GEMMs.  (The flag is per model: a session may
-// observe a flag raised by another session's step -- its call then fails although its own rows were fine; conservative.)
+// captured step graphs are dropped, so the caller's retry decodes with f32 GEMMs.  The flag word is this SESSION's
+// (guard_host[1]): only the session whose rows were invalid fails; the others keep their (finite) results and drop their
+// own graphs at their next look-up, where the graph signature carries the model's switch (launch_step).
 static int dec_split_check(wb_session* s) {
   wb_model* m = s->m;
-  if (!m->dec_flag_host || __atomic_load_n(m->dec_flag_host, __ATOMIC_ACQUIRE) == 0) return WB_OK;
-  __atomic_store_n(m->dec_flag_host, 0, __ATOMIC_RELEASE);
+  if (!s->guard_host || __atomic_load_n(&s->guard_host[1], __ATOMIC_ACQUIRE) == 0) return WB_OK;
+  __atomic_store_n(&s->guard_host[1], 0, __ATOMIC_RELEASE);
   __atomic_store_n(&m->dec_split_off, 1, __ATOMIC_RELEASE);
   s->clear_graphs();
   WB_REQUIRE(false, WB_ERR_STATE, "a decoder activation left fp16's range under the split-precision decode GEMM: this call's "
@@ -507,7 +538,7 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
       SkinnyArgs g;
       g.A = A; g.lda = w.k; g.B = w.w; g.ldb = w.n; g.M = n; g.N = w.n; g.K = w.k; g.ksplit = ks;
       g.P = P; g.plane = S * w.n;
-      if (dec_split && w.th && w.tl) { g.Bh = w.th; g.Bl = w.tl; g.range_flag = m->dec_flag_dev; g.st = dst; }   // 16-bit matrix path, f32-grade
+      if (dec_split && w.th && w.tl) { g.Bh = w.th; g.Bl = w.tl; g.range_flag = s->guard_dev + 1; g.st = dst; }   // 16-bit matrix path, f32-grade
       prof_tag(KC_B_GEMM, wsz * (double)w.k * w.n + 4.0 * n * ((double)w.k + (double)ks * w.n));
       WB_REQUIRE(launch_dec_skinny_gemm(st, g) == 0, WB_ERR_SHAPE, "skinny gemm: unsupported shape M=%d N=%d K=%d ks=%d", n,
                  w.n, w.k, ks);
@@ -760,7 +791,8 @@ static int launch_step(wb_session* s, int n_launch, int k, int use_mask, bool fu
                               &s->win_meta, &s->gctl, &s->gtok, &s->hm})
     mix((uint64_t)(uintptr_t)b->p);
   mix((uint64_t)(uintptr_t)s->host_block_dev);
-  for (int v : {s->S, s->W, s->Lmax, s->n_chunks, s->max_beams, m->ln_eps_inside_sqrt, eot}) mix((uint64_t)(int64_t)v);
+  for (int v : {s->S, s->W, s->Lmax, s->n_chunks, s->max_beams, m->ln_eps_inside_sqrt, eot, (int)m->dec_split_active()})
+    mix((uint64_t)(int64_t)v);      // (the last one: another session's trip switched the model's decoder GEMM under these graphs)
   mix(m->uid);
   if (sig != s->buf_sig) { s->clear_graphs(); s->buf_sig = sig; }
   // (reps > 1: device-chained steps read their position from the control block, so one graph can hold
@@ -1217,6 +1249,8 @@ int session_greedy_chain(wb_session* s, const int32_t* prompt, int eot, int max_
   WB_HIP(hipStreamSynchronize(st));
   tm.collect();
   WB_TRY(dec_split_check(s));
+  WB_REQUIRE(ctl[GC_BAD] == 0, WB_ERR_STATE, "a decode step produced a row without a finite log-prob (NaN logits: non-finite "
+             "weights or activations); its window was ended on <|endoftext|> on the device and the rows of this call are invalid");
   for (int w = 0; w < W; w++) {
     int len = ctl[GC_HDR + 2 * S + w];                 // prompt + generated (through EOT if it came)
     if (len < prompt_len) len = prompt_len;

@@ -45,6 +45,13 @@ struct wb_session {
   // profiling only: which kernel classes carried the per-row cached K/V bytes of the last enqueued step, and how many
   // chained steps were enqueued since s->step was last advanced (the chained loop advances it once, at its end)
   int prof_cls_cross = -1, prof_cls_self = -1, prof_step_off = 0;
+  // Range-guard words of the 16-bit matrix paths (mapped pinned host memory; the kernels raise them through guard_dev):
+  // [0] the split-precision encoder-side GEMM of this session's encode pass (engine.cpp: split_guarded), [1] the
+  // split-precision decoder GEMM of its batch-mode steps (dec_split_check).  Per session: sessions of one model on different
+  // streams / threads never see or clear each other's flags.
+  int* guard_host = nullptr; int* guard_dev = nullptr;
+  bool enc_guard_pending = false;   // the encode pass was enqueued with a deferred check (session_enc_guard_resolve)
+  wb::MelBatch enc_mb;              // ... its input, kept so the pass can be repeated on the exact-f32 kernel
   std::unordered_map<uint64_t, hipGraphExec_t> graphs;   // captured decode steps, keyed by launch shape
   uint64_t buf_sig = 0;                                  // signature of the buffers the graphs were captured with
   void clear_graphs();
@@ -74,8 +81,12 @@ struct ScopedTimer {
 void session_pool_register(wb_model* m);   // a model became alive (build_model)
 void session_pool_purge(wb_model* m);
 int session_create(wb_model* m, int n_windows, int max_beams, int padding, wb_session** out);
+// defer_guard: do not synchronise for the encoder's range guard; the caller calls session_enc_guard_resolve after its next
+// synchronisation of s->st (the decode's) and, when told so, repeats the decode.
 int session_encode_pcm(wb_session* s, const float* pcm, int64_t n_pcm, const int64_t* starts, const int64_t* lens,
-                       bool pcm_on_device);
+                       bool pcm_on_device, bool defer_guard = false);
+int session_enc_guard_resolve(wb_session* s, bool* reencoded);
+void session_rewind(wb_session* s);      // back to step 0 over the same (re-)encoded window batch
 int session_reserve(wb_session* s, int max_len);
 int session_greedy_chain(wb_session* s, const int32_t* prompt, int eot, int max_depth, int mask_until_len, int prompt_len,
                          int32_t* out_tokens, int32_t row_stride, int32_t* out_lens);

@@ -412,10 +412,20 @@ static int waveform_to_tokens_impl(wb_model* m, const float* pcm, bool pcm_on_de
     int rc = session_create(m, nb, p->beam_size, p->padding, &s);
     if (rc == WB_OK) {
       s->sample_rate = (double)sample_rate;
-      rc = session_encode_pcm(s, pcm, n, starts.data() + win_begin + b0, lens.data() + win_begin + b0, pcm_on_device);
+      // the encoder's range guard is resolved behind the decode's own synchronisation (no extra one per batch); if the
+      // split-precision kernel tripped, the pass has been repeated on the exact-f32 kernel and the batch is decoded again
+      rc = session_encode_pcm(s, pcm, n, starts.data() + win_begin + b0, lens.data() + win_begin + b0, pcm_on_device, true);
       if (rc == WB_OK) rc = wb_session_set_special_mask(s, is_special);
       if (rc == WB_OK) rc = session_reserve(s, 4 + p->max_depth + 1);
-      if (rc == WB_OK) rc = wb_session_decode(s, p, win_tokens + (size_t)b0 * row_stride, row_stride, win_lens + b0);
+      for (int attempt = 0; rc == WB_OK && attempt < 2; attempt++) {
+        rc = wb_session_decode(s, p, win_tokens + (size_t)b0 * row_stride, row_stride, win_lens + b0);
+        bool reencoded = false;
+        const int rg = session_enc_guard_resolve(s, &reencoded);
+        if (rg != WB_OK) { rc = rg; break; }
+        if (!reencoded) break;
+        rc = WB_OK;                            // (whatever the decode made of the non-finite encoder output is void)
+        session_rewind(s);                     // back to step 0 over the re-encoded window batch
+      }
       wb_session_free(s);
     }
     return rc;

@@ -139,21 +139,20 @@ struct wb_model {
   wb::DevMem arena_split;     // exact-f32 models with the split-precision encoder: fp16 hi / lo copies of the encoder-side weights
   // range guard of the split-precision kernel: a mapped host word the kernel raises when a result is not finite; once it
   // has tripped the model stays on the exact-f32 kernel (split_off)
-  // Guarded passes of ONE model are serialised by split_mu (engine.cpp: split_guarded): the flag word is per model, so the
-  // flag a pass reads after its synchronisation can only have been raised by that pass.  split_off is the one field of a
-  // loaded model that ever changes (0 -> 1, once); it is atomic and read once per GEMM dispatch.
+  // The model's own flag word serves the stateless entry points only (api.cpp serialises them); every session carries
+  // its own words (session.h: guard_host), so guarded passes of one model on different streams share nothing but
+  // split_off -- the one field of a loaded model that ever changes (0 -> 1, once); atomic, read once per GEMM dispatch.
   int* split_flag_host = nullptr; int* split_flag_dev = nullptr; int split_off = 0;
-  std::mutex split_mu;
   bool split_active() const { return arena_split.p && !__atomic_load_n(&split_off, __ATOMIC_ACQUIRE); }
-  // decoder side (batch-mode skinny GEMM on fp16 hi / lo tiles): its own arena, flag word and off switch.  The flag is
-  // checked wherever a decode synchronises with the host (session.cpp: dec_split_check): a trip fails THAT call loudly and
-  // switches the model to the exact-f32 decoder GEMMs, so the caller's retry succeeds.
+  // decoder side (batch-mode skinny GEMM on fp16 hi / lo tiles): its own arena and off switch; the flag words are the
+  // sessions' (guard_host[1]), checked wherever a decode synchronises with the host (session.cpp: dec_split_check): a trip
+  // fails THAT session's call loudly and switches the model to the exact-f32 decoder GEMMs, so the caller's retry succeeds;
+  // other sessions drop their captured step graphs the next time they look one up (the graph key carries the switch).
   wb::DevMem arena_dec_split;
-  int* dec_flag_host = nullptr; int* dec_flag_dev = nullptr; int dec_split_off = 0;
+  int dec_split_off = 0;
   bool dec_split_active() const { return arena_dec_split.p && !__atomic_load_n(&dec_split_off, __ATOMIC_ACQUIRE); }
   ~wb_model() {
     if (split_flag_host) (void)hipHostFree(split_flag_host);
-    if (dec_flag_host) (void)hipHostFree(dec_flag_host);
   }
   // encoder
   wb::LinearW conv1;   // repacked [240 = ci*3+kk][d]

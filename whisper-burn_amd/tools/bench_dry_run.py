@@ -28,6 +28,7 @@ import torch  # noqa: E402
 torch.cuda.is_available = lambda: True
 torch.cuda.set_device = lambda *a, **k: None
 torch.cuda.synchronize = lambda *a, **k: None
+torch.cuda.current_device = lambda: 0
 _to, _empty, _tensor = torch.Tensor.to, torch.empty, torch.tensor
 
 

@@ -51,6 +51,7 @@ SIGNATURES = {
     "wb_model_set_ln_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "wb_model_set_frame_limit": (C.c_int, [C.c_void_p, C.c_int]),
     "wb_model_encoder_gemm": (C.c_int, [C.c_void_p]),
+    "wb_model_decoder_gemm": (C.c_int, [C.c_void_p]),
     "wb_max_waveform_samples": (C.c_int64, [C.c_int64]),
     "wb_prep_audio": (C.c_int, [C.c_int, c_float_p, C.c_int64, C.c_double, c_float_p, c_int64_p]),
     "wb_model_load_burn_record": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),

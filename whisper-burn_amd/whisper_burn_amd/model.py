@@ -223,6 +223,11 @@ class Whisper:
         per product, f32-grade; the default)."""
         return ("f32", "f16x3")[_lib.load().wb_model_encoder_gemm(self._h)]
 
+    def decoder_gemm(self) -> str:
+        """Arithmetic of the decoder's Linear layers in batch mode: "f16x3" (split precision on fp16 weight tiles; default)
+        or "f32" (exact-f32 MFMA; also after a decoder range guard has tripped -- wb_model_decoder_gemm)."""
+        return ("f32", "f16x3")[_lib.load().wb_model_decoder_gemm(self._h)]
+
     def max_mel_frames(self) -> int:
         """Mel frames one window may hold (what transcribe.rs:32 calls n_ctx_max_encoder)."""
         return self.dims["n_audio_ctx"] * (2 if getattr(self, "_frame_limit_x2", False) else 1)

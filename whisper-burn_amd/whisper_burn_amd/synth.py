@@ -59,6 +59,7 @@ RECIPE = dict(
     succ_share=0.15, anti_self=1.0, e_noise=0.3,
     eot_ramp=(1.0, 3.5), eot_beta=12.0,
     depth_ref=6,                     # depth normalisation: models deeper than this get smaller branch gains (see synth_weights)
+    logit_depth_norm=True,           # False: the depth normalisation leaves logit_scale / eot_beta alone (logits at full scale 6)
 )
 
 # what the depth normalisation multiplies by sqrt(depth_ref / n_layer) -- encoder keys by n_audio_layer, the rest by n_text_layer
@@ -110,6 +111,9 @@ def synth_weights(dims: dict, seed: int, logit_scale: float = 6.0, **overrides) 
     the logit scale and the <|endoftext|> ramp multiplied by sqrt(depth_ref / n_layer): small 0.707, medium 0.5,
     large-v2 0.433; tiny.en / base.en / the micro models are unchanged.  The f32 oracle then sits within 1e-4 of the
     f64 evaluation of the same operators at every preset (5e-5 at large-v2 over a 56-token top-5 walk; before: 2e-2).
+    `logit_depth_norm=False` (round 6) keeps the logit scale and the EOT ramp at their full values (log-probs of magnitude
+    10 - 30 at every depth, SURVEY hard part 1) and shrinks only the branch gains / attention strengths: the variant the
+    large-v2 log-prob row tests of tests/test_gpu_batchmode.py run on.
     """
     P = dict(RECIPE)
     P["logit_scale"] = logit_scale
@@ -120,6 +124,8 @@ def synth_weights(dims: dict, seed: int, logit_scale: float = 6.0, **overrides) 
         for k in _DEPTH_ENC:
             P[k] *= f_enc
         for k in _DEPTH_DEC:
+            if k in ("logit_scale", "eot_beta") and not P["logit_depth_norm"]:
+                continue            # round 6 variant: only the branch gains / attention strengths shrink, log-probs keep scale 6
             P[k] *= f_dec
     rng = np.random.Generator(np.random.PCG64(seed))
     d = dims["n_audio_state"]
