@@ -85,7 +85,13 @@ def test_small_10min_all_51_windows_depth_100_batch_mode():
 
 @pytest.fixture(scope="module")
 def large_v2():
-    w = synth.synth_preset("large-v2")
+    # Round 6: the variant whose logits keep the full scale 6 (log-probs up to ~75 in magnitude; only the branch gains and
+    # attention strengths are depth-normalised).  Round 5's fixture also shrank the logit scale to 2.6, which makes an
+    # ABSOLUTE 1e-3 easier; tests/study_large_v2_conditioning.py (CPU, 24-token top-5 walk at full window length): f32 oracle
+    # vs its f64 twin 4.5e-5 on this variant (max |log-prob| 75, smallest top-2 gap 0.13) against 1.5e-5 on round 5's
+    # (max |log-prob| 30) -- both well-conditioned, so 1e-3 is asserted outright here too.  Round 5's fixture stays covered
+    # by the 38-row leg tests below, the `large_window` workload and tests/test_gpu_e2e.py.
+    w = synth.synth_preset("large-v2", logit_depth_norm=False)
     eng, o = wb.Whisper.from_tensors(w), OracleWhisper(w)
     assert eng.dims["n_text_state"] == 1280 and eng.dims["n_text_layer"] == 32 and eng.dims["n_vocab"] == 51865
     yield eng, o
