@@ -42,7 +42,11 @@ SWITCHES = [{}, {"WHISPER_HIP_FUSE_X": "0"}, {"WHISPER_HIP_FUSE_SUB": "0"}, {"WH
             # split-precision fp16 one (decode_batch.hip: dec_skinny_f16x3_kernel, the default since round 5)
             {"WHISPER_HIP_DECODER_SPLIT": "0"},
             # 9 - 16 live rows (beam 5 x 3 windows = 15): batch mode instead of the fused sublayer kernels with row groups
-            {"WHISPER_HIP_FUSE16": "0"}]
+            {"WHISPER_HIP_FUSE16": "0"},
+            # beam search driven by the HOST (one synchronisation + the beam.rs bookkeeping on the CPU per step) instead of
+            # the device-chained search (decode.hip: dec_beam_update_kernel, the default since round 6) -- alone and over
+            # batch mode, so that both row paths see both drivers
+            {"WHISPER_HIP_BEAM_CHAIN": "0"}, {"WHISPER_HIP_BEAM_CHAIN": "0", "WHISPER_HIP_FUSE16": "0"}]
 
 
 _CACHE = {}

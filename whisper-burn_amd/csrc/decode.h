@@ -131,6 +131,43 @@ void launch_dec_topk_rows(hipStream_t st, int* state, int n_max, const float* lo
 void launch_dec_logprob_row(hipStream_t st, const float* x, int KS, int64_t plane, int V, const float* mask,
                             int use_mask, const float* stats, float* out);
 
+// ---- device-chained beam search (src/beam.rs:9-110 + transcribe.rs:253-312 on the device) -------------------------
+// The host-driven beam search (transcribe.cpp: beam_search_windows) pays a synchronisation, a PCIe read of the top-k and the
+// beam bookkeeping per step (~45 us of a ~240 us step at tiny.en).  Here the bookkeeping is a one-block kernel between two
+// steps: it reads the step's top-k rows, applies beam_search_step (beam.rs:39-79) window by window in f64 exactly as the host
+// code does, runs the termination test of beam.rs:23-27 and writes the NEXT step's state block (token, parent slot, length,
+// window of every live beam) to device memory, where dec_prepare_kernel picks it up: the host enqueues step after step
+// without looking.  Sequences are a tree of (token, parent node) pairs -- one node per (step, window, beam) -- walked back
+// by the host at the end.
+constexpr int BEAM_KB = 2 * TOPK_MAX;     // beams a window can hold: k new + k finished (beam.rs:72-78)
+enum { BC_DEPTH = 0, BC_ALLDONE = 1, BC_ERR = 2, BC_NLIVE = 3, BC_HDR = 8 };   // header ints of the control block
+struct BeamChainLayout {
+  int W = 0, max_depth = 0;
+  // int offsets: nb[W], done[W], node / fin / prev_slot / slot_now [W][BEAM_KB]; then doubles lp[W][BEAM_KB] (8-byte aligned);
+  // then the node pool int2[(max_depth + 1) * W * BEAM_KB]
+  int nb = 0, done = 0, node = 0, fin = 0, prev_slot = 0, slot_now = 0, lp = 0, nodes = 0, total_ints = 0;
+};
+inline BeamChainLayout make_beam_layout(int W, int max_depth) {
+  BeamChainLayout b;
+  b.W = W; b.max_depth = max_depth;
+  b.nb = BC_HDR; b.done = b.nb + W; b.node = b.done + W; b.fin = b.node + W * BEAM_KB; b.prev_slot = b.fin + W * BEAM_KB;
+  b.slot_now = b.prev_slot + W * BEAM_KB;
+  b.lp = (b.slot_now + W * BEAM_KB + 1) & ~1;
+  b.nodes = b.lp + 2 * W * BEAM_KB;
+  b.total_ints = b.nodes + 2 * (max_depth + 1) * W * BEAM_KB;
+  return b;
+}
+struct BeamChainArgs {
+  int* ctl = nullptr; BeamChainLayout bl;
+  const int32_t* topk_id = nullptr; const float* topk_lp = nullptr;   // [S][TOPK_MAX] of the step just run (device memory)
+  int* state_out = nullptr; StepLayout lay;                            // the next step's state block (device memory)
+  int k = 0, eot = 0, first = 0;                                       // first: no step has run yet (termination test + slots only)
+  int V = 0;                                                           // vocabulary: a top-k id outside [0, V) (NaN logits) ends its beam and raises BC_ERR
+  int step_pos = 0;                                                    // position index (ST_STEP) of the first decode step
+  int* done_flag_host = nullptr;                                       // mapped host word: set when every window has ended
+};
+void launch_dec_beam_update(hipStream_t st, const BeamChainArgs& a);
+
 // ---- fused small-batch sublayer kernels (decode_fused.hip) ----------------------------------------------
 // Common prologue of both: x = x_in + (pbias + sum_s pend[s]) (KSp planes of [S][d]; KSp = 0: none), block 0
 // writes x to x_out, then LayerNorm(ln_g, ln_b, ln_eps).

@@ -1282,6 +1282,158 @@ __global__ __launch_bounds__(1024) void dec_topk_rows_kernel(int* __restrict__ s
   }
 }
 
+// One thread per window restates transcribe.cpp's beam_search_windows loop body (which restates beam.rs) on the device.
+// Every comparison, insertion rule and f64 sum is the host code's: get_top_elements inserts before the first stored score >=
+// the new one and evicts index 0 (beam.rs:81-110), max_by takes the LAST of equal maxima (beam.rs:23-27, :33-36), a beam's
+// score is log_prob + (double)lp (transcribe.rs:299).
+__global__ __launch_bounds__(64) void dec_beam_update_kernel(BeamChainArgs a) {
+  __shared__ int n_live_w[64];
+  __shared__ int base_w[64];
+  __shared__ int n_total;
+  const BeamChainLayout& B = a.bl;
+  const StepLayout& L = a.lay;
+  int* ctl = a.ctl;
+  double* lpv = reinterpret_cast<double*>(ctl + B.lp);
+  int2* nodes = reinterpret_cast<int2*>(ctl + B.nodes);
+  const int W = B.W, k = a.k;
+  const int depth = ctl[BC_DEPTH];            // decode steps completed before this call's step
+  const int tid = threadIdx.x;
+  // (windows beyond 64 per batch never reach this path: the host caps the batch)
+  const int w = tid;
+  int live = 0;
+  if (w < W) {
+    int* nb = ctl + B.nb; int* done = ctl + B.done;
+    int* node = ctl + B.node + w * BEAM_KB; int* fin = ctl + B.fin + w * BEAM_KB;
+    int* prev = ctl + B.prev_slot + w * BEAM_KB; int* slot_now = ctl + B.slot_now + w * BEAM_KB;
+    double* lp = lpv + w * BEAM_KB;
+    if (!a.first && !done[w]) {
+      // ---- beam_search_step (beam.rs:39-79) on the step that just ran ----
+      // new beams in generation order: for each unfinished beam its k continuations, ascending by score (get_top_elements)
+      int nn_tok[TOPK_MAX * TOPK_MAX], nn_src[TOPK_MAX * TOPK_MAX]; double nn_lp[TOPK_MAX * TOPK_MAX];
+      int n_new = 0;
+      int f_idx[BEAM_KB]; int n_fin = 0;
+      const int n_b = nb[w];
+      for (int i = 0; i < n_b; i++) {
+        if (fin[i]) { f_idx[n_fin++] = i; continue; }
+        const int slot = slot_now[i];
+        // the k best continuations by (log-prob desc, id asc) cover every element the V-wide insertion scan can retain;
+        // replay that scan on them in id order
+        int ct[TOPK_MAX]; double cs[TOPK_MAX];
+        for (int j = 0; j < k; j++) {
+          ct[j] = a.topk_id[slot * TOPK_MAX + j]; cs[j] = lp[i] + (double)a.topk_lp[slot * TOPK_MAX + j];
+          // a row without k finite candidates (NaN logits) leaves 0x7fffffff in its list: never an embedding index -- the
+          // host fails the call (BC_ERR); distinct negative stand-ins keep the id sort below well-defined
+          if ((unsigned)ct[j] >= (unsigned)a.V) { ctl[BC_ERR] = 1; ct[j] = -1 - j; }
+        }
+        for (int x = 1; x < k; x++) {                    // insertion sort by token id (ids are distinct)
+          const int t = ct[x]; const double sc = cs[x]; int y = x - 1;
+          while (y >= 0 && ct[y] > t) { ct[y + 1] = ct[y]; cs[y + 1] = cs[y]; y--; }
+          ct[y + 1] = t; cs[y + 1] = sc;
+        }
+        int top[TOPK_MAX]; double tsc[TOPK_MAX]; int nt = 0;
+        for (int j = 0; j < k; j++) {                    // get_top_elements(conts, k)
+          const double sc = cs[j];
+          if (nt == k && sc < tsc[0]) continue;
+          int idx = nt;
+          for (int q = 0; q < nt; q++) if (tsc[q] >= sc) { idx = q; break; }
+          for (int q = nt; q > idx; q--) { top[q] = top[q - 1]; tsc[q] = tsc[q - 1]; }
+          top[idx] = j; tsc[idx] = sc; nt++;
+          if (nt > k) { for (int q = 0; q + 1 < nt; q++) { top[q] = top[q + 1]; tsc[q] = tsc[q + 1]; } nt--; }
+        }
+        for (int q = 0; q < nt; q++) { nn_tok[n_new] = ct[top[q]]; nn_lp[n_new] = tsc[q]; nn_src[n_new] = i; n_new++; }
+      }
+      // next = top-k of the new beams (ascending) ++ top-k of the finished ones (ascending)
+      int sel[TOPK_MAX + 1]; double ssc[TOPK_MAX + 1]; int ns = 0;
+      for (int j = 0; j < n_new; j++) {
+        const double sc = nn_lp[j];
+        if (ns == k && sc < ssc[0]) continue;
+        int idx = ns;
+        for (int q = 0; q < ns; q++) if (ssc[q] >= sc) { idx = q; break; }
+        for (int q = ns; q > idx; q--) { sel[q] = sel[q - 1]; ssc[q] = ssc[q - 1]; }
+        sel[idx] = j; ssc[idx] = sc; ns++;
+        if (ns > k) { for (int q = 0; q + 1 < ns; q++) { sel[q] = sel[q + 1]; ssc[q] = ssc[q + 1]; } ns--; }
+      }
+      int fsel[TOPK_MAX + 1]; double fsc[TOPK_MAX + 1]; int nf = 0;
+      for (int j = 0; j < n_fin; j++) {
+        const double sc = lp[f_idx[j]];
+        if (nf == k && sc < fsc[0]) continue;
+        int idx = nf;
+        for (int q = 0; q < nf; q++) if (fsc[q] >= sc) { idx = q; break; }
+        for (int q = nf; q > idx; q--) { fsel[q] = fsel[q - 1]; fsc[q] = fsc[q - 1]; }
+        fsel[idx] = f_idx[j]; fsc[idx] = sc; nf++;
+        if (nf > k) { for (int q = 0; q + 1 < nf; q++) { fsel[q] = fsel[q + 1]; fsc[q] = fsc[q + 1]; } nf--; }
+      }
+      // write the next generation (reads of the old arrays first: they are overwritten in place)
+      int o_node[BEAM_KB], o_fin[BEAM_KB], o_prev[BEAM_KB]; double o_lp[BEAM_KB];
+      const int pool0 = (depth + 1) * W * BEAM_KB + w * BEAM_KB;
+      for (int q = 0; q < ns; q++) {
+        const int j = sel[q], src = nn_src[j];
+        const int tk = nn_tok[j] < 0 ? a.eot : nn_tok[j];
+        nodes[pool0 + q] = make_int2(tk, node[src]);
+        o_node[q] = pool0 + q; o_fin[q] = tk == a.eot ? 1 : 0; o_prev[q] = slot_now[src]; o_lp[q] = ssc[q];
+      }
+      for (int q = 0; q < nf; q++) {
+        const int i = fsel[q];
+        o_node[ns + q] = node[i]; o_fin[ns + q] = 1; o_prev[ns + q] = prev[i]; o_lp[ns + q] = fsc[q];
+      }
+      const int n_next = ns + nf;
+      for (int q = 0; q < n_next; q++) { node[q] = o_node[q]; fin[q] = o_fin[q]; prev[q] = o_prev[q]; lp[q] = o_lp[q]; }
+      nb[w] = n_next;
+    }
+    // ---- termination test of the next iteration (beam.rs:23-27) and its live beams ----
+    if (!done[w]) {
+      const int n_b = nb[w];
+      int best = -1;
+      for (int i = 0; i < n_b; i++) {
+        if (!(lp[i] == lp[i])) ctl[BC_ERR] = 1;          // NaN log-probability: the reference panics (partial_cmp().unwrap())
+        if (best < 0 || lp[i] >= lp[best]) best = i;
+      }
+      if (best >= 0 && fin[best]) done[w] = 1;
+      else for (int i = 0; i < n_b; i++) if (!fin[i]) live++;
+    }
+    n_live_w[w] = live;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int i = 0; i < W; i++) { base_w[i] = acc; acc += n_live_w[i]; }
+    const int last = !a.first && depth + 1 >= B.max_depth;      // the step that just ran was the last one allowed
+    if (last) acc = 0;
+    if (!a.first) ctl[BC_DEPTH] = depth + 1;
+    ctl[BC_NLIVE] = acc;
+    if (acc == 0) { ctl[BC_ALLDONE] = 1; if (a.done_flag_host) __hip_atomic_store(a.done_flag_host, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+    n_total = acc;
+  }
+  __syncthreads();
+  const int n_all = n_total;
+  // ---- the next step's state block (what wb_session_step writes on the host) ----
+  const int step_next = a.step_pos + depth + (a.first ? 0 : 1);
+  int* so = a.state_out;
+  for (int e = tid; e < L.total; e += 64) {
+    int v = 0;
+    if (e == ST_N) v = n_all;
+    else if (e == ST_STEP) v = step_next;
+    so[e] = v;
+  }
+  __syncthreads();
+  if (w < W && n_all > 0) {
+    const int* fin = ctl + B.fin + w * BEAM_KB; const int* node = ctl + B.node + w * BEAM_KB;
+    const int* prev = ctl + B.prev_slot + w * BEAM_KB; int* slot_now = ctl + B.slot_now + w * BEAM_KB;
+    const int n_b = ctl[B.nb + w];
+    int slot = base_w[w], j = 0;
+    const bool is_done = ctl[B.done + w] != 0;
+    for (int i = 0; i < n_b; i++) {
+      slot_now[i] = -1;
+      if (is_done || fin[i]) continue;
+      so[L.tok + slot] = nodes[node[i]].x; so[L.parent + slot] = prev[i]; so[L.len + slot] = step_next + 1; so[L.win + slot] = w;
+      so[L.win_slots + w * MAX_BEAMS + j] = slot;
+      slot_now[i] = slot;
+      slot++; j++;
+    }
+    so[L.win_nb + w] = is_done ? 0 : j;
+  }
+}
+
 __global__ void dec_logprob_row_kernel(const float* __restrict__ x, int KS, int64_t plane, int V,
                                        const float* __restrict__ mask, int use_mask,
                                        const float* __restrict__ stats, float* __restrict__ out) {
@@ -1418,6 +1570,10 @@ void launch_dec_topk_merge(hipStream_t st, int* state, int n_max, const float* t
                            int Lmax, int eot, const NextPrep& nx) {
   WB_KLAUNCH(dec_topk_merge_kernel, dim3(n_max), dim3(256), 0, st, state, tstats, n_tiles, k, out_id, out_lp,
                      row_stats, lay, gctl, gtok, Lmax, eot, nx);
+}
+
+void launch_dec_beam_update(hipStream_t st, const BeamChainArgs& a) {
+  WB_KLAUNCH(dec_beam_update_kernel, dim3(1), dim3(64), 0, st, a);
 }
 
 void launch_dec_logprob_row(hipStream_t st, const float* x, int KS, int64_t plane, int V, const float* mask,

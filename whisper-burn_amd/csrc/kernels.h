@@ -15,7 +15,7 @@ enum KernelClass {
   KC_GEMV_LN_QKV, KC_SELF_ATTN, KC_GEMV_OUT, KC_GEMV_LN_CQ, KC_GEMV_LN_MLP1, KC_GEMV_MLP2, KC_CROSS_FUSED,
   // batch mode (more than 8 live rows): one class per kernel of the per-layer chain
   KC_B_RESOLVE_LN, KC_B_GEMM, KC_B_SELF_ATTN, KC_B_CROSS_STREAM, KC_B_CROSS_CHUNK, KC_B_COMBINE, KC_B_GELU_FOLD,
-  KC_B_LOGITS_GEMM, KC_B_TOPK_ROWS, KC_PERSIST,
+  KC_B_LOGITS_GEMM, KC_B_TOPK_ROWS, KC_PERSIST, KC_BEAM_UPDATE,
   KC_COUNT
 };
 void prof_tag(int cls, double algo_bytes);

@@ -35,7 +35,8 @@ static const char* const g_kernel_names[KC_COUNT] = {
     "batch: dec_resolve_ln (fold + LayerNorm)", "batch: split-K MFMA GEMM (decoder weight stream)",
     "batch: dec_self_attn (paged self-KV)", "batch: dec_cross_attn_stream (cached K/V stream)",
     "batch: dec_cross_attn chunked (cached K/V, beams)", "batch: dec_attn_combine", "batch: dec_gelu_fold",
-    "batch: logits MFMA GEMM (E^T stream)", "batch: dec_topk_rows", "dec_persist (flag-chained decode steps)"};
+    "batch: logits MFMA GEMM (E^T stream)", "batch: dec_topk_rows", "dec_persist (flag-chained decode steps)",
+    "dec_beam_update (beam.rs bookkeeping on the device)"};
 struct PendingLaunch { hipEvent_t a, b; int cls; double bytes; };
 static std::mutex g_prof_mu;
 static std::vector<PendingLaunch> g_pending;
@@ -464,16 +465,19 @@ static int dec_split_check(wb_session* s) {
   return WB_OK;
 }
 
+// device-chained beam search: where a step reads its state block and leaves its top-k rows, and the bookkeeping launch behind it
+struct BeamStepIO { const int* state_src; int32_t* topk_id; float* topk_lp; BeamChainArgs upd; };
+
 static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool fuse_ln, int max_nb, bool timed,
-                        bool chained = false, int eot = -1) {
+                        bool chained = false, int eot = -1, const BeamStepIO* bio = nullptr) {
   wb_model* m = s->m;
   const wb_dims& D = m->dims;
   const int d = D.n_text_state, H = D.n_text_head, NL = D.n_text_layer, V = D.n_vocab, S = s->S;
   const StepLayout& L = s->lay;
   hipStream_t st = s->st;
-  const int* hst = reinterpret_cast<const int*>(s->host_block_dev);           // mapped view of state_host
-  int32_t* out_id_dev = reinterpret_cast<int32_t*>(s->host_block_dev + (size_t)L.total * 4);
-  float* out_lp_dev = reinterpret_cast<float*>(s->host_block_dev + (size_t)L.total * 4 + (size_t)S * TOPK_MAX * 4);
+  const int* hst = bio ? bio->state_src : reinterpret_cast<const int*>(s->host_block_dev);   // mapped view of state_host
+  int32_t* out_id_dev = bio ? bio->topk_id : reinterpret_cast<int32_t*>(s->host_block_dev + (size_t)L.total * 4);
+  float* out_lp_dev = bio ? bio->topk_lp : reinterpret_cast<float*>(s->host_block_dev + (size_t)L.total * 4 + (size_t)S * TOPK_MAX * 4);
   const int* dst = s->state.as<int>();
   int* tabs = s->tabs.as<int>();
   float* xb[2] = {s->x.as<float>(), s->x.as<float>() + (size_t)S * d};
@@ -622,6 +626,7 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
       prof_tag(KC_B_TOPK_ROWS, 4.0 * (double)n * V);
       launch_dec_topk_rows(st, s->state.as<int>(), n, s->logits.as<float>(), V, s->mask.as<float>(), use_mask, k, out_id_dev,
                            out_lp_dev, s->row_stats.as<float>(), L, gctl, s->gtok.as<int>(), s->Lmax, eot);
+      if (bio) { prof_tag(KC_BEAM_UPDATE, 8.0 * n * k); launch_dec_beam_update(st, bio->upd); }
       if (timed && tm_logits.on) {
         WB_HIP(hipStreamSynchronize(st));
         tm_logits.collect();
@@ -760,6 +765,7 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
     prof_tag(KC_TOPK_MERGE, 4.0 * n * s->n_tiles_v * TS_STRIDE);
     launch_dec_topk_merge(st, s->state.as<int>(), n, s->tstats.as<float>(), s->n_tiles_v, k, out_id_dev, out_lp_dev,
                           s->row_stats.as<float>(), L, gctl, s->gtok.as<int>(), s->Lmax, eot, nx);
+    if (bio) { prof_tag(KC_BEAM_UPDATE, 8.0 * n * k); launch_dec_beam_update(st, bio->upd); }
     if (timed && tm_logits.on) {
       WB_HIP(hipStreamSynchronize(st));
       tm_logits.collect();
@@ -773,13 +779,13 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
 // Launch one decode step: replay the captured graph for this launch shape (capturing it on first use),
 // or enqueue the kernels eagerly.
 static int launch_step(wb_session* s, int n_launch, int k, int use_mask, bool fuse_ln, int max_nb, bool use_graph,
-                       bool chained, int eot, int reps = 1) {
+                       bool chained, int eot, int reps = 1, const BeamStepIO* bio = nullptr) {
   wb_model* m = s->m;
   hipStream_t st = s->st;
   if (!use_graph) {
     for (int i = 0; i < reps; i++) {
-      WB_TRY(enqueue_step(s, n_launch, k, use_mask, fuse_ln, max_nb, true, chained, eot));
-      if (chained) s->prof_step_off++;
+      WB_TRY(enqueue_step(s, n_launch, k, use_mask, fuse_ln, max_nb, true, chained, eot, bio));
+      if (chained || bio) s->prof_step_off++;
     }
     return WB_OK;
   }
@@ -788,7 +794,7 @@ static int launch_step(wb_session* s, int n_launch, int k, int use_mask, bool fu
   auto mix = [&](uint64_t v) { sig = (sig ^ v) * 1099511628211ull; };
   for (const wb::DevMem* b : {&s->kc, &s->vc, &s->tabs, &s->state, &s->x, &s->h, &s->att, &s->Pqkv, &s->Po, &s->Pq,
                               &s->P1, &s->P2, &s->Pa, &s->Pc, &s->carec, &s->ca, &s->logits, &s->tstats, &s->row_stats, &s->mask, &s->ckv,
-                              &s->win_meta, &s->gctl, &s->gtok, &s->hm})
+                              &s->win_meta, &s->gctl, &s->gtok, &s->hm, &s->bc_ctl, &s->bc_state, &s->bc_topk})
     mix((uint64_t)(uintptr_t)b->p);
   mix((uint64_t)(uintptr_t)s->host_block_dev);
   for (int v : {s->S, s->W, s->Lmax, s->n_chunks, s->max_beams, m->ln_eps_inside_sqrt, eot, (int)m->dec_split_active()})
@@ -797,7 +803,9 @@ static int launch_step(wb_session* s, int n_launch, int k, int use_mask, bool fu
   if (sig != s->buf_sig) { s->clear_graphs(); s->buf_sig = sig; }
   // (reps > 1: device-chained steps read their position from the control block, so one graph can hold
   // several consecutive steps and the host launches once per run)
-  const uint64_t key = ((uint64_t)reps << 48) | ((uint64_t)n_launch << 32) | ((uint64_t)k << 8) | (chained ? 4u : 0u) |
+  // (a beam-chain graph also bakes in the search's constants -- beam size = k, eot via the signature above, max_depth and the
+  // first step's position via the control block layout: session_beam_chain drops the graphs when those change)
+  const uint64_t key = ((uint64_t)reps << 48) | ((uint64_t)n_launch << 32) | ((uint64_t)k << 8) | (bio ? 8u : 0u) | (chained ? 4u : 0u) |
                        ((uint64_t)use_mask << 1) | (fuse_ln ? 1u : 0u);
   auto it = s->graphs.find(key);
   if (it == s->graphs.end()) {
@@ -807,7 +815,7 @@ static int launch_step(wb_session* s, int n_launch, int k, int use_mask, bool fu
     std::lock_guard<std::mutex> lk(capture_mu);
     WB_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
     int rc = WB_OK;
-    for (int i = 0; i < reps && rc == WB_OK; i++) rc = enqueue_step(s, n_launch, k, use_mask, fuse_ln, max_nb, false, chained, eot);
+    for (int i = 0; i < reps && rc == WB_OK; i++) rc = enqueue_step(s, n_launch, k, use_mask, fuse_ln, max_nb, false, chained, eot, bio);
     hipError_t e = hipStreamEndCapture(st, &g);
     WB_TRY(rc);
     WB_HIP(e);
@@ -1039,6 +1047,141 @@ static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_
 // A fresh session (step 0) hands in the whole prompt: the persistent kernel runs the prompt's first prompt_len - 1 positions as
 // forced steps of the same launch (no host round trip between the prompt and the first generated token); the chain of one
 // launch per sublayer (and the persistent kernel's fallback) prefills through host-driven steps first, as before.
+// Beam search with the bookkeeping on the device.  What the host still does: the prompt prefill (P - 1 ordinary steps), the
+// initial control block, enqueueing the steps (whole chunks as one graph launch), one synchronisation per chunk to see whether
+// every window has ended, and the walk back through the node tree at the end.  Results are those of beam_search_windows
+// (transcribe.cpp) step for step: same top-k rows, same f64 sums, same insertion and tie rules.
+int session_beam_chain(wb_session* s, const int32_t* prompt, int P, int k, int eot, int max_depth, int mask_until_len,
+                       int32_t* out_tokens, int32_t row_stride, int32_t* out_lens, bool* handled) {
+  *handled = false;
+  wb_model* m = s->m;
+  const wb_dims& D = m->dims;
+  const int W = s->W, S = s->S, V = D.n_vocab;
+  static const bool enabled = []() { const char* e = getenv("WHISPER_HIP_BEAM_CHAIN"); return !(e && e[0] == '0'); }();
+  if (!enabled || W > 64 || k < 1 || k > TOPK_MAX || k > s->max_beams || max_depth <= 0 || s->step != 0 || P < 1 || W * k > S)
+    return WB_OK;
+  WB_REQUIRE(s->has_mask || mask_until_len < P, WB_ERR_STATE, "wb_session_decode: special mask not set");
+  *handled = true;
+  const int asked_depth = max_depth;
+  max_depth = std::min(max_depth, s->Lmax - (P - 1));
+  WB_HIP(hipSetDevice(m->device));
+  hipStream_t st = s->st;
+  const StepLayout& L = s->lay;
+  {  // prefill: all prompt tokens but the last only feed the KV cache (beam_search_windows does the same)
+    std::vector<int32_t> tok(W), par(W), win(W);
+    for (int t = 0; t < P - 1; t++) {
+      for (int w = 0; w < W; w++) { tok[w] = prompt[t]; par[w] = t == 0 ? -1 : w; win[w] = w; }
+      WB_TRY(wb_session_step(s, tok.data(), par.data(), win.data(), W, 0, 0, nullptr, nullptr));
+    }
+  }
+  const BeamChainLayout bl = make_beam_layout(W, std::max(max_depth, 0));
+  WB_TRY(s->bc_ctl.ensure((size_t)bl.total_ints * 4));
+  WB_TRY(s->bc_state.ensure((size_t)L.total * 4));
+  WB_TRY(s->bc_topk.ensure((size_t)S * TOPK_MAX * 8));
+  std::vector<int> ctl((size_t)bl.total_ints, 0);
+  {
+    double* lp = reinterpret_cast<double*>(ctl.data() + bl.lp);
+    int* nodes = ctl.data() + bl.nodes;
+    for (int w = 0; w < W; w++) {
+      const int nd = w * BEAM_KB;                   // level 0 of the pool
+      ctl[bl.nb + w] = 1;
+      ctl[bl.node + w * BEAM_KB] = nd;
+      nodes[2 * nd] = prompt[P - 1]; nodes[2 * nd + 1] = -1;
+      ctl[bl.fin + w * BEAM_KB] = prompt[P - 1] == eot ? 1 : 0;     // transcribe.rs:235-241
+      ctl[bl.prev_slot + w * BEAM_KB] = P > 1 ? w : -1;
+      lp[w * BEAM_KB] = 0.0;
+    }
+  }
+  WB_HIP(hipMemcpyAsync(s->bc_ctl.p, ctl.data(), ctl.size() * 4, hipMemcpyHostToDevice, st));
+  WB_HIP(hipStreamSynchronize(st));
+  // launch shape: the bucket wb_session_step would pick for the most rows the search can have live (W k)
+  const int n = W * k;
+  static const bool fuse16_enabled = []() {
+    const char* e = getenv("WHISPER_HIP_FUSE16"); const char* f = getenv("WHISPER_HIP_FUSE_SUB"); const char* x = getenv("WHISPER_HIP_FUSE_X");
+    const char* c = getenv("WHISPER_HIP_FUSE_CO");
+    return !(e && e[0] == '0') && !(f && f[0] == '0') && !(x && x[0] == '0') && !(c && c[0] == '1');
+  }();
+  const bool g16 = fuse16_enabled && n > 8 && n <= 16 && S >= 9 && dec_fused_supported(D.n_text_state) &&
+                   D.n_text_state == 64 * D.n_text_head && s->maxC <= CROSS_FUSED_MAX_PASSES * CROSS_FUSED_MAX_C;
+  const int n_launch = n <= 4 ? std::min(4, S) : n <= 8 ? std::min(8, S) : g16 ? std::min(16, S) : S;
+  const bool fuse_ln = n_launch <= 8 || g16;
+  const int max_nb = s->max_beams <= 1 ? 1 : s->max_beams <= 2 ? 2 : s->max_beams <= 4 ? 4 : 8;
+  static const bool graphs_enabled = []() { const char* e = getenv("WHISPER_HIP_GRAPH"); return !(e && e[0] == '0'); }();
+  const bool use_graph = graphs_enabled && !profile().on;
+  BeamStepIO bio;
+  bio.state_src = s->bc_state.as<int>();
+  bio.topk_id = s->bc_topk.as<int32_t>();
+  bio.topk_lp = reinterpret_cast<float*>(s->bc_topk.as<int32_t>() + (size_t)S * TOPK_MAX);
+  bio.upd.ctl = s->bc_ctl.as<int>(); bio.upd.bl = bl; bio.upd.topk_id = bio.topk_id; bio.upd.topk_lp = bio.topk_lp;
+  bio.upd.state_out = s->bc_state.as<int>(); bio.upd.lay = L; bio.upd.k = k; bio.upd.eot = eot; bio.upd.V = V;
+  bio.upd.first = 0; bio.upd.step_pos = P - 1;
+  // the captured graphs bake in the search's constants: drop them when those differ from the last search of this session
+  const uint64_t bsig = ((uint64_t)max_depth << 40) ^ ((uint64_t)(P - 1) << 24) ^ ((uint64_t)k << 16) ^ (uint64_t)(unsigned)eot;
+  if (bsig != s->beam_sig) { s->clear_graphs(); s->beam_sig = bsig; }
+  ScopedTimer tm(st, 3);
+  {
+    BeamChainArgs a0 = bio.upd;
+    a0.first = 1;                                  // termination test + slots of the first step (beam.rs:23-27 runs BEFORE the step)
+    launch_dec_beam_update(st, a0);
+  }
+  const int chunk = 16;
+  int depth = 0;
+  int hdr[BC_HDR] = {0};
+  while (depth < max_depth) {
+    int enq = 0;
+    while (depth + enq < max_depth && enq < chunk) {
+      const int d0 = depth + enq;
+      const int use_mask = (P + d0) <= mask_until_len ? 1 : 0;     // transcribe.rs:271-275
+      const int run = (!use_mask && max_depth - d0 >= chunk && enq == 0) ? chunk : 1;
+      WB_TRY(launch_step(s, n_launch, k, use_mask, fuse_ln, max_nb, use_graph, false, eot, run, &bio));
+      if (profile().on) profile().ms[4] += run;
+      enq += run;
+    }
+    depth += enq;
+    WB_HIP(hipMemcpyAsync(hdr, s->bc_ctl.p, sizeof(hdr), hipMemcpyDeviceToHost, st));
+    WB_HIP(hipStreamSynchronize(st));
+    if (hdr[BC_ALLDONE] || hdr[BC_ERR]) break;     // every window has ended: the kernels of further steps would exit at once
+  }
+  tm.stop();
+  WB_HIP(hipMemcpyAsync(ctl.data(), s->bc_ctl.p, ctl.size() * 4, hipMemcpyDeviceToHost, st));
+  WB_HIP(hipStreamSynchronize(st));
+  tm.collect();
+  if (profile().on) prof_collect();
+  s->prof_step_off = 0;
+  const int steps_done = ctl[BC_DEPTH];
+  s->step += steps_done;
+  s->prev_n = 0; s->prev_len.clear(); s->prev_win.clear();     // (the device-side slots are not mirrored: no host-driven step may follow)
+  s->last_had_logits = 0;
+  WB_TRY(dec_split_check(s));
+  WB_REQUIRE(ctl[BC_ERR] == 0, WB_ERR_STATE, "beam search: NaN log-probability (reference panics)");
+  {
+    const double* lp = reinterpret_cast<const double*>(ctl.data() + bl.lp);
+    const int* nodes = ctl.data() + bl.nodes;
+    bool all_done = true;
+    for (int w = 0; w < W; w++) {   // beam.rs:33-36: the LAST of the equal maxima
+      const int nb = ctl[bl.nb + w];
+      int best = -1;
+      for (int i = 0; i < nb; i++) {
+        WB_REQUIRE(lp[w * BEAM_KB + i] == lp[w * BEAM_KB + i], WB_ERR_STATE, "beam search: NaN log-probability (reference panics)");
+        if (best < 0 || lp[w * BEAM_KB + i] >= lp[w * BEAM_KB + best]) best = i;
+      }
+      std::vector<int32_t> seq;
+      for (int nd = best >= 0 ? ctl[bl.node + w * BEAM_KB + best] : -1; nd >= 0; nd = nodes[2 * nd + 1]) seq.push_back(nodes[2 * nd]);
+      std::reverse(seq.begin(), seq.end());
+      const int len = (P - 1) + (int)seq.size();
+      WB_REQUIRE(len <= row_stride, WB_ERR_ARG, "row_stride too small");
+      int32_t* row = out_tokens + (size_t)w * row_stride;
+      for (int i = 0; i < P - 1; i++) row[i] = prompt[i];
+      for (size_t i = 0; i < seq.size(); i++) row[P - 1 + i] = seq[i];
+      out_lens[w] = len;
+      all_done = all_done && (ctl[bl.done + w] != 0 || (best >= 0 && ctl[bl.fin + w * BEAM_KB + best]));
+    }
+    if (max_depth < asked_depth && !all_done)
+      WB_REQUIRE(false, WB_ERR_SHAPE, "Token sequence length %d must not exceed %d.", s->Lmax + 1, s->Lmax);
+  }
+  return WB_OK;
+}
+
 int session_greedy_chain(wb_session* s, const int32_t* prompt, int eot, int max_depth, int mask_until_len, int prompt_len,
                          int32_t* out_tokens, int32_t row_stride, int32_t* out_lens) {
   wb_model* m = s->m;

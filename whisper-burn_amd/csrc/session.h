@@ -38,6 +38,7 @@ struct wb_session {
   int ps_grid = -1;                                                    // co-resident blocks for this model (-1: not asked yet)
   int n_tiles_v = 0, ct_v = 128;
   int ks_qkv = 1, ksl_qkv = 0, ks_o = 1, ksl_o = 0, ks_1 = 1, ksl_1 = 0, ks_2 = 1, ksl_2 = 0, ks_v = 1, ksl_v = 0;
+  wb::DevMem bc_ctl, bc_state, bc_topk;   // device-chained beam search (decode.h: BeamChainArgs): control block, next step's state, top-k rows
   std::vector<int> prev_len, prev_win;
   int prev_n = 0, step = 0;
   bool has_mask = false, decode_ready = false;
@@ -54,6 +55,7 @@ struct wb_session {
   wb::MelBatch enc_mb;              // ... its input, kept so the pass can be repeated on the exact-f32 kernel
   std::unordered_map<uint64_t, hipGraphExec_t> graphs;   // captured decode steps, keyed by launch shape
   uint64_t buf_sig = 0;                                  // signature of the buffers the graphs were captured with
+  uint64_t beam_sig = 0;                                 // ... and of the constants of the last device-chained beam search
   void clear_graphs();
   ~wb_session();
 };
@@ -88,6 +90,10 @@ int session_encode_pcm(wb_session* s, const float* pcm, int64_t n_pcm, const int
 int session_enc_guard_resolve(wb_session* s, bool* reencoded);
 void session_rewind(wb_session* s);      // back to step 0 over the same (re-)encoded window batch
 int session_reserve(wb_session* s, int max_len);
+// beam search with the bookkeeping on the device (decode.hip: dec_beam_update_kernel): *handled = false when the shape is not
+// served (the caller runs the host-driven search)
+int session_beam_chain(wb_session* s, const int32_t* prompt, int prompt_len, int beam_size, int eot, int max_depth,
+                       int mask_until_len, int32_t* out_tokens, int32_t row_stride, int32_t* out_lens, bool* handled);
 int session_greedy_chain(wb_session* s, const int32_t* prompt, int eot, int max_depth, int mask_until_len, int prompt_len,
                          int32_t* out_tokens, int32_t row_stride, int32_t* out_lens);
 }  // namespace wb

@@ -307,6 +307,18 @@ extern "C" int wb_session_decode(wb_session* s, const wb_decode_params* p, int32
     return session_greedy_chain(s, prompt, p->tok_end_of_text, p->max_depth, p->mask_until_len, 4, out_tokens,
                                 row_stride, out_lens);
   }
+  if (s->step == 0) {
+    // beam search with the bookkeeping on the device (session.cpp: session_beam_chain; WHISPER_HIP_BEAM_CHAIN=0: host-driven)
+    const int V = s->m->dims.n_vocab;
+    const int32_t prompt[4] = {p->tok_start_of_transcript, p->tok_language, p->tok_transcribe, p->tok_no_timestamps};
+    for (int t : prompt) WB_REQUIRE(t >= 0 && t < V, WB_ERR_ARG, "prompt token %d out of range", t);
+    WB_REQUIRE(p->tok_end_of_text >= 0 && p->tok_end_of_text < V, WB_ERR_ARG, "end-of-text token out of range");
+    WB_REQUIRE(row_stride >= 4 + p->max_depth, WB_ERR_ARG, "row_stride %d < %d", row_stride, 4 + p->max_depth);
+    bool handled = false;
+    WB_TRY(session_beam_chain(s, prompt, 4, p->beam_size, p->tok_end_of_text, p->max_depth, p->mask_until_len, out_tokens,
+                              row_stride, out_lens, &handled));
+    if (handled) return WB_OK;
+  }
   return beam_search_windows(p, s->W, s->m->dims.n_vocab, s->S, session_step_thunk, s, out_tokens, row_stride, out_lens);
 }
 
