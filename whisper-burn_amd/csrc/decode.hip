@@ -411,6 +411,160 @@ __global__ __launch_bounds__(256, (MR >= 8 && DPL >= 16) ? 1 : 2) void dec_gemv_
   }
 }
 
+// ---- logits for 9 - 16 live rows on the matrix cores (beam search over a 30 s chunk: 3 windows x 5 beams = 15 rows) -------
+// The vector-pipe GEMV above spends 16 x 128 x d FMAs per block with an LDS read per four of them: 41 us per step for
+// tiny.en's 80 MB of E^T even without its prologue (profiles/r05_k_fold16.txt).  Same launch geometry (one block per
+// 128-column tile), same prologue (fold of the pending planes + LayerNorm, one wave per row), same tile statistics and
+// output planes -- but the product runs on v_mfma_f32_16x16x4_f32 (exact f32, the skinny weight-stream kernel's scheme,
+// decode_batch.hip): a wave owns 64 columns over half of K, one float4 per lane = 4 K-rows x 64 columns per load, component c
+// of the float4 is the B operand of accumulator c (columns 4 j + c), the 16 rows sit k-major in LDS (A operand of lane l for
+// K-rows k .. k + 3 is word 16 k + l: conflict-free).  The two K halves of a column strip meet in LDS in fixed order.
+typedef float lg_f32x4 __attribute__((ext_vector_type(4)));
+template <int DPL>
+__global__ __launch_bounds__(256, 2) void dec_logits_mfma16_kernel(GemvArgs a) {
+  constexpr int MR = 16, CT = 128, KMAX = 64 * DPL;
+  __shared__ __attribute__((aligned(16))) float xT[KMAX * MR];          // [k][16]; later red[2][MR][CT] (KMAX >= 256)
+  __shared__ float tilev[MR][CT];
+  static_assert(KMAX * MR >= 2 * MR * CT, "reduction buffer must fit");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ct = a.ct > 0 ? a.ct : CT;
+  const int n0 = blockIdx.x * ct;
+  const int d = a.K;                                 // a multiple of 64; the host guarantees d % 8 == 0 and d <= KMAX
+  const int n_rows = a.st[ST_N];
+  const int strip = wave & 1, khalf = wave >> 1;
+  const int kh = d >> 1;                             // K-rows per wave (a multiple of 4: d % 8 == 0)
+  const int krow = lane >> 4, cq = lane & 15;
+  const int col0 = strip * 64 + 4 * cq;              // first of this lane's four columns inside the tile
+  const bool col_ok = (n0 + col0) < a.ldw && col0 < ct;
+  const float* bp = a.W + (int64_t)(khalf * kh + krow) * a.ldw + n0 + (col_ok ? col0 : 0);
+  constexpr int LD = 24;                             // float4 loads a lane keeps in flight (96 K-rows)
+  const int nld = kh >> 2;
+  float4 bw[LD];
+#pragma unroll
+  for (int t = 0; t < LD; t++)
+    if (t < nld) bw[t] = *reinterpret_cast<const float4*>(bp + (int64_t)(4 * t) * a.ldw);
+  if (n_rows == 0) return;
+  // ---- prologue: x + (bias + pending planes), LayerNorm, staged k-major (dec_gemv_kernel's LN prologue) ----
+  {
+    const bool writer = blockIdx.x == 0;
+#pragma unroll 1
+    for (int r = wave; r < MR; r += 4) {
+      if (r >= n_rows) {
+        for (int c = lane; c < d; c += 64) xT[c * MR + r] = 0.f;
+        continue;
+      }
+      int co[DPL];
+#pragma unroll
+      for (int i = 0; i < DPL; i++) co[i] = lane + (64 * i < d ? 64 * i : 0);
+      float gv[DPL], bv[DPL], v[DPL];
+      const float* xr = a.src + (int64_t)r * d;
+#pragma unroll
+      for (int i = 0; i < DPL; i++) { gv[i] = a.ln_g[co[i]]; bv[i] = a.ln_b[co[i]]; v[i] = xr[co[i]]; }
+      if (a.KSp > 0) {
+        float acc[DPL];
+#pragma unroll
+        for (int i = 0; i < DPL; i++) acc[i] = a.pbias[co[i]];
+        const float* pp = a.pend + (int64_t)r * d;
+        const int64_t plane = (int64_t)a.S * d;
+        constexpr int CH = DPL <= 6 ? 8 : 4;
+        for (int sp = 0; sp < a.KSp; sp += CH) {
+          float t[CH][DPL];
+#pragma unroll
+          for (int j = 0; j < CH; j++) {
+            const float* pj = pp + (int64_t)min(sp + j, a.KSp - 1) * plane;
+#pragma unroll
+            for (int i = 0; i < DPL; i++) t[j][i] = pj[co[i]];
+          }
+#pragma unroll
+          for (int j = 0; j < CH; j++) {
+            const bool live = sp + j < a.KSp;
+#pragma unroll
+            for (int i = 0; i < DPL; i++) acc[i] += live ? t[j][i] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < DPL; i++) v[i] = v[i] + acc[i];
+      }
+      float sm = 0.f;
+#pragma unroll
+      for (int i = 0; i < DPL; i++) {
+        if (64 * i < d) { sm += v[i]; if (writer) a.x_out[(int64_t)r * d + co[i]] = v[i]; }
+      }
+      const float mean = wave_sum(sm) / (float)d;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < DPL; i++) {
+        if (64 * i < d) { const float t = v[i] - mean; q += t * t; }
+      }
+      const float var = wave_sum(q) / (float)d;
+      const float denom = a.ln_inside ? sqrtf(var + a.ln_eps) : (sqrtf(var) + a.ln_eps);
+#pragma unroll
+      for (int i = 0; i < DPL; i++) {
+        const int c = lane + 64 * i;
+        if (c < d) xT[c * MR + r] = (v[i] - mean) / denom * gv[i] + bv[i];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- product: 4 accumulators (columns 4 j + c of the strip), K-rows in ascending order ----
+  lg_f32x4 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) acc[c] = lg_f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* ap = xT + (khalf * kh) * MR + lane;
+  for (int t0 = 0; t0 < nld; t0 += LD) {
+#pragma unroll
+    for (int t = 0; t < LD; t++) {
+      if (t0 + t < nld) {
+        const float av = ap[(4 * (t0 + t)) * MR];
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[t].x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[t].y, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[t].z, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[t].w, acc[3], 0, 0, 0);
+      }
+    }
+    if (t0 + LD < nld) {
+#pragma unroll
+      for (int t = 0; t < LD; t++)
+        if (t0 + LD + t < nld) bw[t] = *reinterpret_cast<const float4*>(bp + (int64_t)(4 * (t0 + LD + t)) * a.ldw);
+    }
+  }
+  __syncthreads();                                   // everyone is done with the staged rows: reuse them as red[2][MR][CT]
+  // accumulator c, register i of lane l: row 4 (l / 16) + i, column 4 (l % 16) + c of the strip
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    *reinterpret_cast<float4*>(&xT[(khalf * MR + 4 * krow + i) * CT + col0]) = make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
+  __syncthreads();
+  for (int e = tid; e < MR * CT; e += 256) {
+    const int r = e / CT, c = e - r * CT;
+    const int col = n0 + c;
+    float v = -INFINITY;
+    if (r < n_rows && col < a.N && c < ct) {
+      v = xT[(0 * MR + r) * CT + c] + xT[(1 * MR + r) * CT + c];
+      a.P[(int64_t)r * a.N + col] = v;
+      if (a.use_mask) v += a.mask[col];              // transcribe.rs:271-275
+    }
+    tilev[r][c] = v;
+  }
+  __syncthreads();
+  // per-tile log-softmax statistics and top-k candidates of each row (one wave per row; dec_gemv_kernel's epilogue)
+  for (int r = wave; r < MR; r += 4) {
+    if (r >= n_rows) continue;
+    float v0 = tilev[r][lane], v1 = tilev[r][lane + 64];
+    const float m = wave_max(fmaxf(v0, v1));
+    const float se = m > -INFINITY ? wave_sum(expf(v0 - m) + expf(v1 - m)) : 0.f;
+    float* ts = a.tstats + ((int64_t)r * gridDim.x + blockIdx.x) * TS_STRIDE;
+    if (lane == 0) { ts[0] = m; ts[1] = se; }
+    for (int j = 0; j < a.topk; j++) {
+      float bv; int bi;
+      if (better(v0, lane, v1, lane + 64)) { bv = v0; bi = lane; } else { bv = v1; bi = lane + 64; }
+      wave_argmax(bv, bi);
+      if (lane == 0) { ts[2 + 2 * j] = bv; ts[3 + 2 * j] = __int_as_float(n0 + bi); }
+      if (bi == lane) v0 = -INFINITY;
+      if (bi == lane + 64) v1 = -INFINITY;
+    }
+  }
+}
+
 // device-chained greedy: the argmax feeds the next step, tokens stay on the device
 // When the last unfinished window ends, the step state is blanked (ST_N = 0): the host enqueues decode chunks ahead
 // of reading the finished flags, and every kernel of an already-enqueued step then exits at its first instruction.
@@ -1502,6 +1656,13 @@ void launch_dec_gemv(hipStream_t st, const GemvArgs& a, int n_rows_hint, bool st
     // 9 - 16 live rows on the fused sublayer path (d <= 512): ONE 16-row pass -- two row groups of 8 stream E^T twice
     // (52.7 us per step for tiny.en's 80 MB against 18 us at <= 8 rows: profiles/r05_d_beam5_fused16.txt)
     grid.z = 1;
+    // ... on the matrix cores (exact-f32 MFMA, dec_logits_mfma16_kernel) unless WHISPER_HIP_LOGITS_MFMA=0
+    static const bool mfma_enabled = []() { const char* e = getenv("WHISPER_HIP_LOGITS_MFMA"); return !(e && e[0] == '0'); }();
+    if (mfma_enabled && a.KS == 1 && a.K % 64 == 0 && a.K >= 256 && ct == GV_CT_LOGITS && a.pro == PRO_LN) {
+      if (a.K <= 384) launch_gemv_k(dec_logits_mfma16_kernel<6>, st, grid, a);
+      else launch_gemv_k(dec_logits_mfma16_kernel<8>, st, grid, a);
+      return;
+    }
     if (a.K <= 384) launch_gemv_k(dec_gemv_kernel<16, 512, 6, true, true, GV_CT_LOGITS>, st, grid, a);
     else launch_gemv_k(dec_gemv_kernel<16, 512, 8, true, true, GV_CT_LOGITS>, st, grid, a);
     return;
