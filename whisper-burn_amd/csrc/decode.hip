@@ -1436,13 +1436,30 @@ __global__ __launch_bounds__(1024) void dec_topk_rows_kernel(int* __restrict__ s
   }
 }
 
-// One thread per window restates transcribe.cpp's beam_search_windows loop body (which restates beam.rs) on the device.
-// Every comparison, insertion rule and f64 sum is the host code's: get_top_elements inserts before the first stored score >=
-// the new one and evicts index 0 (beam.rs:81-110), max_by takes the LAST of equal maxima (beam.rs:23-27, :33-36), a beam's
-// score is log_prob + (double)lp (transcribe.rs:299).
-__global__ __launch_bounds__(64) void dec_beam_update_kernel(BeamChainArgs a) {
-  __shared__ int n_live_w[64];
-  __shared__ int base_w[64];
+// One WAVE per window restates transcribe.cpp's beam_search_windows loop body (which restates beam.rs) on the device.
+//
+// beam.rs's get_top_elements is a streaming insertion (ascending list; insert before the first stored score >= the new one;
+// evict index 0 when over capacity; skip when full and score < min).  Its result is a function of the sequence only through
+// a total order: the survivors are the `num` best by (score descending, position in the sequence ascending) -- on a tie at
+// the boundary the later element is inserted at index 0 and evicted at once, so the earlier one survives -- and the list ends
+// up ascending by score with the LATER of two equal scores in front.  Hence, with rank = #elements that beat an element in
+// that order, element e survives iff rank < num and sits at index (n_kept - 1 - rank).  That is what the lanes compute, one
+// candidate each, instead of replaying the insertion serially (the first version of this kernel did, one thread per window:
+// 74 us per step at tiny.en, all of it dependent memory round trips and scratch traffic -- profiles/r06_b_bench.json).
+// A beam's k continuations enter the sequence sorted by token id (transcribe.cpp / transcribe.rs:286-304 produce them in id
+// order), and all k survive the per-beam pass (it holds exactly k), ordered by that same rule.  Scores are f64:
+// log_prob + (double)lp (transcribe.rs:299).  max_by takes the LAST of equal maxima (beam.rs:23-27, :33-36).
+__global__ __launch_bounds__(1024) void dec_beam_update_kernel(BeamChainArgs a) {
+  constexpr int NW = 16;                              // waves per block = windows per pass
+  __shared__ int w_node[NW][BEAM_KB], w_fin[NW][BEAM_KB], w_prev[NW][BEAM_KB], w_slot[NW][BEAM_KB];
+  __shared__ double w_lp[NW][BEAM_KB];
+  __shared__ int c_tok[NW][64], c_seq[NW][64];
+  __shared__ double c_sc[NW][64];
+  __shared__ int o_node[NW][BEAM_KB], o_fin[NW][BEAM_KB], o_prev[NW][BEAM_KB], o_tok[NW][BEAM_KB];
+  __shared__ double o_lp[NW][BEAM_KB];
+  // what the state block of the next step needs, kept for every window of the batch (<= 64)
+  __shared__ int g_tok[64][BEAM_KB], g_fin[64][BEAM_KB], g_prev[64][BEAM_KB];
+  __shared__ int g_nb[64], g_done[64], n_live_w[64], base_w[64];
   __shared__ int n_total;
   const BeamChainLayout& B = a.bl;
   const StepLayout& L = a.lay;
@@ -1450,104 +1467,127 @@ __global__ __launch_bounds__(64) void dec_beam_update_kernel(BeamChainArgs a) {
   double* lpv = reinterpret_cast<double*>(ctl + B.lp);
   int2* nodes = reinterpret_cast<int2*>(ctl + B.nodes);
   const int W = B.W, k = a.k;
-  const int depth = ctl[BC_DEPTH];            // decode steps completed before this call's step
-  const int tid = threadIdx.x;
-  // (windows beyond 64 per batch never reach this path: the host caps the batch)
-  const int w = tid;
-  int live = 0;
-  if (w < W) {
-    int* nb = ctl + B.nb; int* done = ctl + B.done;
-    int* node = ctl + B.node + w * BEAM_KB; int* fin = ctl + B.fin + w * BEAM_KB;
-    int* prev = ctl + B.prev_slot + w * BEAM_KB; int* slot_now = ctl + B.slot_now + w * BEAM_KB;
-    double* lp = lpv + w * BEAM_KB;
-    if (!a.first && !done[w]) {
-      // ---- beam_search_step (beam.rs:39-79) on the step that just ran ----
-      // new beams in generation order: for each unfinished beam its k continuations, ascending by score (get_top_elements)
-      int nn_tok[TOPK_MAX * TOPK_MAX], nn_src[TOPK_MAX * TOPK_MAX]; double nn_lp[TOPK_MAX * TOPK_MAX];
-      int n_new = 0;
-      int f_idx[BEAM_KB]; int n_fin = 0;
-      const int n_b = nb[w];
-      for (int i = 0; i < n_b; i++) {
-        if (fin[i]) { f_idx[n_fin++] = i; continue; }
-        const int slot = slot_now[i];
-        // the k best continuations by (log-prob desc, id asc) cover every element the V-wide insertion scan can retain;
-        // replay that scan on them in id order
-        int ct[TOPK_MAX]; double cs[TOPK_MAX];
-        for (int j = 0; j < k; j++) {
-          ct[j] = a.topk_id[slot * TOPK_MAX + j]; cs[j] = lp[i] + (double)a.topk_lp[slot * TOPK_MAX + j];
-          // a row without k finite candidates (NaN logits) leaves 0x7fffffff in its list: never an embedding index -- the
-          // host fails the call (BC_ERR); distinct negative stand-ins keep the id sort below well-defined
-          if ((unsigned)ct[j] >= (unsigned)a.V) { ctl[BC_ERR] = 1; ct[j] = -1 - j; }
-        }
-        for (int x = 1; x < k; x++) {                    // insertion sort by token id (ids are distinct)
-          const int t = ct[x]; const double sc = cs[x]; int y = x - 1;
-          while (y >= 0 && ct[y] > t) { ct[y + 1] = ct[y]; cs[y + 1] = cs[y]; y--; }
-          ct[y + 1] = t; cs[y + 1] = sc;
-        }
-        int top[TOPK_MAX]; double tsc[TOPK_MAX]; int nt = 0;
-        for (int j = 0; j < k; j++) {                    // get_top_elements(conts, k)
-          const double sc = cs[j];
-          if (nt == k && sc < tsc[0]) continue;
-          int idx = nt;
-          for (int q = 0; q < nt; q++) if (tsc[q] >= sc) { idx = q; break; }
-          for (int q = nt; q > idx; q--) { top[q] = top[q - 1]; tsc[q] = tsc[q - 1]; }
-          top[idx] = j; tsc[idx] = sc; nt++;
-          if (nt > k) { for (int q = 0; q + 1 < nt; q++) { top[q] = top[q + 1]; tsc[q] = tsc[q + 1]; } nt--; }
-        }
-        for (int q = 0; q < nt; q++) { nn_tok[n_new] = ct[top[q]]; nn_lp[n_new] = tsc[q]; nn_src[n_new] = i; n_new++; }
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int depth = ctl[BC_DEPTH];                    // decode steps completed before this call's step
+  for (int w0 = 0; w0 < W; w0 += NW) {                // (block-uniform trip count: every wave meets every barrier)
+    const int w = w0 + wv;
+    const bool act = w < W;
+    const int nb = act ? ctl[B.nb + w] : 0;
+    const int was_done = act ? ctl[B.done + w] : 1;
+    // ---- the window's beams: one round trip ----
+    int my_fin = 0; double my_lp = 0.0;
+    if (lane < BEAM_KB) {
+      int nd = -1, fn = 0, pv = -1, sl = -1; double lp = 0.0;
+      if (act && lane < nb) {
+        const int o = w * BEAM_KB + lane;
+        nd = ctl[B.node + o]; fn = ctl[B.fin + o]; pv = ctl[B.prev_slot + o]; sl = ctl[B.slot_now + o]; lp = lpv[o];
       }
-      // next = top-k of the new beams (ascending) ++ top-k of the finished ones (ascending)
-      int sel[TOPK_MAX + 1]; double ssc[TOPK_MAX + 1]; int ns = 0;
-      for (int j = 0; j < n_new; j++) {
-        const double sc = nn_lp[j];
-        if (ns == k && sc < ssc[0]) continue;
-        int idx = ns;
-        for (int q = 0; q < ns; q++) if (ssc[q] >= sc) { idx = q; break; }
-        for (int q = ns; q > idx; q--) { sel[q] = sel[q - 1]; ssc[q] = ssc[q - 1]; }
-        sel[idx] = j; ssc[idx] = sc; ns++;
-        if (ns > k) { for (int q = 0; q + 1 < ns; q++) { sel[q] = sel[q + 1]; ssc[q] = ssc[q + 1]; } ns--; }
-      }
-      int fsel[TOPK_MAX + 1]; double fsc[TOPK_MAX + 1]; int nf = 0;
-      for (int j = 0; j < n_fin; j++) {
-        const double sc = lp[f_idx[j]];
-        if (nf == k && sc < fsc[0]) continue;
-        int idx = nf;
-        for (int q = 0; q < nf; q++) if (fsc[q] >= sc) { idx = q; break; }
-        for (int q = nf; q > idx; q--) { fsel[q] = fsel[q - 1]; fsc[q] = fsc[q - 1]; }
-        fsel[idx] = f_idx[j]; fsc[idx] = sc; nf++;
-        if (nf > k) { for (int q = 0; q + 1 < nf; q++) { fsel[q] = fsel[q + 1]; fsc[q] = fsc[q + 1]; } nf--; }
-      }
-      // write the next generation (reads of the old arrays first: they are overwritten in place)
-      int o_node[BEAM_KB], o_fin[BEAM_KB], o_prev[BEAM_KB]; double o_lp[BEAM_KB];
-      const int pool0 = (depth + 1) * W * BEAM_KB + w * BEAM_KB;
-      for (int q = 0; q < ns; q++) {
-        const int j = sel[q], src = nn_src[j];
-        const int tk = nn_tok[j] < 0 ? a.eot : nn_tok[j];
-        nodes[pool0 + q] = make_int2(tk, node[src]);
-        o_node[q] = pool0 + q; o_fin[q] = tk == a.eot ? 1 : 0; o_prev[q] = slot_now[src]; o_lp[q] = ssc[q];
-      }
-      for (int q = 0; q < nf; q++) {
-        const int i = fsel[q];
-        o_node[ns + q] = node[i]; o_fin[ns + q] = 1; o_prev[ns + q] = prev[i]; o_lp[ns + q] = fsc[q];
-      }
-      const int n_next = ns + nf;
-      for (int q = 0; q < n_next; q++) { node[q] = o_node[q]; fin[q] = o_fin[q]; prev[q] = o_prev[q]; lp[q] = o_lp[q]; }
-      nb[w] = n_next;
+      w_node[wv][lane] = nd; w_fin[wv][lane] = fn; w_prev[wv][lane] = pv; w_slot[wv][lane] = sl; w_lp[wv][lane] = lp;
+      my_fin = fn; my_lp = lp;
     }
-    // ---- termination test of the next iteration (beam.rs:23-27) and its live beams ----
-    if (!done[w]) {
-      const int n_b = nb[w];
-      int best = -1;
-      for (int i = 0; i < n_b; i++) {
-        if (!(lp[i] == lp[i])) ctl[BC_ERR] = 1;          // NaN log-probability: the reference panics (partial_cmp().unwrap())
-        if (best < 0 || lp[i] >= lp[best]) best = i;
-      }
-      if (best >= 0 && fin[best]) done[w] = 1;
-      else for (int i = 0; i < n_b; i++) if (!fin[i]) live++;
+    const bool stepA = act && !a.first && !was_done;
+    // order of the unfinished / finished beams among themselves (list order)
+    const unsigned long long unf_mask = __ballot(lane < nb && !my_fin), fin_mask = __ballot(lane < nb && my_fin);
+    const int n_unf = __popcll(unf_mask), n_fin = __popcll(fin_mask);
+    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    __syncthreads();
+    // ---- candidates: lane c = (b_ord, j) -> the j-th top-k entry of the b_ord-th unfinished beam ----
+    int tok = -1, src = -1; double sc = 0.0; bool cand = false;
+    if (stepA && lane < n_unf * k) {
+      const int b_ord = lane / k, j = lane - b_ord * k;
+      // the b_ord-th set bit of unf_mask
+      unsigned long long mm = unf_mask; for (int t = 0; t < b_ord; t++) mm &= mm - 1;
+      src = __ffsll((long long)mm) - 1;
+      const int slot = w_slot[wv][src];
+      tok = a.topk_id[slot * TOPK_MAX + j];
+      sc = w_lp[wv][src] + (double)a.topk_lp[slot * TOPK_MAX + j];      // transcribe.rs:299
+      // a row without k finite candidates (NaN logits) leaves 0x7fffffff in its list: never an embedding index -- the host
+      // fails the call (BC_ERR); distinct negative stand-ins keep the id order below well-defined
+      if ((unsigned)tok >= (unsigned)a.V) { ctl[BC_ERR] = 1; tok = -1 - j; }
+      if (!(sc == sc)) ctl[BC_ERR] = 1;
+      cand = true;
     }
-    n_live_w[w] = live;
+    c_tok[wv][lane] = tok; c_sc[wv][lane] = sc;
+    __syncthreads();
+    int seq = 0x7fffffff;
+    if (cand) {
+      // position inside the beam's own pass: ascending score, the later (larger id) of two equal scores in front
+      const int b_ord = lane / k;
+      int pos = 0;
+      for (int j2 = 0; j2 < k; j2++) {
+        const double s2 = c_sc[wv][b_ord * k + j2]; const int t2 = c_tok[wv][b_ord * k + j2];
+        if (s2 < sc || (s2 == sc && t2 > tok)) pos++;
+      }
+      seq = b_ord * k + pos;
+    }
+    c_seq[wv][lane] = seq;
+    __syncthreads();
+    const int n_cand = stepA ? n_unf * k : 0;
+    const int ns = min(k, n_cand), nf = stepA ? min(k, n_fin) : 0;
+    if (cand) {
+      int rank = 0;
+      for (int c2 = 0; c2 < n_cand; c2++) {
+        const double s2 = c_sc[wv][c2];
+        if (s2 > sc || (s2 == sc && c_seq[wv][c2] < seq)) rank++;
+      }
+      if (rank < k) {
+        const int q = ns - 1 - rank;
+        const int tk = tok < 0 ? a.eot : tok;
+        const int pool = (depth + 1) * W * BEAM_KB + w * BEAM_KB + q;
+        nodes[pool] = make_int2(tk, w_node[wv][src]);
+        o_node[wv][q] = pool; o_fin[wv][q] = tk == a.eot ? 1 : 0; o_prev[wv][q] = w_slot[wv][src]; o_lp[wv][q] = sc; o_tok[wv][q] = tk;
+      }
+    }
+    if (stepA && lane < nb && my_fin) {                 // finished beams: carried, the best k of them (beam.rs:56-57, :75-78)
+      const int f_ord = __popcll(fin_mask & below);
+      int rank = 0;
+      for (int i2 = 0; i2 < nb; i2++) {
+        if (!w_fin[wv][i2] || i2 == lane) continue;
+        const double s2 = w_lp[wv][i2];
+        const int f2 = __popcll(fin_mask & (i2 == 0 ? 0ull : (~0ull >> (64 - i2))));
+        if (s2 > my_lp || (s2 == my_lp && f2 < f_ord)) rank++;
+      }
+      if (rank < k) {
+        const int q = ns + (nf - 1 - rank);
+        o_node[wv][q] = w_node[wv][lane]; o_fin[wv][q] = 1; o_prev[wv][q] = w_prev[wv][lane]; o_lp[wv][q] = my_lp; o_tok[wv][q] = a.eot;
+      }
+    }
+    __syncthreads();
+    // ---- the next generation (or, with no step behind this call / an ended window, the current one) ----
+    const int n_next = stepA ? ns + nf : nb;
+    int cur_fin = 0; double cur_lp = 0.0;
+    if (act && lane < BEAM_KB) {
+      int nd, fn, pv, tk; double lp;
+      if (stepA) { nd = o_node[wv][lane]; fn = o_fin[wv][lane]; pv = o_prev[wv][lane]; lp = o_lp[wv][lane]; tk = o_tok[wv][lane]; }
+      else { nd = w_node[wv][lane]; fn = w_fin[wv][lane]; pv = w_prev[wv][lane]; lp = w_lp[wv][lane]; tk = (lane < nb && nd >= 0) ? nodes[nd].x : 0; }
+      if (lane < n_next) {
+        if (stepA) {
+          const int o = w * BEAM_KB + lane;
+          ctl[B.node + o] = nd; ctl[B.fin + o] = fn; ctl[B.prev_slot + o] = pv; lpv[o] = lp;
+        }
+        cur_fin = fn; cur_lp = lp;
+        if (!(lp == lp)) ctl[BC_ERR] = 1;             // NaN log-probability: the reference panics (partial_cmp().unwrap())
+      }
+      g_tok[w][lane] = tk; g_fin[w][lane] = fn; g_prev[w][lane] = pv;
+    }
+    // ---- termination test of the next iteration (beam.rs:23-27): the LAST of the equal maxima ----
+    double best_lp = cur_lp; int best_i = (act && lane < n_next) ? lane : -1;
+#pragma unroll
+    for (int off = 1; off < BEAM_KB; off <<= 1) {      // butterfly over the first BEAM_KB lanes (the rest hold -1)
+      const double o_l = __shfl_xor(best_lp, off); const int o_i = __shfl_xor(best_i, off);
+      if (o_i >= 0 && (best_i < 0 || o_l > best_lp || (o_l == best_lp && o_i > best_i))) { best_lp = o_l; best_i = o_i; }
+    }
+    best_i = __shfl(best_i, 0);
+    const int best_fin = best_i >= 0 ? __shfl(cur_fin, best_i) : 0;
+    const int now_done = was_done || (best_i >= 0 && best_fin);
+    const int live = now_done ? 0 : __popcll(__ballot(lane < n_next && !cur_fin));
+    if (act && lane == 0) {
+      if (stepA) ctl[B.nb + w] = n_next;
+      if (now_done && !was_done) ctl[B.done + w] = 1;
+      g_nb[w] = n_next; g_done[w] = now_done; n_live_w[w] = live;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   if (tid == 0) {
     int acc = 0;
     for (int i = 0; i < W; i++) { base_w[i] = acc; acc += n_live_w[i]; }
@@ -1563,28 +1603,29 @@ __global__ __launch_bounds__(64) void dec_beam_update_kernel(BeamChainArgs a) {
   // ---- the next step's state block (what wb_session_step writes on the host) ----
   const int step_next = a.step_pos + depth + (a.first ? 0 : 1);
   int* so = a.state_out;
-  for (int e = tid; e < L.total; e += 64) {
+  for (int e = tid; e < L.total; e += 1024) {
     int v = 0;
     if (e == ST_N) v = n_all;
     else if (e == ST_STEP) v = step_next;
     so[e] = v;
   }
   __syncthreads();
-  if (w < W && n_all > 0) {
-    const int* fin = ctl + B.fin + w * BEAM_KB; const int* node = ctl + B.node + w * BEAM_KB;
-    const int* prev = ctl + B.prev_slot + w * BEAM_KB; int* slot_now = ctl + B.slot_now + w * BEAM_KB;
-    const int n_b = ctl[B.nb + w];
-    int slot = base_w[w], j = 0;
-    const bool is_done = ctl[B.done + w] != 0;
-    for (int i = 0; i < n_b; i++) {
-      slot_now[i] = -1;
-      if (is_done || fin[i]) continue;
-      so[L.tok + slot] = nodes[node[i]].x; so[L.parent + slot] = prev[i]; so[L.len + slot] = step_next + 1; so[L.win + slot] = w;
-      so[L.win_slots + w * MAX_BEAMS + j] = slot;
-      slot_now[i] = slot;
-      slot++; j++;
+  if (n_all > 0) {
+    for (int w = wv; w < W; w += NW) {
+      const int nb = g_nb[w];
+      const bool is_done = g_done[w] != 0;
+      const bool lv = lane < nb && !is_done && !g_fin[w][lane];
+      const unsigned long long lm = __ballot(lv);
+      const int j = __popcll(lm & (lane == 0 ? 0ull : (~0ull >> (64 - lane))));
+      int slot = -1;
+      if (lv) {
+        slot = base_w[w] + j;
+        so[L.tok + slot] = g_tok[w][lane]; so[L.parent + slot] = g_prev[w][lane]; so[L.len + slot] = step_next + 1; so[L.win + slot] = w;
+        so[L.win_slots + w * MAX_BEAMS + j] = slot;
+      }
+      if (lane < nb) ctl[B.slot_now + w * BEAM_KB + lane] = slot;
+      if (lane == 0) so[L.win_nb + w] = is_done ? 0 : __popcll(lm);
     }
-    so[L.win_nb + w] = is_done ? 0 : j;
   }
 }
 
@@ -1734,7 +1775,7 @@ void launch_dec_topk_merge(hipStream_t st, int* state, int n_max, const float* t
 }
 
 void launch_dec_beam_update(hipStream_t st, const BeamChainArgs& a) {
-  WB_KLAUNCH(dec_beam_update_kernel, dim3(1), dim3(64), 0, st, a);
+  WB_KLAUNCH(dec_beam_update_kernel, dim3(1), dim3(1024), 0, st, a);
 }
 
 void launch_dec_logprob_row(hipStream_t st, const float* x, int KS, int64_t plane, int V, const float* mask,

@@ -397,7 +397,8 @@ int wb_session_begin_mel(wb_model* m, const float* mel, const int32_t* T, int n_
     src += (size_t)80 * T[w];
   }
   int rc = s->mel.ensure(host.size() * 4);
-  if (rc == WB_OK && hipMemcpy(s->mel.p, host.data(), host.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+  if (rc == WB_OK && (hipMemcpyAsync(s->mel.p, host.data(), host.size() * 4, hipMemcpyHostToDevice, s->st) != hipSuccess ||
+                      hipStreamSynchronize(s->st) != hipSuccess)) {
     set_error("mel upload failed");
     rc = WB_ERR_HIP;
   }
@@ -438,7 +439,10 @@ int wb_session_set_special_mask(wb_session* s, const uint8_t* is_special) {
   for (int i = 0; i < V; i++) mk[i] = is_special[i] ? -INFINITY : 0.f;   // transcribe.rs:244
   WB_HIP(hipSetDevice(s->m->device));
   WB_TRY(s->mask.ensure((size_t)V * 4));
-  WB_HIP(hipMemcpy(s->mask.p, mk.data(), (size_t)V * 4, hipMemcpyHostToDevice));
+  // (on the session's own stream: a copy on the legacy stream fails while ANOTHER session of the process is capturing a
+  // step graph -- "would make the legacy stream depend on a capturing blocking stream", profiles/r06_b_two_lanes.txt)
+  WB_HIP(hipMemcpyAsync(s->mask.p, mk.data(), (size_t)V * 4, hipMemcpyHostToDevice, s->st));
+  WB_HIP(hipStreamSynchronize(s->st));
   s->has_mask = true;
   return WB_OK;
 }
@@ -1539,8 +1543,9 @@ int wb_session_encoder_output(wb_session* s, int w, float* out, int32_t* C) {
   if (C) *C = s->C[w];
   if (out) {
     WB_HIP(hipSetDevice(s->m->device));
-    WB_HIP(hipMemcpy(out, s->enc_out.as<float>() + (size_t)s->row0[w] * d, (size_t)s->C[w] * d * 4,
-                     hipMemcpyDeviceToHost));
+    WB_HIP(hipMemcpyAsync(out, s->enc_out.as<float>() + (size_t)s->row0[w] * d, (size_t)s->C[w] * d * 4,
+                          hipMemcpyDeviceToHost, s->st));
+    WB_HIP(hipStreamSynchronize(s->st));
   }
   return WB_OK;
 }

@@ -310,18 +310,21 @@ static inline hipemu_f32x16 hipemu_mfma_f32_32x32x16_bf16(hipemu_bf16x8 a, hipem
   for (int i = 0; i < 16; i++) d[i] = co[i];
   return d;
 }
+// (64-bit values travel as two 32-bit halves, as the device's own __shfl of a double does)
 template <class T> static inline T __shfl_xor(T v, int mask, int width = 64) {
-  static_assert(sizeof(T) == 4, "hipemu: 32-bit shuffles only");
-  int iv, r; memcpy(&iv, &v, 4);
-  hipemu::wave_op(hipemu::OP_SHFL_XOR, &iv, 0, 0, &r, mask, width, 0, 0);
-  T o; memcpy(&o, &r, 4); return o;
+  static_assert(sizeof(T) == 4 || sizeof(T) == 8, "hipemu: 32- and 64-bit shuffles only");
+  int iv[2] = {0, 0}, r[2] = {0, 0}; memcpy(iv, &v, sizeof(T));
+  for (unsigned h = 0; h < sizeof(T) / 4; h++) hipemu::wave_op(hipemu::OP_SHFL_XOR, &iv[h], 0, 0, &r[h], mask, width, 0, 0);
+  T o; memcpy(&o, r, sizeof(T)); return o;
 }
 template <class T> static inline T __shfl(T v, int src, int width = 64) {
-  static_assert(sizeof(T) == 4, "hipemu: 32-bit shuffles only");
-  int iv, r; memcpy(&iv, &v, 4);
-  hipemu::wave_op(hipemu::OP_SHFL, &iv, 0, 0, &r, src, width, 0, 0);
-  T o; memcpy(&o, &r, 4); return o;
+  static_assert(sizeof(T) == 4 || sizeof(T) == 8, "hipemu: 32- and 64-bit shuffles only");
+  int iv[2] = {0, 0}, r[2] = {0, 0}; memcpy(iv, &v, sizeof(T));
+  for (unsigned h = 0; h < sizeof(T) / 4; h++) hipemu::wave_op(hipemu::OP_SHFL, &iv[h], 0, 0, &r[h], src, width, 0, 0);
+  T o; memcpy(&o, r, sizeof(T)); return o;
 }
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 static inline unsigned long long __ballot(int pred) {
   unsigned long long r; hipemu::wave_op(hipemu::OP_BALLOT, &pred, 0, 0, &r, 0, 0, 0, 0); return r;
 }

@@ -7,6 +7,8 @@ threads -- ctypes drops the GIL) overlap one half's HBM-bound cross-K/V stream w
 import os
 import sys
 import threading
+
+os.environ.setdefault("WHISPER_HIP_GRAPH", "0")      # eager launches on both arms: two threads capturing graphs at once is another experiment
 import time
 
 import numpy as np
