@@ -56,6 +56,7 @@ struct GemvArgs {
   const float* ln_g = nullptr; const float* ln_b = nullptr; float ln_eps = 0.f; int ln_inside = 0;
   int n_head = 0, n_chunks = 0;             // ATTN prologue
   float* P = nullptr;                       // out partials [KS][S][N]
+  float* h_tmp = nullptr;                   // [S][K] scratch: LN rows of the 9 - 16-row logits pass (dec_fold_ln_rows_kernel)
   // STATS epilogue (logits): + mask, per-tile max / sum-exp / top-k -> tstats [row][n_tiles][TS_STRIDE]
   const float* mask = nullptr; int use_mask = 0, topk = 0; float* tstats = nullptr;
   const int* st = nullptr; int S = 0;
@@ -165,6 +166,8 @@ struct BeamChainArgs {
   int V = 0;                                                           // vocabulary: a top-k id outside [0, V) (NaN logits) ends its beam and raises BC_ERR
   int step_pos = 0;                                                    // position index (ST_STEP) of the first decode step
   int* done_flag_host = nullptr;                                       // mapped host word: set when every window has ended
+  // dec_prepare_kernel's work for the next step, done here (one launch less per step): position tables + embedding rows
+  int* tabs = nullptr; int Lmax = 0; const float* E = nullptr; const float* pos = nullptr; int d = 0; float* x = nullptr;
 };
 void launch_dec_beam_update(hipStream_t st, const BeamChainArgs& a);
 

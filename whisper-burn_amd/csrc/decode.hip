@@ -411,6 +411,65 @@ __global__ __launch_bounds__(256, (MR >= 8 && DPL >= 16) ? 1 : 2) void dec_gemv_
   }
 }
 
+// The final fold + LayerNorm of the 9 - 16-row logits pass, ONCE: one wave per row, the arithmetic of the logits prologue
+// (planes in ascending order, statistics by wave shuffles) -> h_tmp [rows][d], and the folded stream to x_out.
+template <int DPL>
+__global__ __launch_bounds__(64) void dec_fold_ln_rows_kernel(GemvArgs a) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const int d = a.K;
+  if (r >= a.st[ST_N]) return;
+  int co[DPL];
+#pragma unroll
+  for (int i = 0; i < DPL; i++) co[i] = lane + (64 * i < d ? 64 * i : 0);
+  float gv[DPL], bv[DPL], v[DPL];
+  const float* xr = a.src + (int64_t)r * d;
+#pragma unroll
+  for (int i = 0; i < DPL; i++) { gv[i] = a.ln_g[co[i]]; bv[i] = a.ln_b[co[i]]; v[i] = xr[co[i]]; }
+  if (a.KSp > 0) {
+    float acc[DPL];
+#pragma unroll
+    for (int i = 0; i < DPL; i++) acc[i] = a.pbias[co[i]];
+    const float* pp = a.pend + (int64_t)r * d;
+    const int64_t plane = (int64_t)a.S * d;
+    constexpr int CH = DPL <= 6 ? 8 : 4;
+    for (int sp = 0; sp < a.KSp; sp += CH) {
+      float t[CH][DPL];
+#pragma unroll
+      for (int j = 0; j < CH; j++) {
+        const float* pj = pp + (int64_t)min(sp + j, a.KSp - 1) * plane;
+#pragma unroll
+        for (int i = 0; i < DPL; i++) t[j][i] = pj[co[i]];
+      }
+#pragma unroll
+      for (int j = 0; j < CH; j++) {
+        const bool live = sp + j < a.KSp;
+#pragma unroll
+        for (int i = 0; i < DPL; i++) acc[i] += live ? t[j][i] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < DPL; i++) v[i] = v[i] + acc[i];
+  }
+  float sm = 0.f;
+#pragma unroll
+  for (int i = 0; i < DPL; i++) {
+    if (64 * i < d) { sm += v[i]; a.x_out[(int64_t)r * d + co[i]] = v[i]; }
+  }
+  const float mean = wave_sum(sm) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < DPL; i++) {
+    if (64 * i < d) { const float t = v[i] - mean; q += t * t; }
+  }
+  const float var = wave_sum(q) / (float)d;
+  const float denom = a.ln_inside ? sqrtf(var + a.ln_eps) : (sqrtf(var) + a.ln_eps);
+#pragma unroll
+  for (int i = 0; i < DPL; i++) {
+    const int c = lane + 64 * i;
+    if (c < d) a.h_tmp[(int64_t)r * d + c] = (v[i] - mean) / denom * gv[i] + bv[i];
+  }
+}
+
 // ---- logits for 9 - 16 live rows on the matrix cores (beam search over a 30 s chunk: 3 windows x 5 beams = 15 rows) -------
 // The vector-pipe GEMV above spends 16 x 128 x d FMAs per block with an LDS read per four of them: 41 us per step for
 // tiny.en's 80 MB of E^T even without its prologue (profiles/r05_k_fold16.txt).  Same launch geometry (one block per
@@ -420,7 +479,10 @@ __global__ __launch_bounds__(256, (MR >= 8 && DPL >= 16) ? 1 : 2) void dec_gemv_
 // of the float4 is the B operand of accumulator c (columns 4 j + c), the 16 rows sit k-major in LDS (A operand of lane l for
 // K-rows k .. k + 3 is word 16 k + l: conflict-free).  The two K halves of a column strip meet in LDS in fixed order.
 typedef float lg_f32x4 __attribute__((ext_vector_type(4)));
-template <int DPL>
+// PRELN: the rows arrive folded and normalised (a.h_tmp, written by dec_fold_ln_rows_kernel one launch earlier) -- with the
+// product on the matrix cores the per-block prologue was the larger half of the launch (every one of the ~400 blocks folding
+// 16 rows x 24 planes from L2: 250 MB of traffic for an 80 MB weight stream; 41 us with it in, profiles/r06_c_bench.json).
+template <int DPL, bool PRELN>
 __global__ __launch_bounds__(256, 2) void dec_logits_mfma16_kernel(GemvArgs a) {
   constexpr int MR = 16, CT = 128, KMAX = 64 * DPL;
   __shared__ __attribute__((aligned(16))) float xT[KMAX * MR];          // [k][16]; later red[2][MR][CT] (KMAX >= 256)
@@ -445,7 +507,12 @@ __global__ __launch_bounds__(256, 2) void dec_logits_mfma16_kernel(GemvArgs a) {
     if (t < nld) bw[t] = *reinterpret_cast<const float4*>(bp + (int64_t)(4 * t) * a.ldw);
   if (n_rows == 0) return;
   // ---- prologue: x + (bias + pending planes), LayerNorm, staged k-major (dec_gemv_kernel's LN prologue) ----
-  {
+  if constexpr (PRELN) {
+    for (int e = tid; e < MR * d; e += 256) {
+      const int r = e / d, c = e - r * d;
+      xT[c * MR + r] = r < n_rows ? a.h_tmp[(int64_t)r * d + c] : 0.f;
+    }
+  } else {
     const bool writer = blockIdx.x == 0;
 #pragma unroll 1
     for (int r = wave; r < MR; r += 4) {
@@ -1627,6 +1694,27 @@ __global__ __launch_bounds__(1024) void dec_beam_update_kernel(BeamChainArgs a) 
       if (lane == 0) so[L.win_nb + w] = is_done ? 0 : __popcll(lm);
     }
   }
+  // ---- the next step's rows: position tables (copied from the parent's, double-buffered by step parity) and
+  // x = E[token] + pos[len - 1] (mod.rs:141-146) -- what dec_prepare_kernel does for a host-driven step
+  if (a.x != nullptr && n_all > 0) {
+    __syncthreads();                                  // the state block above is complete
+    int* tab_new = a.tabs + (size_t)(step_next & 1) * L.S * a.Lmax;
+    const int* tab_old = a.tabs + (size_t)((step_next & 1) ^ 1) * L.S * a.Lmax;
+    const int len = step_next + 1, d4 = a.d >> 2;
+    for (int i = wv; i < n_all; i += NW) {            // one wave per row
+      const int parent = so[L.parent + i], tk = so[L.tok + i];
+      if (parent >= 0)
+        for (int p = lane; p < len - 1; p += 64) tab_new[i * a.Lmax + p] = tab_old[parent * a.Lmax + p];
+      if (lane == 0) tab_new[i * a.Lmax + len - 1] = step_next * L.S + i;
+      const float4* e = reinterpret_cast<const float4*>(a.E + (int64_t)tk * a.d);
+      const float4* pp = reinterpret_cast<const float4*>(a.pos + (int64_t)(len - 1) * a.d);
+      float4* o = reinterpret_cast<float4*>(a.x + (int64_t)i * a.d);
+      for (int c = lane; c < d4; c += 64) {
+        const float4 u = e[c], v = pp[c];
+        o[c] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+      }
+    }
+  }
 }
 
 __global__ void dec_logprob_row_kernel(const float* __restrict__ x, int KS, int64_t plane, int V,
@@ -1700,8 +1788,19 @@ void launch_dec_gemv(hipStream_t st, const GemvArgs& a, int n_rows_hint, bool st
     // ... on the matrix cores (exact-f32 MFMA, dec_logits_mfma16_kernel) unless WHISPER_HIP_LOGITS_MFMA=0
     static const bool mfma_enabled = []() { const char* e = getenv("WHISPER_HIP_LOGITS_MFMA"); return !(e && e[0] == '0'); }();
     if (mfma_enabled && a.KS == 1 && a.K % 64 == 0 && a.K >= 256 && ct == GV_CT_LOGITS && a.pro == PRO_LN) {
-      if (a.K <= 384) launch_gemv_k(dec_logits_mfma16_kernel<6>, st, grid, a);
-      else launch_gemv_k(dec_logits_mfma16_kernel<8>, st, grid, a);
+      static const bool preln = []() { const char* e = getenv("WHISPER_HIP_LOGITS_PRELN"); return !(e && e[0] == '0'); }();
+      if (preln && a.h_tmp) {
+        // (profiling: the caller's tag is superseded -- each of the two launches carries its own class)
+        prof_tag(KC_FOLD_LN_ROWS, 4.0 * 16 * (double)a.K * (a.KSp + 3));
+        if (a.K <= 384) WB_KLAUNCH(dec_fold_ln_rows_kernel<6>, dim3(16), dim3(64), 0, st, a);
+        else WB_KLAUNCH(dec_fold_ln_rows_kernel<8>, dim3(16), dim3(64), 0, st, a);
+        prof_tag(KC_LOGITS, 4.0 * (double)a.N * a.K + 4.0 * 16 * ((double)a.K + a.N));
+        if (a.K <= 384) launch_gemv_k(dec_logits_mfma16_kernel<6, true>, st, grid, a);
+        else launch_gemv_k(dec_logits_mfma16_kernel<8, true>, st, grid, a);
+        return;
+      }
+      if (a.K <= 384) launch_gemv_k(dec_logits_mfma16_kernel<6, false>, st, grid, a);
+      else launch_gemv_k(dec_logits_mfma16_kernel<8, false>, st, grid, a);
       return;
     }
     if (a.K <= 384) launch_gemv_k(dec_gemv_kernel<16, 512, 6, true, true, GV_CT_LOGITS>, st, grid, a);

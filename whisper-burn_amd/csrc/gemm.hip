@@ -213,6 +213,8 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
       const int col = n0 + wn * TN + j * 32 + li;
       const bool col_ok = col < N;
       const int colc = col_ok ? col : N - 1;
+      // (column blocks: GemmArgs::c_block_cols)
+      const int64_t cbase = g.c_block_cols > 0 ? (int64_t)(col / g.c_block_cols) * g.c_block_stride + col % g.c_block_cols : col;
       const float bias = g.bias ? g.bias[colc] : 0.f;
       float cs = 1.f;
       if (g.col_scale_period > 0 && (colc % g.col_scale_period) < g.col_scale_width) cs = g.col_scale;
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
         if (g.col_scale_period > 0) v *= cs;
         if (g.residual) v = res[r] + v;
         if (g.aux) v = v + ax[r];
-        if (col_ok && row < M) Cout[(int64_t)row * g.ldc + col] = v;
+        if (col_ok && row < M) Cout[cbase + (int64_t)row * g.ldc] = v;
       }
     }
 }

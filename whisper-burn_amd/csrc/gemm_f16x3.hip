@@ -246,6 +246,8 @@ __global__ __launch_bounds__(NT, WB_F16X3_MIN_WAVES) void gemm_f16x3_kernel(Gemm
       const int col = n0 + wn * TN + j * 32 + li;
       const bool col_ok = col < N;
       const int colc = col_ok ? col : N - 1;
+      // (column blocks: GemmArgs::c_block_cols)
+      const int64_t cbase = g.c_block_cols > 0 ? (int64_t)(col / g.c_block_cols) * g.c_block_stride + col % g.c_block_cols : col;
       const float bias = g.bias ? g.bias[colc] : 0.f;
       float cs = 1.f;
       if (g.col_scale_period > 0 && (colc % g.col_scale_period) < g.col_scale_width) cs = g.col_scale;
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(NT, WB_F16X3_MIN_WAVES) void gemm_f16x3_kernel(Gemm
         if (g.col_scale_period > 0) v *= cs;
         if (g.residual) v = res[r] + v;
         if (g.aux) v = v + ax[r];
-        if (col_ok && row < M) Cout[(int64_t)row * g.ldc + col] = v;
+        if (col_ok && row < M) Cout[cbase + (int64_t)row * g.ldc] = v;
       }
     }
   // range guard: the host re-runs the pass on the exact-f32 kernel and stops using this one (engine.cpp: split_guarded)

@@ -15,7 +15,7 @@ enum KernelClass {
   KC_GEMV_LN_QKV, KC_SELF_ATTN, KC_GEMV_OUT, KC_GEMV_LN_CQ, KC_GEMV_LN_MLP1, KC_GEMV_MLP2, KC_CROSS_FUSED,
   // batch mode (more than 8 live rows): one class per kernel of the per-layer chain
   KC_B_RESOLVE_LN, KC_B_GEMM, KC_B_SELF_ATTN, KC_B_CROSS_STREAM, KC_B_CROSS_CHUNK, KC_B_COMBINE, KC_B_GELU_FOLD,
-  KC_B_LOGITS_GEMM, KC_B_TOPK_ROWS, KC_PERSIST, KC_BEAM_UPDATE,
+  KC_B_LOGITS_GEMM, KC_B_TOPK_ROWS, KC_PERSIST, KC_BEAM_UPDATE, KC_FOLD_LN_ROWS,
   KC_COUNT
 };
 void prof_tag(int cls, double algo_bytes);
@@ -88,6 +88,10 @@ struct GemmArgs {
   int M = 0, N = 0, K = 0;                       // K % 16 == 0
   int act = ACT_NONE;
   int ksplit = 1; int64_t c_split_stride = 0;    // split-K: raw partials of K-slice z go to C + z * c_split_stride
+  // column blocks: output column n lands at C + (n / c_block_cols) * c_block_stride + row * ldc + n % c_block_cols (0: plain).
+  // The cross-K/V projection of ALL decoder layers is one GEMM over [d][n_layer * 2d]; its output is laid out layer-major
+  // ([layer][row][2d]) so that a decode step's pass over ONE layer's cached K/V is one dense stream (session.cpp).
+  int c_block_cols = 0; int64_t c_block_stride = 0;
   int* range_flag = nullptr;                     // split-precision kernel only: set to 1 (system scope) when a result is not
                                                  // finite, i.e. an operand left fp16's range (|x| >= 65504)
 };

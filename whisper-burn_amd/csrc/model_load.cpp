@@ -432,8 +432,14 @@ int build_model(TensorMap& tm, int device, int compute_dtype, wb_model** out) {
       }
     size_t total = 0;
     for (LinearW* l : ws) total += (size_t)l->k * l->n;
-    if (total && ws.size() == (size_t)D.n_text_layer * 6) {            // all or nothing: one arithmetic per decode step
-      WB_TRY(m->arena_dec_split.alloc(total * 2 * 2));
+    // all or nothing: one arithmetic per decode step.  The tiles cost another 4 B per decoder-layer weight element (2.9 GB at
+    // large-v2, next to 6.5 GB of f32 weights): when the device cannot spare them the model simply stays on the exact-f32
+    // skinny kernel -- an optional speed path must not fail the load (wb_model_decoder_gemm then reports 0)
+    if (total && ws.size() == (size_t)D.n_text_layer * 6 && m->arena_dec_split.alloc(total * 2 * 2) != WB_OK) {
+      (void)hipGetLastError();                                       // (clear the sticky out-of-memory status)
+      ws.clear();
+    }
+    if (total && ws.size() == (size_t)D.n_text_layer * 6) {
       uint16_t* p = m->arena_dec_split.as<uint16_t>();
       for (LinearW* l : ws) {
         const size_t n = (size_t)l->k * l->n;

@@ -36,7 +36,7 @@ static const char* const g_kernel_names[KC_COUNT] = {
     "batch: dec_self_attn (paged self-KV)", "batch: dec_cross_attn_stream (cached K/V stream)",
     "batch: dec_cross_attn chunked (cached K/V, beams)", "batch: dec_attn_combine", "batch: dec_gelu_fold",
     "batch: logits MFMA GEMM (E^T stream)", "batch: dec_topk_rows", "dec_persist (flag-chained decode steps)",
-    "dec_beam_update (beam.rs bookkeeping on the device)"};
+    "dec_beam_update (beam.rs bookkeeping on the device)", "dec_fold_ln_rows (final fold + LayerNorm, 9 - 16 rows)"};
 struct PendingLaunch { hipEvent_t a, b; int cls; double bytes; };
 static std::mutex g_prof_mu;
 static std::vector<PendingLaunch> g_pending;
@@ -183,7 +183,9 @@ static int session_finish_encode(wb_session* s, const MelBatch& mb, bool defer_g
   {
     ScopedTimer tm(s->st, 2);
     GemmArgs g;
-    g.A = s->enc_out.as<float>(); g.lda = d; g.B = m->ckv_all.w; g.ldb = ldkv_all; g.C = s->ckv.as<float>(); g.ldc = ldkv_all;
+    // output layer-major: [layer][packed encoder row][K | V] -- one layer's cached K/V is one dense region (ckv_of)
+    g.A = s->enc_out.as<float>(); g.lda = d; g.B = m->ckv_all.w; g.ldb = ldkv_all; g.C = s->ckv.as<float>(); g.ldc = 2 * d;
+    g.c_block_cols = 2 * d; g.c_block_stride = (int64_t)rows_all * 2 * d;
     g.bias = m->ckv_all.b; g.M = rows_all; g.N = ldkv_all; g.K = d;
     g.col_scale = m->qk_scale; g.col_scale_period = 2 * d; g.col_scale_width = d;   // K * s (mod.rs:510-514)
     WB_TRY(gemm_dispatch(m, s->st, g, m->ckv_all.k, m->ckv_all.sh, m->ckv_all.sl));
@@ -488,7 +490,9 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
   int xi = 0;                                     // xb[xi] holds the current residual stream
   float *h = s->h.as<float>(), *att = s->att.as<float>();
   const size_t pool = (size_t)s->Lmax * S;
-  const int ldkv = NL * 2 * d;
+  // cached cross K|V: layer-major, [layer][packed encoder row][2d] (session_finish_encode) -- layer l's rows start at ckv_of(l)
+  const int ldkv = 2 * d;
+  auto ckv_of = [&](int l) { return s->ckv.as<float>() + (size_t)l * s->enc_rows * 2 * d; };
   const int* win_row0 = s->win_meta.as<int>();
   const int* win_C = win_row0 + s->W;
   const int n = n_launch;
@@ -502,8 +506,9 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
   // chained small-batch steps: the previous step's merge kernel already prepared this one (the chain's
   // first step is prepared by session_greedy_chain)
   const bool merge_prepares = chained && fuse_ln;
-  if (!merge_prepares) prof_tag(KC_PREPARE, 8.0 * n * d);
-  if (!merge_prepares)
+  // (device-chained beam search: the bookkeeping launch behind the previous step prepared this one)
+  if (!merge_prepares && !bio) prof_tag(KC_PREPARE, 8.0 * n * d);
+  if (!merge_prepares && !bio)
     launch_dec_prepare(st, hst, s->state.as<int>(), L, n, tabs, s->Lmax, m->tok_emb, m->dec_pos, d, xb[0], gctl);
   auto gemv = [&](const LinearW& w, int ks, int ksl, int pro, const float* src, int ld_src, float* P) {
     GemvArgs a;
@@ -585,7 +590,7 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
         fz.ln_g = b.ln2.g; fz.ln_b = b.ln2.b; fz.ln_eps = b.ln2.eps; fz.ln_inside = m->ln_eps_inside_sqrt; fz.Wq = b.cq.w;
         prof_tag(KC_B_CROSS_STREAM, ckv_bytes + 4.0 * dd + 4.0 * n * d * (ko + 2));
         s->prof_cls_cross = KC_B_CROSS_STREAM;
-        launch_dec_cross_attn_stream_fused(st, dst, L, s->W, H, b.cq.b, d, s->ckv.as<float>(), ldkv, l * 2 * d, win_row0,
+        launch_dec_cross_attn_stream_fused(st, dst, L, s->W, H, b.cq.b, d, ckv_of(l), ldkv, 0, win_row0,
                                            win_C, m->qk_scale, att, fz);
         xi ^= 1;
       } else {
@@ -595,13 +600,13 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
       if (cross_stream) {
         prof_tag(KC_B_CROSS_STREAM, ckv_bytes + 4.0 * n * d * (ko + 1));
         s->prof_cls_cross = KC_B_CROSS_STREAM;
-        launch_dec_cross_attn_stream(st, dst, L, s->W, H, s->Pq.as<float>(), ko, b.cq.b, d, s->ckv.as<float>(), ldkv,
-                                     l * 2 * d, win_row0, win_C, m->qk_scale, att);
+        launch_dec_cross_attn_stream(st, dst, L, s->W, H, s->Pq.as<float>(), ko, b.cq.b, d, ckv_of(l), ldkv,
+                                     0, win_row0, win_C, m->qk_scale, att);
       } else {
         prof_tag(KC_B_CROSS_CHUNK, ckv_bytes + 4.0 * n * d * ko);
         s->prof_cls_cross = KC_B_CROSS_CHUNK;
-        launch_dec_cross_attn(st, dst, L, s->W, H, s->n_chunks, s->Pq.as<float>(), ko, b.cq.b, d, s->ckv.as<float>(),
-                              ldkv, l * 2 * d, win_row0, win_C, m->qk_scale, s->ca.as<float>(), max_nb);
+        launch_dec_cross_attn(st, dst, L, s->W, H, s->n_chunks, s->Pq.as<float>(), ko, b.cq.b, d, ckv_of(l),
+                              ldkv, 0, win_row0, win_C, m->qk_scale, s->ca.as<float>(), max_nb);
         prof_tag(KC_B_COMBINE, 4.0 * n * H * s->n_chunks * CA_STRIDE);
         launch_dec_attn_combine(st, dst, n, s->ca.as<float>(), H, s->n_chunks, att);
       }
@@ -696,7 +701,7 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
       ca.x_in = xb[xi]; ca.pend = att_planes; ca.KSp = att_ks; ca.pbias = b.out.b; ca.x_out = xb[xi ^ 1];
       ca.ln_g = b.ln2.g; ca.ln_b = b.ln2.b; ca.ln_eps = b.ln2.eps; ca.ln_inside = m->ln_eps_inside_sqrt;
       ca.Wq = b.cq.w; ca.bq = b.cq.b; ca.scale = m->qk_scale;
-      ca.ckv = s->ckv.as<float>(); ca.ldkv = ldkv; ca.koff = l * 2 * d; ca.win_row0 = win_row0; ca.win_C = win_C;
+      ca.ckv = ckv_of(l); ca.ldkv = ldkv; ca.koff = 0; ca.win_row0 = win_row0; ca.win_C = win_C;
       ca.Wo = b.cout.w; ca.P = s->Pc.as<float>();
       ca.n_pass = s->maxC > CROSS_FUSED_MAX_C ? 2 : 1;
       prof_tag(KC_CROSS_FUSED, ckv_bytes + 4.0 * dd * 2);
@@ -712,8 +717,8 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
       if (fuse_co) { fz.Wo = b.cout.w; fz.rec = s->carec.as<float>(); }
       prof_tag(KC_CROSS_ATTN, ckv_bytes + 4.0 * dd * (fuse_co ? 2 : 1));
       s->prof_cls_cross = KC_CROSS_ATTN;
-      launch_dec_cross_attn(st, dst, L, s->W, H, s->n_chunks, nullptr, 0, b.cq.b, d, s->ckv.as<float>(), ldkv,
-                            l * 2 * d, win_row0, win_C, m->qk_scale, s->ca.as<float>(), max_nb, &fz);
+      launch_dec_cross_attn(st, dst, L, s->W, H, s->n_chunks, nullptr, 0, b.cq.b, d, ckv_of(l), ldkv,
+                            0, win_row0, win_C, m->qk_scale, s->ca.as<float>(), max_nb, &fz);
       xi ^= 1;
     } else {
       prof_tag(KC_GEMV_LN_CQ, wsz * dd);
@@ -722,7 +727,7 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
       prof_tag(KC_CROSS_ATTN, ckv_bytes);
       s->prof_cls_cross = KC_CROSS_ATTN;
       launch_dec_cross_attn(st, dst, L, s->W, H, s->n_chunks, s->Pq.as<float>(), s->ks_o, b.cq.b, d,
-                            s->ckv.as<float>(), ldkv, l * 2 * d, win_row0, win_C, m->qk_scale, s->ca.as<float>(), max_nb);
+                            ckv_of(l), ldkv, 0, win_row0, win_C, m->qk_scale, s->ca.as<float>(), max_nb);
     }
     if (!fuse_co && !fuse_x) {
       GemvArgs a = gemv(b.cout, s->ks_o, s->ksl_o, PRO_ATTN, s->ca.as<float>(), 0, s->Po.as<float>());
@@ -760,6 +765,7 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
     a.W = m->tok_emb_t; a.ldw = m->vocab_ld; a.K = d; a.N = V; a.KS = 1; a.KSL = d;
     a.P = s->logits.as<float>(); a.st = dst; a.S = S;
     a.mask = s->mask.as<float>(); a.use_mask = use_mask; a.topk = k; a.tstats = s->tstats.as<float>(); a.ct = s->ct_v;
+    a.h_tmp = h;                            // (9 - 16 rows: the fold + LayerNorm runs once, in its own launch, into this buffer)
     prof_tag(KC_LOGITS, wsz * (double)V * d + 4.0 * ((double)n * d + (double)n * V));
     ln_gemv(a, s->P2.as<float>(), ks_mlp, m->dec[NL - 1].mlp2.b, m->ln_dec, true);
     tm_logits.stop();
@@ -856,7 +862,7 @@ static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_
   const int NB = dec_mlp_fused_planes(d);
   const int n_tiles = (V + 127) / 128;
   const size_t pool = (size_t)s->Lmax * S;
-  const int ldkv = NL * 2 * d;
+  const int ldkv = 2 * d;
   // ---- the hand-off buffers: residual streams and partial planes as {tag, value} granules (zero-filled once: tag 0 is
   // never used; the tags of a launch live above launch_count << 16, so leftovers of earlier decodes never match)
   WB_REQUIRE(NB <= 32 && H <= 8, WB_ERR_SHAPE, "persistent decode: more planes than its folds hold");
@@ -892,7 +898,7 @@ static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_
     ca.x_in = xb[xi]; ca.pend = s->Pa.as<float>(); ca.KSp = H; ca.pbias = b.out.b; ca.x_out = xb[xi ^ 1];
     ca.ln_g = b.ln2.g; ca.ln_b = b.ln2.b; ca.ln_eps = b.ln2.eps; ca.ln_inside = m->ln_eps_inside_sqrt;
     ca.Wq = b.cq.w; ca.bq = b.cq.b; ca.scale = m->qk_scale;
-    ca.ckv = s->ckv.as<float>(); ca.ldkv = ldkv; ca.koff = l * 2 * d;
+    ca.ckv = s->ckv.as<float>() + (size_t)l * s->enc_rows * 2 * d; ca.ldkv = ldkv; ca.koff = 0;   // layer-major cached K|V
     ca.win_row0 = s->win_meta.as<int>(); ca.win_C = s->win_meta.as<int>() + W;
     ca.Wo = b.cout.w; ca.P = s->Pc.as<float>();
     ca.n_pass = s->maxC > CROSS_FUSED_MAX_C ? 2 : 1;
@@ -1113,11 +1119,14 @@ int session_beam_chain(wb_session* s, const int32_t* prompt, int P, int k, int e
   static const bool graphs_enabled = []() { const char* e = getenv("WHISPER_HIP_GRAPH"); return !(e && e[0] == '0'); }();
   const bool use_graph = graphs_enabled && !profile().on;
   BeamStepIO bio;
-  bio.state_src = s->bc_state.as<int>();
+  bio.state_src = s->state.as<int>();
   bio.topk_id = s->bc_topk.as<int32_t>();
   bio.topk_lp = reinterpret_cast<float*>(s->bc_topk.as<int32_t>() + (size_t)S * TOPK_MAX);
   bio.upd.ctl = s->bc_ctl.as<int>(); bio.upd.bl = bl; bio.upd.topk_id = bio.topk_id; bio.upd.topk_lp = bio.topk_lp;
-  bio.upd.state_out = s->bc_state.as<int>(); bio.upd.lay = L; bio.upd.k = k; bio.upd.eot = eot; bio.upd.V = V;
+  // the bookkeeping kernel writes the device state block the step kernels read, and prepares the step's rows itself
+  bio.upd.state_out = s->state.as<int>(); bio.upd.lay = L;
+  bio.upd.tabs = s->tabs.as<int>(); bio.upd.Lmax = s->Lmax; bio.upd.E = m->tok_emb; bio.upd.pos = m->dec_pos;
+  bio.upd.d = D.n_text_state; bio.upd.x = s->x.as<float>(); bio.upd.k = k; bio.upd.eot = eot; bio.upd.V = V;
   bio.upd.first = 0; bio.upd.step_pos = P - 1;
   // the captured graphs bake in the search's constants: drop them when those differ from the last search of this session
   const uint64_t bsig = ((uint64_t)max_depth << 40) ^ ((uint64_t)(P - 1) << 24) ^ ((uint64_t)k << 16) ^ (uint64_t)(unsigned)eot;
