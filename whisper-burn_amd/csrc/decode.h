@@ -72,6 +72,7 @@ void launch_dec_resolve_ln(hipStream_t st, const int* state, int n_max, const fl
                            const float* P, int KS, int S, const float* bias, int d, const LayerNormW& ln,
                            int eps_inside_sqrt, float* h);
 void launch_dec_gemv(hipStream_t st, const GemvArgs& a, int n_rows_hint, bool stats);
+bool dec_logits_two_launches(const GemvArgs& a, int n_rows_hint);   // (a with pro = PRO_LN, KS, K, ct, h_tmp set)
 void launch_dec_self_attn(hipStream_t st, const int* state, const StepLayout& lay, int n_max, int n_head,
                           const float* Pqkv, int KS, const float* bqkv, int d, float* Kc, float* Vc, const int* tab,
                           int Lmax, float scale, float* att);

@@ -1776,22 +1776,39 @@ static void launch_gemv_dpl(hipStream_t st, dim3 grid, const GemvArgs& a) {
   else launch_gemv_k(dec_gemv_kernel<MR, XLD, LN ? 20 : 1, LN, STATS, CT>, st, grid, a);
 }
 
+static bool logits_mfma_enabled() {
+  static const bool on = []() { const char* e = getenv("WHISPER_HIP_LOGITS_MFMA"); return !(e && e[0] == '0'); }();
+  return on;
+}
+static bool logits_preln_enabled() {
+  static const bool on = []() { const char* e = getenv("WHISPER_HIP_LOGITS_PRELN"); return !(e && e[0] == '0'); }();
+  return on;
+}
+static bool logits_mr16_enabled() {
+  static const bool on = []() { const char* e = getenv("WHISPER_HIP_LOGITS_MR16"); return !(e && e[0] == '0'); }();
+  return on;
+}
+// the 9 - 16-row logits pass as TWO launches (fold + LayerNorm once, then the MFMA product)?  The caller tags its first launch
+// accordingly (profiling classes KC_FOLD_LN_ROWS / KC_LOGITS).
+bool dec_logits_two_launches(const GemvArgs& a, int n_rows_hint) {
+  const int ct = a.ct > 0 ? a.ct : GV_CT_LOGITS;
+  return n_rows_hint > 8 && n_rows_hint <= 16 && a.K <= 512 && logits_mr16_enabled() && logits_mfma_enabled() && a.KS == 1 &&
+         a.K % 64 == 0 && a.K >= 256 && ct == GV_CT_LOGITS && logits_preln_enabled() && a.h_tmp != nullptr;
+}
+
 void launch_dec_gemv(hipStream_t st, const GemvArgs& a, int n_rows_hint, bool stats) {
   const int ct = a.ct > 0 ? a.ct : (stats ? GV_CT_LOGITS : GV_CT);
   dim3 grid((a.N + ct - 1) / ct, a.KS, n_rows_hint > 8 ? (n_rows_hint + 7) / 8 : 1);   // (z: row groups of 8)
   const bool ln = a.pro == PRO_LN;
-  static const bool mr16_enabled = []() { const char* e = getenv("WHISPER_HIP_LOGITS_MR16"); return !(e && e[0] == '0'); }();
-  if (stats && n_rows_hint > 8 && n_rows_hint <= 16 && a.K <= 512 && mr16_enabled) {
+  if (stats && n_rows_hint > 8 && n_rows_hint <= 16 && a.K <= 512 && logits_mr16_enabled()) {
     // 9 - 16 live rows on the fused sublayer path (d <= 512): ONE 16-row pass -- two row groups of 8 stream E^T twice
     // (52.7 us per step for tiny.en's 80 MB against 18 us at <= 8 rows: profiles/r05_d_beam5_fused16.txt)
     grid.z = 1;
     // ... on the matrix cores (exact-f32 MFMA, dec_logits_mfma16_kernel) unless WHISPER_HIP_LOGITS_MFMA=0
-    static const bool mfma_enabled = []() { const char* e = getenv("WHISPER_HIP_LOGITS_MFMA"); return !(e && e[0] == '0'); }();
-    if (mfma_enabled && a.KS == 1 && a.K % 64 == 0 && a.K >= 256 && ct == GV_CT_LOGITS && a.pro == PRO_LN) {
-      static const bool preln = []() { const char* e = getenv("WHISPER_HIP_LOGITS_PRELN"); return !(e && e[0] == '0'); }();
-      if (preln && a.h_tmp) {
-        // (profiling: the caller's tag is superseded -- each of the two launches carries its own class)
-        prof_tag(KC_FOLD_LN_ROWS, 4.0 * 16 * (double)a.K * (a.KSp + 3));
+    if (logits_mfma_enabled() && a.KS == 1 && a.K % 64 == 0 && a.K >= 256 && ct == GV_CT_LOGITS && a.pro == PRO_LN) {
+      if (logits_preln_enabled() && a.h_tmp) {
+        // (profiling: the caller tagged this launch as KC_FOLD_LN_ROWS -- dec_logits_two_launches -- and the product
+        // launch behind it carries the logits class)
         if (a.K <= 384) WB_KLAUNCH(dec_fold_ln_rows_kernel<6>, dim3(16), dim3(64), 0, st, a);
         else WB_KLAUNCH(dec_fold_ln_rows_kernel<8>, dim3(16), dim3(64), 0, st, a);
         prof_tag(KC_LOGITS, 4.0 * (double)a.N * a.K + 4.0 * 16 * ((double)a.K + a.N));

@@ -222,8 +222,10 @@ int run_encoder_unguarded(wb_model* m, hipStream_t st, Workspace& ws, const MelB
     GemmArgs g = linear_args(h, rows2, b.qkv, qkv);
     g.col_scale = m->qk_scale; g.col_scale_period = 3 * d; g.col_scale_width = 2 * d;   // q*s, k*s (mod.rs:506-514)
     WB_TRY(gemm(m, st, g, &b.qkv));
-    launch_attention_f32(st, qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, att, d, ws.segs.as<AttnSeg>(), nw, maxC, H,
-                         1.0f, 0);
+    // (split precision only inside a guarded pass whose out-projection runs on the split GEMM: that GEMM's range guard is
+    // what reports an attention operand outside fp16's range -- NaN in, flag raised, the pass repeated in exact f32)
+    launch_attention(st, qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, att, d, ws.segs.as<AttnSeg>(), nw, maxC, H, 1.0f, 0,
+                     m->split_active() && tl_split_flag != nullptr && b.out.sh != nullptr && d % 32 == 0);
     g = linear_args(att, rows2, b.out, x);
     g.residual = x; g.ldr = d;
     WB_TRY(gemm(m, st, g, &b.out));

@@ -114,5 +114,10 @@ struct AttnSeg { int32_t q_row0, q_len, kv_row0, kv_len; };   // one (batch) seg
 void launch_attention_f32(hipStream_t st, const float* Q, int ldq, const float* K, const float* V, int ldkv,
                           float* O, int ldo, const AttnSeg* segs_dev, int n_segs, int max_q_len, int n_head,
                           float scale, int causal);
+// the same with the choice of arithmetic: split = the 16-bit matrix path (fp16 hi / lo operands, three MFMAs per product, f32
+// accumulate: f32-grade; operands must stay inside fp16's range -- see attention.hip), else exact f32
+void launch_attention(hipStream_t st, const float* Q, int ldq, const float* K, const float* V, int ldkv,
+                      float* O, int ldo, const AttnSeg* segs_dev, int n_segs, int max_q_len, int n_head,
+                      float scale, int causal, bool split);
 
 }  // namespace wb

@@ -74,6 +74,7 @@ void prof_collect() {
     (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b);
   }
   g_pending.clear();
+  (void)hipGetLastError();      // (a tag whose launch never happened fails its elapsed-time query: not a sticky error for later calls)
 }
 void ScopedTimer::collect() {
   if (!on) return;
@@ -766,7 +767,8 @@ static int enqueue_step(wb_session* s, int n_launch, int k, int use_mask, bool f
     a.P = s->logits.as<float>(); a.st = dst; a.S = S;
     a.mask = s->mask.as<float>(); a.use_mask = use_mask; a.topk = k; a.tstats = s->tstats.as<float>(); a.ct = s->ct_v;
     a.h_tmp = h;                            // (9 - 16 rows: the fold + LayerNorm runs once, in its own launch, into this buffer)
-    prof_tag(KC_LOGITS, wsz * (double)V * d + 4.0 * ((double)n * d + (double)n * V));
+    if (dec_logits_two_launches(a, n)) prof_tag(KC_FOLD_LN_ROWS, 4.0 * n * d * (ks_mlp + 3));   // (the product launch tags itself)
+    else prof_tag(KC_LOGITS, wsz * (double)V * d + 4.0 * ((double)n * d + (double)n * V));
     ln_gemv(a, s->P2.as<float>(), ks_mlp, m->dec[NL - 1].mlp2.b, m->ln_dec, true);
     tm_logits.stop();
     NextPrep nx;
