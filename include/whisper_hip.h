@@ -270,6 +270,12 @@ typedef int (*wb_step_fn)(void* user, const int32_t* new_tokens, const int32_t* 
                           int32_t* top_ids, float* top_logprobs);
 int wb_beam_search(const wb_decode_params* p, int n_windows, int n_vocab, wb_step_fn step, void* user,
                    int32_t* out_tokens, int32_t row_stride, int32_t* out_lens);
+/* The same search with the bookkeeping of src/beam.rs:39-79 done by the DEVICE kernel that wb_session_decode chains between
+ * decode steps (beam_size > 1; WHISPER_HIP_BEAM_CHAIN=0 keeps the host loop above), driven by a caller's step function: a test
+ * hook that lets the device restatement be compared with the host one on scripted log-prob rows (exact ties, finished beams).
+ * n_windows <= 64; `device` only hosts three small buffers (no model). */
+int wb_beam_search_device(int device, const wb_decode_params* p, int n_windows, int n_vocab, wb_step_fn step,
+                          void* user, int32_t* out_tokens, int32_t row_stride, int32_t* out_lens);
 
 /* waveform_to_text (transcribe.rs:23-74) without the tokenizer: windows
  * (transcribe.rs:114-128), per-window decode, token-overlap stitch

@@ -205,6 +205,19 @@ def test_range_guard_words_are_per_session_and_the_encoder_check_is_deferred(emu
     assert p.returncode == 0 and f"EMU_CHECK_OK {which}" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
+def test_device_beam_bookkeeping_under_the_functional_model(emu_lib):
+    """tests/test_gpu_beam_device.py (the device restatement of beam.rs's bookkeeping against the host one on scripted log-prob
+    rows with exact ties) runs unchanged over the functional model: the kernel's rank-based top-k, its wave ballots / 64-bit
+    shuffles and the slot assignment are checked on the CPU too."""
+    env = dict(os.environ)
+    env["WHISPER_HIP_LIB"] = emu_lib
+    env["WHISPER_HIP_ALLOW_EMU"] = "1"
+    env["PYTHONPATH"] = os.pathsep.join([ROOT, PKG, os.path.join(ROOT, "tests"), env.get("PYTHONPATH", "")])
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_beam_device.py"), "-q", "-x",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900, cwd=os.path.join(ROOT, "tests"))
+    assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
 def test_production_key_ring_under_the_functional_model(emu_lib_prod):
     """The micro-model library compiles a 384-key ring so that small fixtures reach both of its code paths; the PRODUCT
     compiles 768 keys.  This runs the product's constant (`make prod`) at the real window lengths: C = 745 keys in one

@@ -1059,6 +1059,51 @@ static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_
 // A fresh session (step 0) hands in the whole prompt: the persistent kernel runs the prompt's first prompt_len - 1 positions as
 // forced steps of the same launch (no host round trip between the prompt and the first generated token); the chain of one
 // launch per sublayer (and the persistent kernel's fallback) prefills through host-driven steps first, as before.
+// The result of a device-chained beam search from its control block (copied to the host): per window the sequence of the
+// max-log-prob beam -- beam.rs:33-36, the LAST of the equal maxima -- walked back through the node tree.
+static int beam_chain_extract(const std::vector<int>& ctl, const BeamChainLayout& bl, const int32_t* prompt, int P,
+                              int32_t* out_tokens, int32_t row_stride, int32_t* out_lens, bool* all_done_out) {
+  const double* lp = reinterpret_cast<const double*>(ctl.data() + bl.lp);
+  const int* nodes = ctl.data() + bl.nodes;
+  bool all_done = true;
+  for (int w = 0; w < bl.W; w++) {
+    const int nb = ctl[bl.nb + w];
+    int best = -1;
+    for (int i = 0; i < nb; i++) {
+      WB_REQUIRE(lp[w * BEAM_KB + i] == lp[w * BEAM_KB + i], WB_ERR_STATE, "beam search: NaN log-probability (reference panics)");
+      if (best < 0 || lp[w * BEAM_KB + i] >= lp[w * BEAM_KB + best]) best = i;
+    }
+    std::vector<int32_t> seq;
+    for (int nd = best >= 0 ? ctl[bl.node + w * BEAM_KB + best] : -1; nd >= 0; nd = nodes[2 * nd + 1]) seq.push_back(nodes[2 * nd]);
+    std::reverse(seq.begin(), seq.end());
+    const int len = (P - 1) + (int)seq.size();
+    WB_REQUIRE(len <= row_stride, WB_ERR_ARG, "row_stride too small");
+    int32_t* row = out_tokens + (size_t)w * row_stride;
+    for (int i = 0; i < P - 1; i++) row[i] = prompt[i];
+    for (size_t i = 0; i < seq.size(); i++) row[P - 1 + i] = seq[i];
+    out_lens[w] = len;
+    all_done = all_done && (ctl[bl.done + w] != 0 || (best >= 0 && ctl[bl.fin + w * BEAM_KB + best]));
+  }
+  *all_done_out = all_done;
+  return WB_OK;
+}
+
+// The initial control block: one beam per window holding the prompt's last token (the rest of the prompt is the KV prefill).
+static void beam_chain_init(std::vector<int>& ctl, const BeamChainLayout& bl, const int32_t* prompt, int P, int eot) {
+  ctl.assign((size_t)bl.total_ints, 0);
+  double* lp = reinterpret_cast<double*>(ctl.data() + bl.lp);
+  int* nodes = ctl.data() + bl.nodes;
+  for (int w = 0; w < bl.W; w++) {
+    const int nd = w * BEAM_KB;                   // level 0 of the pool
+    ctl[bl.nb + w] = 1;
+    ctl[bl.node + w * BEAM_KB] = nd;
+    nodes[2 * nd] = prompt[P - 1]; nodes[2 * nd + 1] = -1;
+    ctl[bl.fin + w * BEAM_KB] = prompt[P - 1] == eot ? 1 : 0;     // transcribe.rs:235-241
+    ctl[bl.prev_slot + w * BEAM_KB] = P > 1 ? w : -1;
+    lp[w * BEAM_KB] = 0.0;
+  }
+}
+
 // Beam search with the bookkeeping on the device.  What the host still does: the prompt prefill (P - 1 ordinary steps), the
 // initial control block, enqueueing the steps (whole chunks as one graph launch), one synchronisation per chunk to see whether
 // every window has ended, and the walk back through the node tree at the end.  Results are those of beam_search_windows
@@ -1090,20 +1135,8 @@ int session_beam_chain(wb_session* s, const int32_t* prompt, int P, int k, int e
   WB_TRY(s->bc_ctl.ensure((size_t)bl.total_ints * 4));
   WB_TRY(s->bc_state.ensure((size_t)L.total * 4));
   WB_TRY(s->bc_topk.ensure((size_t)S * TOPK_MAX * 8));
-  std::vector<int> ctl((size_t)bl.total_ints, 0);
-  {
-    double* lp = reinterpret_cast<double*>(ctl.data() + bl.lp);
-    int* nodes = ctl.data() + bl.nodes;
-    for (int w = 0; w < W; w++) {
-      const int nd = w * BEAM_KB;                   // level 0 of the pool
-      ctl[bl.nb + w] = 1;
-      ctl[bl.node + w * BEAM_KB] = nd;
-      nodes[2 * nd] = prompt[P - 1]; nodes[2 * nd + 1] = -1;
-      ctl[bl.fin + w * BEAM_KB] = prompt[P - 1] == eot ? 1 : 0;     // transcribe.rs:235-241
-      ctl[bl.prev_slot + w * BEAM_KB] = P > 1 ? w : -1;
-      lp[w * BEAM_KB] = 0.0;
-    }
-  }
+  std::vector<int> ctl;
+  beam_chain_init(ctl, bl, prompt, P, eot);
   WB_HIP(hipMemcpyAsync(s->bc_ctl.p, ctl.data(), ctl.size() * 4, hipMemcpyHostToDevice, st));
   WB_HIP(hipStreamSynchronize(st));
   // launch shape: the bucket wb_session_step would pick for the most rows the search can have live (W k)
@@ -1170,27 +1203,8 @@ int session_beam_chain(wb_session* s, const int32_t* prompt, int P, int k, int e
   WB_TRY(dec_split_check(s));
   WB_REQUIRE(ctl[BC_ERR] == 0, WB_ERR_STATE, "beam search: NaN log-probability (reference panics)");
   {
-    const double* lp = reinterpret_cast<const double*>(ctl.data() + bl.lp);
-    const int* nodes = ctl.data() + bl.nodes;
     bool all_done = true;
-    for (int w = 0; w < W; w++) {   // beam.rs:33-36: the LAST of the equal maxima
-      const int nb = ctl[bl.nb + w];
-      int best = -1;
-      for (int i = 0; i < nb; i++) {
-        WB_REQUIRE(lp[w * BEAM_KB + i] == lp[w * BEAM_KB + i], WB_ERR_STATE, "beam search: NaN log-probability (reference panics)");
-        if (best < 0 || lp[w * BEAM_KB + i] >= lp[w * BEAM_KB + best]) best = i;
-      }
-      std::vector<int32_t> seq;
-      for (int nd = best >= 0 ? ctl[bl.node + w * BEAM_KB + best] : -1; nd >= 0; nd = nodes[2 * nd + 1]) seq.push_back(nodes[2 * nd]);
-      std::reverse(seq.begin(), seq.end());
-      const int len = (P - 1) + (int)seq.size();
-      WB_REQUIRE(len <= row_stride, WB_ERR_ARG, "row_stride too small");
-      int32_t* row = out_tokens + (size_t)w * row_stride;
-      for (int i = 0; i < P - 1; i++) row[i] = prompt[i];
-      for (size_t i = 0; i < seq.size(); i++) row[P - 1 + i] = seq[i];
-      out_lens[w] = len;
-      all_done = all_done && (ctl[bl.done + w] != 0 || (best >= 0 && ctl[bl.fin + w * BEAM_KB + best]));
-    }
+    WB_TRY(beam_chain_extract(ctl, bl, prompt, P, out_tokens, row_stride, out_lens, &all_done));
     if (max_depth < asked_depth && !all_done)
       WB_REQUIRE(false, WB_ERR_SHAPE, "Token sequence length %d must not exceed %d.", s->Lmax + 1, s->Lmax);
   }
@@ -1454,6 +1468,63 @@ int session_greedy_chain(wb_session* s, const int32_t* prompt, int eot, int max_
   return WB_OK;
 }
 }  // namespace wb
+
+// Test hook: beam.rs's bookkeeping as the DEVICE runs it (dec_beam_update_kernel), driven by a caller-supplied step function
+// with wb_session_step's contract instead of the decoder -- the counterpart of wb_beam_search (the host restatement), so that
+// the two can be compared on scripted log-prob rows with exact ties, finished beams and windows ending at different depths.
+// No model: `device` only hosts the three small buffers.
+extern "C" int wb_beam_search_device(int device, const wb_decode_params* p, int n_windows, int n_vocab, wb_step_fn step,
+                                     void* user, int32_t* out_tokens, int32_t row_stride, int32_t* out_lens) {
+  using namespace wb;
+  WB_REQUIRE(p && step && out_tokens && out_lens && n_windows >= 1 && n_windows <= 64, WB_ERR_ARG, "wb_beam_search_device: bad argument");
+  WB_REQUIRE(p->beam_size >= 1 && p->beam_size <= TOPK_MAX && p->max_depth >= 0, WB_ERR_ARG, "wb_beam_search_device: bad beam_size / max_depth");
+  const int W = n_windows, k = p->beam_size, S = W * MAX_BEAMS, P = 4, V = n_vocab, eot = p->tok_end_of_text;
+  const int32_t prompt[4] = {p->tok_start_of_transcript, p->tok_language, p->tok_transcribe, p->tok_no_timestamps};
+  WB_REQUIRE(row_stride >= P + p->max_depth, WB_ERR_ARG, "row_stride %d < %d", row_stride, P + p->max_depth);
+  WB_HIP(hipSetDevice(device));
+  const StepLayout L = make_step_layout(S, W);
+  const BeamChainLayout bl = make_beam_layout(W, p->max_depth);
+  DevMem d_ctl, d_state, d_topk;
+  WB_TRY(d_ctl.ensure((size_t)bl.total_ints * 4));
+  WB_TRY(d_state.ensure((size_t)L.total * 4));
+  WB_TRY(d_topk.ensure((size_t)S * TOPK_MAX * 8));
+  std::vector<int32_t> tok(S), par(S), win(S);
+  for (int t = 0; t < P - 1; t++) {               // the prompt prefill: steps without logits, as beam_search_windows issues them
+    for (int w = 0; w < W; w++) { tok[w] = prompt[t]; par[w] = t == 0 ? -1 : w; win[w] = w; }
+    WB_TRY(step(user, tok.data(), par.data(), win.data(), W, 0, 0, nullptr, nullptr));
+  }
+  std::vector<int> ctl;
+  beam_chain_init(ctl, bl, prompt, P, eot);
+  WB_HIP(hipMemcpy(d_ctl.p, ctl.data(), ctl.size() * 4, hipMemcpyHostToDevice));
+  BeamChainArgs a;
+  a.ctl = d_ctl.as<int>(); a.bl = bl; a.topk_id = d_topk.as<int32_t>();
+  a.topk_lp = reinterpret_cast<float*>(d_topk.as<int32_t>() + (size_t)S * TOPK_MAX);
+  a.state_out = d_state.as<int>(); a.lay = L; a.k = k; a.eot = eot; a.V = V; a.step_pos = P - 1;
+  a.first = 1;
+  launch_dec_beam_update(nullptr, a);
+  a.first = 0;
+  std::vector<int> st(L.total);
+  std::vector<int32_t> ids((size_t)S * TOPK_MAX), cid((size_t)S * k);
+  std::vector<float> lps((size_t)S * TOPK_MAX), clp((size_t)S * k);
+  for (int depth = 0; depth < p->max_depth; depth++) {
+    WB_HIP(hipMemcpy(st.data(), d_state.p, st.size() * 4, hipMemcpyDeviceToHost));
+    const int n = st[ST_N];
+    if (n == 0) break;
+    WB_REQUIRE(n <= S, WB_ERR_STATE, "wb_beam_search_device: %d live rows", n);
+    for (int i = 0; i < n; i++) { tok[i] = st[L.tok + i]; par[i] = st[L.parent + i]; win[i] = st[L.win + i]; }
+    const int apply_mask = (P + depth) <= p->mask_until_len;
+    WB_TRY(step(user, tok.data(), par.data(), win.data(), n, apply_mask, k, cid.data(), clp.data()));
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < k; j++) { ids[(size_t)i * TOPK_MAX + j] = cid[(size_t)i * k + j]; lps[(size_t)i * TOPK_MAX + j] = clp[(size_t)i * k + j]; }
+    WB_HIP(hipMemcpy(d_topk.p, ids.data(), ids.size() * 4, hipMemcpyHostToDevice));
+    WB_HIP(hipMemcpy(d_topk.as<int32_t>() + (size_t)S * TOPK_MAX, lps.data(), lps.size() * 4, hipMemcpyHostToDevice));
+    launch_dec_beam_update(nullptr, a);
+  }
+  WB_HIP(hipMemcpy(ctl.data(), d_ctl.p, ctl.size() * 4, hipMemcpyDeviceToHost));
+  WB_REQUIRE(ctl[BC_ERR] == 0, WB_ERR_STATE, "beam search: NaN log-probability (reference panics)");
+  bool all_done = true;
+  return beam_chain_extract(ctl, bl, prompt, P, out_tokens, row_stride, out_lens, &all_done);
+}
 
 extern "C" {
 

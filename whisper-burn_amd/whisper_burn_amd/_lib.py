@@ -94,6 +94,8 @@ SIGNATURES = {
     "wb_waveform_to_tokens_prompted": (C.c_int, [C.c_void_p, c_float_p, C.c_int64, C.c_int, C.POINTER(WbDecodeParams),
                                                  c_uint8_p, C.c_int32, C.c_int32, c_int32_p, C.c_int32, c_int32_p,
                                                  c_int32_p, C.c_int64, c_int64_p]),
+    "wb_beam_search_device": (C.c_int, [C.c_int, C.POINTER(WbDecodeParams), C.c_int, C.c_int, C.c_void_p, C.c_void_p, c_int32_p,
+                                        C.c_int32, c_int32_p]),
     "wb_beam_search": (C.c_int, [C.POINTER(WbDecodeParams), C.c_int, C.c_int, C.c_void_p, C.c_void_p, c_int32_p,
                                  C.c_int32, c_int32_p]),
     "wb_waveform_to_tokens": (C.c_int, [C.c_void_p, c_float_p, C.c_int64, C.c_int, C.POINTER(WbDecodeParams),
