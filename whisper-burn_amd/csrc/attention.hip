@@ -381,7 +381,8 @@ __global__ __launch_bounds__(NW * 64) void attention_f16x3_kernel(const float* _
                                                                     const float* __restrict__ V, int ldkv,
                                                                     float* __restrict__ O, int ldo,
                                                                     const AttnSeg* __restrict__ segs, float scale,
-                                                                    int causal) {
+                                                                    int causal, a_u16* __restrict__ Oh,
+                                                                    a_u16* __restrict__ Ol) {
   __shared__ __attribute__((aligned(16))) a_u16 Khs[2][KV_TILE][KH_LD];
   __shared__ __attribute__((aligned(16))) a_u16 Kls[2][KV_TILE][KH_LD];
   __shared__ __attribute__((aligned(16))) a_u16 Vth[2][64][VT_LD];
@@ -529,14 +530,23 @@ __global__ __launch_bounds__(NW * 64) void attention_f16x3_kernel(const float* _
 
   const float l_tot = xor32_sum(l_run);
   if (qi < seg.q_len) {
-    float* op = O + (int64_t)(seg.q_row0 + qi) * ldo + head * 64;
+    const int64_t orow = (int64_t)(seg.q_row0 + qi) * ldo + head * 64;
 #pragma unroll
     for (int tt = 0; tt < 2; tt++)
 #pragma unroll
       for (int g = 0; g < 4; g++) {
-        float4 v = make_float4(oacc[tt][4 * g + 0] / l_tot, oacc[tt][4 * g + 1] / l_tot,
-                               oacc[tt][4 * g + 2] / l_tot, oacc[tt][4 * g + 3] / l_tot);
-        *reinterpret_cast<float4*>(op + 32 * tt + 8 * g + 4 * hh) = v;
+        const float v[4] = {oacc[tt][4 * g + 0] / l_tot, oacc[tt][4 * g + 1] / l_tot,
+                            oacc[tt][4 * g + 2] / l_tot, oacc[tt][4 * g + 3] / l_tot};
+        const int64_t o = orow + 32 * tt + 8 * g + 4 * hh;
+        if (Oh) {                                    // the out-projection is a split-precision GEMM: fp16 pieces (GemmArgs::Ah)
+          unsigned hb[4], lb[4];
+#pragma unroll
+          for (int c = 0; c < 4; c++) { _Float16 h, l; a_split(v[c], h, l); hb[c] = a_bits(h); lb[c] = a_bits(l); }
+          *reinterpret_cast<uint2*>(Oh + o) = make_uint2(hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16));
+          *reinterpret_cast<uint2*>(Ol + o) = make_uint2(lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16));
+        } else {
+          *reinterpret_cast<float4*>(O + o) = make_float4(v[0], v[1], v[2], v[3]);
+        }
       }
   }
 }
@@ -550,20 +560,22 @@ static bool attention_kvsplit_enabled() {
 
 // split: the 16-bit matrix path (attention_f16x3_kernel) for the LDS-tiled shapes; the key-split kernel for small grids and the
 // 64-query blocks stay exact f32
-void launch_attention(hipStream_t st, const float* Q, int ldq, const float* K, const float* V, int ldkv,
+bool launch_attention(hipStream_t st, const float* Q, int ldq, const float* K, const float* V, int ldkv,
                       float* O, int ldo, const AttnSeg* segs_dev, int n_segs, int max_q_len, int n_head,
-                      float scale, int causal, bool split) {
-  if (n_segs <= 0 || max_q_len <= 0) return;
+                      float scale, int causal, bool split, uint16_t* Oh, uint16_t* Ol) {
+  if (n_segs <= 0 || max_q_len <= 0) return false;
   static const bool f16_enabled = [] { const char* e = getenv("WHISPER_HIP_ATTN_F16"); return !(e && e[0] == '0'); }();
   const int64_t blocks128 = (int64_t)((max_q_len + 127) / 128) * n_head * n_segs;
   const bool kvsplit = !causal && max_q_len >= 256 && blocks128 < 384 && attention_kvsplit_enabled();
   if (split && f16_enabled && !kvsplit && max_q_len > 64) {
     dim3 grid((max_q_len + 127) / 128, n_head, n_segs);
+    const bool pieces = Oh != nullptr && Ol != nullptr;
     hipLaunchKernelGGL((attention_f16x3_kernel<4>), grid, dim3(256), 0, st, Q, ldq, K, V, ldkv, O, ldo, segs_dev,
-                       scale, causal);
-    return;
+                       scale, causal, pieces ? Oh : nullptr, pieces ? Ol : nullptr);
+    return pieces;
   }
   launch_attention_f32(st, Q, ldq, K, V, ldkv, O, ldo, segs_dev, n_segs, max_q_len, n_head, scale, causal);
+  return false;
 }
 
 void launch_attention_f32(hipStream_t st, const float* Q, int ldq, const float* K, const float* V, int ldkv,

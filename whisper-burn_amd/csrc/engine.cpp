@@ -49,14 +49,18 @@ struct SplitFlagScope {
 
 int gemm_dispatch(const wb_model* m, hipStream_t st, const GemmArgs& a, int ldwt, const uint16_t* sh, const uint16_t* sl) {
   // exact-f32 models: encoder-side weights that carry a split copy go through the three-product fp16 kernel
-  if (m->split_active() && tl_split_flag && sh && sl && a.conv1_tstride == 0 && a.K % 32 == 0 && ldwt % 8 == 0 && a.ksplit <= 1 &&
-      (a.a_desc == nullptr || a.a_mask_align % 8 == 0)) {
+  // (a.Ah: the activations already ARE fp16 pieces -- the producer decided at the top of the pass; a model that left the split
+  // kernel in the meantime (another session's guard tripped) still finishes this pass on it, judged by the pass's own flag)
+  const bool pieces = a.Ah != nullptr || a.Ch != nullptr;
+  if ((m->split_active() || pieces) && tl_split_flag && sh && sl && a.conv1_tstride == 0 && a.K % 32 == 0 && ldwt % 8 == 0 &&
+      a.ksplit <= 1 && (a.a_desc == nullptr || a.a_mask_align % 8 == 0)) {
     GemmArgs g = a;
     g.range_flag = tl_split_flag;
     WB_REQUIRE(launch_gemm_f16x3(st, g, sh, sl, ldwt) == 0, WB_ERR_SHAPE, "split gemm: unsupported shape M=%d N=%d K=%d", a.M,
                a.N, a.K);
     return WB_OK;
   }
+  WB_REQUIRE(!pieces, WB_ERR_STATE, "gemm: activation pieces handed to a GEMM that cannot take the split-precision kernel");
   WB_REQUIRE(launch_gemm_f32(st, a) == 0, WB_ERR_SHAPE, "gemm: unsupported shape M=%d N=%d K=%d ldb=%d", a.M,
              a.N, a.K, a.ldb);
   return WB_OK;
@@ -110,7 +114,10 @@ static int gemm(const wb_model* m, hipStream_t st, const GemmArgs& a, const Line
 // f64), and with 24 - 64 such products per forward it set the distance of the whole path from the
 // exact result.  Blocks of 1024 cost one extra read + write of the [M][d] result per block (~1.5 % of the encoder).
 constexpr int GEMM_KBLOCK = 1024;
-static int gemm_residual_kblocked(const wb_model* m, hipStream_t st, const float* A, int M, const LinearW& w, float* x) {
+// Ah / Al non-null: A as fp16 pieces (GemmArgs::Ah) -- only when every block takes the split-precision kernel (the caller
+// checks w.sh and the shape)
+static int gemm_residual_kblocked(const wb_model* m, hipStream_t st, const float* A, int M, const LinearW& w, float* x,
+                                  const uint16_t* Ah = nullptr, const uint16_t* Al = nullptr) {
   const bool blocked = w.k >= 2 * GEMM_KBLOCK && w.k % GEMM_KBLOCK == 0;
   const int kb = blocked ? GEMM_KBLOCK : w.k;
   for (int k0 = 0; k0 < w.k; k0 += kb) {
@@ -118,7 +125,8 @@ static int gemm_residual_kblocked(const wb_model* m, hipStream_t st, const float
     // C[row][col] from the SAME thread, once, with ksplit <= 1 (GemmArgs::residual: "may alias C") -- a split-K or
     // multi-pass tile configuration would break it, hence the explicit ksplit below and the check in gemm_dispatch's callee.
     GemmArgs g;
-    g.A = A + k0; g.lda = w.k; g.B = w.w + (size_t)k0 * w.n; g.ldb = w.n; g.C = x; g.ldc = w.n;
+    g.A = A + k0; g.lda = w.k; g.B = w.w + (size_t)k0 * w.n;
+    if (Ah) { g.Ah = Ah + k0; g.Al = Al + k0; } g.ldb = w.n; g.C = x; g.ldc = w.n;
     g.bias = k0 == 0 ? w.b : nullptr;              // first block: + bias + the residual stream; later blocks: + the running sum
     g.residual = x; g.ldr = w.n;
     g.M = M; g.N = w.n; g.K = kb; g.ksplit = 1;
@@ -216,24 +224,47 @@ int run_encoder_unguarded(wb_model* m, hipStream_t st, Workspace& ws, const MelB
     g.aux = m->enc_pos; g.aux_idx = ws.auxidx.as<int32_t>(); g.ld_aux = d;
     WB_TRY(gemm(m, st, g, &m->conv2));
   }
+  // Activation pieces (round 6): inside a guarded split-precision pass the PRODUCERS of the layer GEMMs' A operands --
+  // LayerNorm, the attention kernel, the GELU epilogue of lin1 -- write them as fp16 hi / lo planes once (the same 4 bytes per
+  // element, in the same buffers), and the GEMM's A path is two 16-byte loads straight to LDS.  WHISPER_HIP_ENCODER_PIECES=0
+  // keeps f32 activations (every column block of every consumer then splits its A tile itself, as in round 5).
+  static const bool pieces_enabled = []() { const char* e = getenv("WHISPER_HIP_ENCODER_PIECES"); return !(e && e[0] == '0'); }();
+  const bool split_pass = m->split_active() && tl_split_flag != nullptr && d % 32 == 0;
+  uint16_t* h_hi = reinterpret_cast<uint16_t*>(h); uint16_t* h_lo = h_hi + (size_t)rows2 * d;
+  uint16_t* att_hi = reinterpret_cast<uint16_t*>(att); uint16_t* att_lo = att_hi + (size_t)rows2 * d;
+  uint16_t* hm_hi = reinterpret_cast<uint16_t*>(hm); uint16_t* hm_lo = hm_hi + (size_t)rows2 * 4 * d;
   for (int i = 0; i < D.n_audio_layer; i++) {   // ResidualEncoderAttentionBlock::forward, mod.rs:299-303
     const EncBlockW& b = m->enc[i];
-    launch_layernorm(st, x, h, rows2, d, b.ln1.g, b.ln1.b, b.ln1.eps, m->ln_eps_inside_sqrt);
+    const bool pcs = pieces_enabled && split_pass && b.qkv.sh && b.out.sh && b.mlp1.sh && b.mlp2.sh;
     GemmArgs g = linear_args(h, rows2, b.qkv, qkv);
+    if (pcs) {
+      launch_layernorm_pieces(st, x, h_hi, h_lo, rows2, d, b.ln1.g, b.ln1.b, b.ln1.eps, m->ln_eps_inside_sqrt);
+      g.Ah = h_hi; g.Al = h_lo;
+    } else {
+      launch_layernorm(st, x, h, rows2, d, b.ln1.g, b.ln1.b, b.ln1.eps, m->ln_eps_inside_sqrt);
+    }
     g.col_scale = m->qk_scale; g.col_scale_period = 3 * d; g.col_scale_width = 2 * d;   // q*s, k*s (mod.rs:506-514)
     WB_TRY(gemm(m, st, g, &b.qkv));
     // (split precision only inside a guarded pass whose out-projection runs on the split GEMM: that GEMM's range guard is
     // what reports an attention operand outside fp16's range -- NaN in, flag raised, the pass repeated in exact f32)
-    launch_attention(st, qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, att, d, ws.segs.as<AttnSeg>(), nw, maxC, H, 1.0f, 0,
-                     m->split_active() && tl_split_flag != nullptr && b.out.sh != nullptr && d % 32 == 0);
+    const bool att_pcs = launch_attention(st, qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, att, d, ws.segs.as<AttnSeg>(), nw, maxC,
+                                          H, 1.0f, 0, split_pass && b.out.sh != nullptr, pcs ? att_hi : nullptr,
+                                          pcs ? att_lo : nullptr);
     g = linear_args(att, rows2, b.out, x);
+    if (att_pcs) { g.Ah = att_hi; g.Al = att_lo; }
     g.residual = x; g.ldr = d;
     WB_TRY(gemm(m, st, g, &b.out));
-    launch_layernorm(st, x, h, rows2, d, b.ln2.g, b.ln2.b, b.ln2.eps, m->ln_eps_inside_sqrt);
     g = linear_args(h, rows2, b.mlp1, hm);
+    if (pcs) {
+      launch_layernorm_pieces(st, x, h_hi, h_lo, rows2, d, b.ln2.g, b.ln2.b, b.ln2.eps, m->ln_eps_inside_sqrt);
+      g.Ah = h_hi; g.Al = h_lo;
+      g.Ch = hm_hi; g.Cl = hm_lo;                 // GELU(lin1) as pieces: lin2's A operand
+    } else {
+      launch_layernorm(st, x, h, rows2, d, b.ln2.g, b.ln2.b, b.ln2.eps, m->ln_eps_inside_sqrt);
+    }
     g.act = ACT_GELU;
     WB_TRY(gemm(m, st, g, &b.mlp1));
-    WB_TRY(gemm_residual_kblocked(m, st, hm, rows2, b.mlp2, x));
+    WB_TRY(gemm_residual_kblocked(m, st, hm, rows2, b.mlp2, x, pcs ? hm_hi : nullptr, pcs ? hm_lo : nullptr));
   }
   launch_layernorm(st, x, out_dev, rows2, d, m->ln_post.g, m->ln_post.b, m->ln_post.eps, m->ln_eps_inside_sqrt);
   WB_HIP(hipGetLastError());

@@ -75,7 +75,9 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make
 // CUs (tiny.en's 3-window encoder: 174 blocks of 64 x 64): one block per CU, nothing to overlap a tile's memory round trip
 // with, and a k-loop of 12 tiles cost 12 round trips (23 us per GEMM for 8 us of MFMA work).  They have registers to spare
 // (110 of 256), so they keep PF = 4 tiles in flight; the 128 x 128 configuration (246 VGPRs, two blocks per CU) keeps PF = 1.
-template <int BM, int BN, int WGM, int WGN, int PF>
+// APRE: the activations arrive as fp16 pieces (GemmArgs::Ah / Al, written once by their producer): an A item is two 16-byte
+// loads that go to LDS as they are -- no split in the k-loop.
+template <int BM, int BN, int WGM, int WGN, int PF, bool APRE>
 __global__ __launch_bounds__(NT, WB_F16X3_MIN_WAVES) void gemm_f16x3_kernel(GemmArgs g, const u16* __restrict__ Wh,
                                                                             const u16* __restrict__ Wl, int ldwt) {
   constexpr int TM = BM / WGM, TN = BN / WGN;
@@ -98,13 +100,16 @@ __global__ __launch_bounds__(NT, WB_F16X3_MIN_WAVES) void gemm_f16x3_kernel(Gemm
   // A: (row, k-octet) items, 8 f32 -> 8 + 8 fp16; B: (n, k-octet) items, 16 B of each piece
   constexpr int A_IT = (BM * (BK / 8) + NT - 1) / NT, B_IT = (BN * (BK / 8) + NT - 1) / NT;
   const float* a_row[A_IT];
+  int64_t a_poff[A_IT];                            // APRE: element offset of the row in the piece planes (-1: no row)
   int a_klo[A_IT], a_khi[A_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; i++) {
     const int idx = tid + i * NT, r = idx / (BK / 8), m = m0 + r;
-    a_row[i] = nullptr; a_klo[i] = 0; a_khi[i] = 0;
+    a_row[i] = nullptr; a_klo[i] = 0; a_khi[i] = 0; a_poff[i] = -1;
     if (r < BM && m < M) {
-      if (g.a_desc) {
+      if constexpr (APRE) {
+        a_poff[i] = (int64_t)m * g.lda;
+      } else if (g.a_desc) {
         const RowDesc d = g.a_desc[m];
         a_row[i] = g.A + d.off; a_klo[i] = d.klo; a_khi[i] = d.khi;
       } else {
@@ -121,6 +126,15 @@ __global__ __launch_bounds__(NT, WB_F16X3_MIN_WAVES) void gemm_f16x3_kernel(Gemm
     for (int i = 0; i < A_IT; i++) {
       const int idx = tid + i * NT, k = k0 + (idx % (BK / 8)) * 8;
       float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+      if constexpr (APRE) {
+        // (ra_lo carries the octet's eight hi halves, ra_hi its eight lo halves: raw bits in the same registers)
+        if (a_poff[i] >= 0) {
+          lo = *reinterpret_cast<const float4*>(g.Ah + a_poff[i] + k);
+          hi = *reinterpret_cast<const float4*>(g.Al + a_poff[i] + k);
+        }
+        ra_lo[sl][i] = lo; ra_hi[sl][i] = hi;
+        continue;
+      }
       // whole octets only: a row mask [klo, khi) must be a multiple of 8 at both ends -- the HOST guarantees it
       // (GemmArgs::a_mask_align, checked in gemm_dispatch; a per-element path for straddling octets cost the hot loop ~100
       // compare / branch instructions per k-tile for a case no caller has)
@@ -145,7 +159,11 @@ __global__ __launch_bounds__(NT, WB_F16X3_MIN_WAVES) void gemm_f16x3_kernel(Gemm
       const int idx = tid + i * NT, r = idx / (BK / 8), ko = (idx % (BK / 8)) * 8;
       if (r < BM) {
         uint4 hi, lo;
-        split8(ra_lo[sl][i], ra_hi[sl][i], hi, lo);
+        if constexpr (APRE) {
+          hi = __builtin_bit_cast(uint4, ra_lo[sl][i]); lo = __builtin_bit_cast(uint4, ra_hi[sl][i]);
+        } else {
+          split8(ra_lo[sl][i], ra_hi[sl][i], hi, lo);
+        }
         *reinterpret_cast<uint4*>(&Ah[buf][r][ko]) = hi;
         *reinterpret_cast<uint4*>(&Al[buf][r][ko]) = lo;
       }
@@ -276,7 +294,15 @@ __global__ __launch_bounds__(NT, WB_F16X3_MIN_WAVES) void gemm_f16x3_kernel(Gemm
         if (g.col_scale_period > 0) v *= cs;
         if (g.residual) v = res[r] + v;
         if (g.aux) v = v + ax[r];
-        if (col_ok && row < M) Cout[cbase + (int64_t)row * g.ldc] = v;
+        if (col_ok && row < M) {
+          if (g.Ch) {                                // the consumer is another split-precision GEMM: pieces, not f32
+            u16 ph, pl;
+            split1(v, ph, pl);
+            g.Ch[(int64_t)row * g.ldc + col] = ph; g.Cl[(int64_t)row * g.ldc + col] = pl;
+          } else {
+            Cout[cbase + (int64_t)row * g.ldc] = v;
+          }
+        }
       }
     }
   // range guard: the host re-runs the pass on the exact-f32 kernel and stops using this one (engine.cpp: split_guarded)
@@ -286,7 +312,8 @@ __global__ __launch_bounds__(NT, WB_F16X3_MIN_WAVES) void gemm_f16x3_kernel(Gemm
 template <int BM, int BN, int WGM, int WGN, int PF>
 void launch_cfg(hipStream_t st, const GemmArgs& a, const u16* Wh, const u16* Wl, int ldwt) {
   dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.ksplit > 1 ? a.ksplit : 1);
-  WB_KLAUNCH((gemm_f16x3_kernel<BM, BN, WGM, WGN, PF>), grid, dim3(NT), 0, st, a, Wh, Wl, ldwt);
+  if (a.Ah) WB_KLAUNCH((gemm_f16x3_kernel<BM, BN, WGM, WGN, PF, true>), grid, dim3(NT), 0, st, a, Wh, Wl, ldwt);
+  else WB_KLAUNCH((gemm_f16x3_kernel<BM, BN, WGM, WGN, PF, false>), grid, dim3(NT), 0, st, a, Wh, Wl, ldwt);
 }
 
 // W [K][N] f32 -> hi, lo [N][K] fp16 (K-contiguous), through a 32 x 32 LDS tile
@@ -318,6 +345,8 @@ void launch_split_weight_f16(hipStream_t st, const float* W, int K, int N, uint1
 int launch_gemm_f16x3(hipStream_t st, const GemmArgs& a, const uint16_t* Wh, const uint16_t* Wl, int ldwt) {
   if (a.M <= 0 || a.N <= 0) return 0;
   if (a.K % BK != 0 || ldwt % 8 != 0 || a.conv1_tstride > 0) return -1;
+  if (a.Ah && (!a.Al || a.a_desc || a.lda % 8 != 0)) return -1;                 // pieces: plain 16-byte-aligned rows only
+  if (a.Ch && (!a.Cl || a.ksplit > 1 || a.c_block_cols > 0)) return -1;
   if (a.ksplit > 1 && (a.bias || a.residual || a.aux || a.act != ACT_NONE || a.col_scale_period > 0)) return -1;
   auto blocks = [&](int bm, int bn) { return (int64_t)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
   static const int force_tile = []() { const char* e = getenv("WHISPER_HIP_SPLIT_TILE"); return e ? atoi(e) : 0; }();   // developer A/B

@@ -94,6 +94,11 @@ struct GemmArgs {
   int c_block_cols = 0; int64_t c_block_stride = 0;
   int* range_flag = nullptr;                     // split-precision kernel only: set to 1 (system scope) when a result is not
                                                  // finite, i.e. an operand left fp16's range (|x| >= 65504)
+  // split-precision kernel only -- activations as fp16 PIECES (hi = fp16(x), lo = fp16((x - hi) 2^11); two [M][ld] planes,
+  // the same 4 bytes per element as f32), written ONCE by the producer instead of being split by every column block of every
+  // consumer GEMM on its way into LDS (round 5: ~100 of the ~226 non-MFMA instructions per k-tile of that kernel):
+  const uint16_t* Ah = nullptr; const uint16_t* Al = nullptr;   // A pre-split: A[m][k] pieces at [m * lda + k] (plain rows only)
+  uint16_t* Ch = nullptr; uint16_t* Cl = nullptr;               // C as pieces at [row * ldc + col] INSTEAD of the f32 C
 };
 int launch_gemm_f32(hipStream_t st, const GemmArgs& a);   // exact-f32 MFMA (v_mfma_f32_32x32x2_f32)
 // split precision (gemm_f16x3.hip): f32-grade products from three fp16 MFMAs; weight pre-split as Wh, Wl [N][ldwt] fp16
@@ -104,6 +109,9 @@ void launch_split_weight_f16(hipStream_t st, const float* W, int K, int N, uint1
 // y[m] = LN(x[m]) * g + b, biased variance; eps placement per variant (see whisper_hip.h)
 void launch_layernorm(hipStream_t st, const float* x, float* y, int M, int d, const float* g, const float* b,
                       float eps, int eps_inside_sqrt);
+// ... with the result as fp16 pieces (GemmArgs::Ah / Al): yh, yl [M][d]
+void launch_layernorm_pieces(hipStream_t st, const float* x, uint16_t* yh, uint16_t* yl, int M, int d, const float* g,
+                             const float* b, float eps, int eps_inside_sqrt);
 // x[r] = E[tok[r]] + pos[r % L]    (mod.rs:141-146)
 void launch_embed(hipStream_t st, const int32_t* tok, int n_rows, int L, int d, const float* E, const float* pos,
                   float* x);
@@ -116,8 +124,10 @@ void launch_attention_f32(hipStream_t st, const float* Q, int ldq, const float* 
                           float scale, int causal);
 // the same with the choice of arithmetic: split = the 16-bit matrix path (fp16 hi / lo operands, three MFMAs per product, f32
 // accumulate: f32-grade; operands must stay inside fp16's range -- see attention.hip), else exact f32
-void launch_attention(hipStream_t st, const float* Q, int ldq, const float* K, const float* V, int ldkv,
+// Oh / Ol non-null: the 16-bit kernel writes its output as fp16 pieces there (ldo halves per row) instead of f32 into O.
+// Returns true when it did (the caller's next GEMM then reads pieces), false when O holds f32 (exact-f32 kernels).
+bool launch_attention(hipStream_t st, const float* Q, int ldq, const float* K, const float* V, int ldkv,
                       float* O, int ldo, const AttnSeg* segs_dev, int n_segs, int max_q_len, int n_head,
-                      float scale, int causal, bool split);
+                      float scale, int causal, bool split, uint16_t* Oh = nullptr, uint16_t* Ol = nullptr);
 
 }  // namespace wb
