@@ -71,9 +71,14 @@ __global__ __launch_bounds__(SK_NT, MT <= 2 ? 2 : 1) void dec_skinny_gemm_kernel
   __shared__ __attribute__((aligned(16))) float smem[MT * 512 * LDW > MT * (PAIR ? 4096 : 8192) ? MT * 512 * LDW : MT * (PAIR ? 4096 : 8192)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int strip = blockIdx.x, z = blockIdx.y;
-  const int kchunk = a.K / a.ksplit;                 // host: K % (32 ksplit) == 0
+  // K-slice z: the 32-row tiles [z T / ks, (z + 1) T / ks) of the T = K / 32 tiles -- slices may differ by one tile, so that
+  // the launch can have close to one block per compute unit whatever K / 32 factors into (round 6: large-v2's MLP products
+  // ran 160 blocks on 256 CUs because 1280 / 32 = 40 tiles only split evenly by 2 or 4)
+  const int nt_all = a.K >> 5;
+  const int t0 = (int)((int64_t)z * nt_all / a.ksplit), t1 = (int)((int64_t)(z + 1) * nt_all / a.ksplit);
+  const int kchunk = (t1 - t0) << 5;                 // host: every slice <= 32 LDW rows
   const int kw = kchunk >> 3;                        // K-rows per wave (multiple of 4)
-  const int kb = z * kchunk;
+  const int kb = t0 << 5;
   const int n0 = strip * 64;
   const int krow = lane >> 4, cq = lane & 15;
 
@@ -218,9 +223,11 @@ __global__ __launch_bounds__(SK_NT, MT <= 2 ? 2 : 1) void dec_skinny_f16x3_kerne
   __shared__ __attribute__((aligned(16))) float smem[WORDS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int strip = blockIdx.x, z = blockIdx.y;
-  const int kchunk = a.K / a.ksplit;                 // host: K % (32 ksplit) == 0, kchunk <= 32 LDW
-  const int nch = kchunk >> 5;                       // 32-deep tiles of the block
-  const int kb = z * kchunk;
+  const int nt_all = a.K >> 5;                       // (uneven K slices: see dec_skinny_gemm_kernel)
+  const int t0 = (int)((int64_t)z * nt_all / a.ksplit), t1 = (int)((int64_t)(z + 1) * nt_all / a.ksplit);
+  const int kchunk = (t1 - t0) << 5;                 // host: every slice <= 32 LDW rows
+  const int nch = t1 - t0;                           // 32-deep tiles of the block
+  const int kb = t0 << 5;
   const int n0 = strip * 64;
   const int kg = lane >> 4, j = lane & 15;
   u16* As_hi = reinterpret_cast<u16*>(smem);
@@ -344,9 +351,9 @@ int skinny_ksplit(int K, int N, int max_ks, int max_rows) {
   static const int max_blocks = []() { const char* e = getenv("WHISPER_HIP_SK_MAX_BLOCKS"); return e ? atoi(e) : 256; }();
   const int strips = N / 64;
   int best = 0;
-  for (int ks = 1; ks <= std::min(KS_MAX, max_ks); ks++) {
-    if (K % (32 * ks) != 0) continue;
-    if (K / ks / 32 > sk_ldw((max_rows + 15) / 16)) continue;
+  const int nt = K / 32;
+  for (int ks = 1; ks <= std::min(std::min(KS_MAX, max_ks), nt); ks++) {
+    if ((nt + ks - 1) / ks > sk_ldw((max_rows + 15) / 16)) continue;      // the largest slice (slices differ by <= one 32-row tile)
     if (best > 0 && strips * ks > max_blocks) break;
     best = ks;
   }
@@ -356,8 +363,8 @@ int skinny_ksplit(int K, int N, int max_ks, int max_rows) {
 bool skinny_supported(int M, int K, int N) { return M >= 1 && M <= 64 && skinny_ksplit(K, N, KS_MAX, M) > 0; }
 
 int launch_dec_skinny_gemm(hipStream_t st, const SkinnyArgs& a) {
-  if (a.ksplit < 1 || a.ksplit > KS_MAX || a.K % (32 * a.ksplit) != 0 || a.N % 64 != 0 || a.M < 1 || a.M > 64) return -1;
-  if (a.K / a.ksplit / 32 > sk_ldw((a.M + 15) / 16)) return -1;
+  if (a.ksplit < 1 || a.ksplit > KS_MAX || a.K % 32 != 0 || a.ksplit > a.K / 32 || a.N % 64 != 0 || a.M < 1 || a.M > 64) return -1;
+  if ((a.K / 32 + a.ksplit - 1) / a.ksplit > sk_ldw((a.M + 15) / 16)) return -1;
   const int MT = (a.M + 15) / 16;
   const dim3 grid(a.N / 64, a.ksplit), block(SK_NT);
   if (a.Bh && a.Bl) {                                // split-precision variant: same geometry, same planes
