@@ -41,4 +41,9 @@ timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_C
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES -d /tmp/p_k12b -o pmc -- python $BK > $OUT/k12_pmc_b.log 2>&1
 python $R/profiles/summarize_counters.py $(find /tmp/p_k12a /tmp/p_k12b -name '*.db') 2>&1 | grep -E "^==|gemm_f16x3|attention_f|layernorm" | head -60 > $OUT/k12_counters.txt
 head -30 $OUT/k12_counters.txt
+# the mel frontend's issue mix (what 1.29 G frames/s is a fraction of): dynamic VALU / LDS instruction counts and busy cycles
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d /tmp/p_mela -o pmc -- python $BG --steps 1 --warmup 0 > $OUT/mel_pmc_a.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_WAVES -d /tmp/p_melb -o pmc -- python $BG --steps 1 --warmup 0 > $OUT/mel_pmc_b.log 2>&1
+python $R/profiles/summarize_counters.py $(find /tmp/p_mela /tmp/p_melb -name '*.db') 2>&1 | grep -E "^==|mel_spectrogram" | head -40 > $OUT/mel_counters.txt
+cat $OUT/mel_counters.txt
 echo "[$(( $(date +%s) - T0 )) s] done"
