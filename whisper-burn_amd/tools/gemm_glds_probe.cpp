@@ -119,6 +119,118 @@ __global__ __launch_bounds__(256, STAGES <= 2 ? 2 : 1) void gemm_glds_kernel(Gem
       }
     }
 }
+
+// The same ring (2 stages, 2 blocks per CU) with the k-loop SKEWED so that the LDS reads of the next k-step are always issued
+// before the 12 MFMAs of the current one (the plain loop above exposes two LDS round trips per k-tile: ISA schedule
+// "8 ds_read, wait, 12 MFMA, 8 ds_read, wait, 12 MFMA"):
+//   [read F(t, ks1)] [12 MFMA on F(t, ks0)] [tile t+1 landed? ; barrier] [refill stage of tile t with t+2] [read F(t+1, ks0)] [12 MFMA on F(t, ks1)]
+__global__ __launch_bounds__(256, 2) void gemm_glds_pipe_kernel(GemmArgs g, const u16* __restrict__ Wh, const u16* __restrict__ Wl,
+                                                                 int ldwt) {
+  constexpr int BM = 128, BN = 128, PIECE = 128 * 32, STAGES = 2;
+  __shared__ __attribute__((aligned(16))) u16 smem[STAGES][4][PIECE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+  const int M = g.M, N = g.N, K = g.K;
+  const int nk = K / 32;
+  const u16* srcA_h[2]; const u16* srcA_l[2]; const u16* srcB_h[2]; const u16* srcB_l[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int p = i * 256 + tid, row = p >> 2, ps = p & 3, ls = ps ^ ((row >> 2) & 3);
+    const int ma = min(m0 + row, M - 1), nb = min(n0 + row, N - 1);
+    srcA_h[i] = g.Ah + (int64_t)ma * g.lda + ls * 8; srcA_l[i] = g.Al + (int64_t)ma * g.lda + ls * 8;
+    srcB_h[i] = Wh + (int64_t)nb * ldwt + ls * 8; srcB_l[i] = Wl + (int64_t)nb * ldwt + ls * 8;
+  }
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto issue = [&](int t, int stage) {
+    const int k0 = t * 32;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const unsigned off = (unsigned)((i * 256 + wave_u * 64) * 16);
+      glds16(srcA_h[i] + k0, lds_addr(&smem[stage][0][0]) + off);
+      glds16(srcA_l[i] + k0, lds_addr(&smem[stage][1][0]) + off);
+      glds16(srcB_h[i] + k0, lds_addr(&smem[stage][2][0]) + off);
+      glds16(srcB_l[i] + k0, lds_addr(&smem[stage][3][0]) + off);
+    }
+  };
+  f32x16 acc[2][2], acl[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) { acc[i][j][r] = 0.f; acl[i][j][r] = 0.f; }
+  struct Frags { f16x8 ah[2], al[2], bh[2], bl[2]; };
+  auto read_frags = [&](Frags& f, int stage, int ks) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int row = wm * 64 + i * 32 + li, sl = (ks * 2 + lh) ^ ((row >> 2) & 3);
+      f.ah[i] = *reinterpret_cast<const f16x8*>(&smem[stage][0][(row * 4 + sl) * 8]);
+      f.al[i] = *reinterpret_cast<const f16x8*>(&smem[stage][1][(row * 4 + sl) * 8]);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int row = wn * 64 + j * 32 + li, sl = (ks * 2 + lh) ^ ((row >> 2) & 3);
+      f.bh[j] = *reinterpret_cast<const f16x8*>(&smem[stage][2][(row * 4 + sl) * 8]);
+      f.bl[j] = *reinterpret_cast<const f16x8*>(&smem[stage][3][(row * 4 + sl) * 8]);
+    }
+  };
+  // half a k-step: the six MFMAs of A row block i (the accumulation order per accumulator is the plain loop's)
+  auto mma_half = [&](const Frags& f, int i) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+      acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acl[i][j], 0, 0, 0);
+      acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acl[i][j], 0, 0, 0);
+    }
+  };
+  Frags f0, f1;
+  issue(0, 0);
+  if (nk > 1) issue(1, 1);
+  if (nk > 1) wait_vm<8>(); else wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+  read_frags(f0, 0, 0);
+  for (int t = 0; t < nk; t++) {
+    const int stage = t & 1;
+    // the reads of a k-step sit BETWEEN the two MFMA halves of the step before it: never in front of a wait
+    mma_half(f0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(f1, stage, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_half(f0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < nk) {
+      // tile t + 1 has landed for this wave (its 8 instructions are the only ones outstanding) and this wave's reads of
+      // tile t are complete (issued six MFMAs ago): behind the barrier both hold for every wave -> stage t % 2 is free
+      wait_vm<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t + 2 < nk) issue(t + 2, stage);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mma_half(f1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < nk) read_frags(f0, stage ^ 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_half(f1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int col = n0 + wn * 64 + j * 32 + li;
+      const bool col_ok = col < N;
+      const float bias = g.bias ? g.bias[col_ok ? col : N - 1] : 0.f;
+      const int rbase = m0 + wm * 64 + i * 32 + 4 * lh;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
+        const float v = (acc[i][j][r] + acl[i][j][r] * LO_UNSCALE) + bias;
+        if (col_ok && row < M) g.C[(int64_t)row * g.ldc + col] = v;
+      }
+    }
+}
 __global__ void split_rows_kernel(const float* x, u16* hi, u16* lo, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) { u16 h, l; split1(x[i], h, l); hi[i] = h; lo[i] = l; }
@@ -150,12 +262,13 @@ int main() {
     g.A = A; g.lda = s.K; g.Ah = Ah; g.Al = Al; g.C = C; g.ldc = s.N; g.bias = bias; g.M = s.M; g.N = s.N; g.K = s.K;
     const double flop = 2.0 * s.M * s.K * s.N;
     const dim3 grid((s.N + 127) / 128, (s.M + 127) / 128);
-    for (int cfg = 0; cfg < 4; cfg++) {
+    for (int cfg = 0; cfg < 5; cfg++) {
       auto run = [&]() {
         if (cfg == 0) hipLaunchKernelGGL((gemm_f16x3_kernel<128, 128, 2, 2, 1, true>), grid, dim3(256), 0, st, g, Wh, Wl, s.K);
         else if (cfg == 1) hipLaunchKernelGGL((gemm_glds_kernel<2>), grid, dim3(256), 0, st, g, Wh, Wl, s.K);
         else if (cfg == 2) hipLaunchKernelGGL((gemm_glds_kernel<3>), grid, dim3(256), 0, st, g, Wh, Wl, s.K);
-        else hipLaunchKernelGGL((gemm_glds_kernel<4>), grid, dim3(256), 0, st, g, Wh, Wl, s.K);
+        else if (cfg == 3) hipLaunchKernelGGL((gemm_glds_kernel<4>), grid, dim3(256), 0, st, g, Wh, Wl, s.K);
+        else hipLaunchKernelGGL(gemm_glds_pipe_kernel, grid, dim3(256), 0, st, g, Wh, Wl, s.K);
       };
       hipMemsetAsync(C, 0, (size_t)s.M * s.N * 4, st);
       run();
@@ -171,7 +284,7 @@ int main() {
       hipStreamSynchronize(st);
       float ms; hipEventElapsedTime(&ms, e0, e1);
       printf("%-11s M=%5d K=%4d N=%4d %-18s %8.1f us  %6.1f TF/s (f32-equivalent)  %s (%zu differ, max %.3g)\n", s.name, s.M, s.K, s.N,
-             cfg == 0 ? "product APRE" : cfg == 1 ? "glds 2 stages" : cfg == 2 ? "glds 3 stages" : "glds 4 stages", ms * 1e3 / REP,
+             cfg == 0 ? "product APRE" : cfg == 1 ? "glds 2 stages" : cfg == 2 ? "glds 3 stages" : cfg == 3 ? "glds 4 stages" : "glds 2 st. skewed", ms * 1e3 / REP,
              flop / (ms * 1e-3 / REP) / 1e12, ndiff == 0 ? "bit-identical" : "DIFFERS", ndiff, maxd);
     }
   }
