@@ -578,21 +578,20 @@ __global__ __launch_bounds__(256, 2) void dec_logits_mfma16_kernel(GemvArgs a) {
 #pragma unroll
   for (int c = 0; c < 4; c++) acc[c] = lg_f32x4{0.f, 0.f, 0.f, 0.f};
   const float* ap = xT + (khalf * kh) * MR + lane;
+  // (rolling ring: a slot is refilled for pass + 1 right behind its use -- the stream never drains between passes; loads
+  // return in order, so the wait in front of slot t + 1 leaves the younger refills in flight)
   for (int t0 = 0; t0 < nld; t0 += LD) {
 #pragma unroll
     for (int t = 0; t < LD; t++) {
       if (t0 + t < nld) {
         const float av = ap[(4 * (t0 + t)) * MR];
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[t].x, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[t].y, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[t].z, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[t].w, acc[3], 0, 0, 0);
-      }
-    }
-    if (t0 + LD < nld) {
-#pragma unroll
-      for (int t = 0; t < LD; t++)
+        const float4 w = bw[t];
         if (t0 + LD + t < nld) bw[t] = *reinterpret_cast<const float4*>(bp + (int64_t)(4 * (t0 + LD + t)) * a.ldw);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w.x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w.y, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w.z, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w.w, acc[3], 0, 0, 0);
+      }
     }
   }
   __syncthreads();                                   // everyone is done with the staged rows: reuse them as red[2][MR][CT]
@@ -1527,6 +1526,7 @@ __global__ __launch_bounds__(1024) void dec_beam_update_kernel(BeamChainArgs a) 
   // what the state block of the next step needs, kept for every window of the batch (<= 64)
   __shared__ int g_tok[64][BEAM_KB], g_fin[64][BEAM_KB], g_prev[64][BEAM_KB];
   __shared__ int g_nb[64], g_done[64], n_live_w[64], base_w[64];
+  __shared__ int s_tok[64 * MAX_BEAMS], s_par[64 * MAX_BEAMS];      // the next step's rows by slot (for the prepare phase)
   __shared__ int n_total;
   const BeamChainLayout& B = a.bl;
   const StepLayout& L = a.lay;
@@ -1545,9 +1545,11 @@ __global__ __launch_bounds__(1024) void dec_beam_update_kernel(BeamChainArgs a) 
     int my_fin = 0; double my_lp = 0.0;
     if (lane < BEAM_KB) {
       int nd = -1, fn = 0, pv = -1, sl = -1; double lp = 0.0;
-      if (act && lane < nb) {
+      if (act) {
+        // (requested together with nb / done above -- entries past nb hold zeros or an earlier generation: masked below)
         const int o = w * BEAM_KB + lane;
         nd = ctl[B.node + o]; fn = ctl[B.fin + o]; pv = ctl[B.prev_slot + o]; sl = ctl[B.slot_now + o]; lp = lpv[o];
+        if (lane >= nb) { nd = -1; fn = 0; pv = -1; sl = -1; lp = 0.0; }
       }
       w_node[wv][lane] = nd; w_fin[wv][lane] = fn; w_prev[wv][lane] = pv; w_slot[wv][lane] = sl; w_lp[wv][lane] = lp;
       my_fin = fn; my_lp = lp;
@@ -1689,6 +1691,7 @@ __global__ __launch_bounds__(1024) void dec_beam_update_kernel(BeamChainArgs a) 
         slot = base_w[w] + j;
         so[L.tok + slot] = g_tok[w][lane]; so[L.parent + slot] = g_prev[w][lane]; so[L.len + slot] = step_next + 1; so[L.win + slot] = w;
         so[L.win_slots + w * MAX_BEAMS + j] = slot;
+        s_tok[slot] = g_tok[w][lane]; s_par[slot] = g_prev[w][lane];
       }
       if (lane < nb) ctl[B.slot_now + w * BEAM_KB + lane] = slot;
       if (lane == 0) so[L.win_nb + w] = is_done ? 0 : __popcll(lm);
@@ -1702,7 +1705,7 @@ __global__ __launch_bounds__(1024) void dec_beam_update_kernel(BeamChainArgs a) 
     const int* tab_old = a.tabs + (size_t)((step_next & 1) ^ 1) * L.S * a.Lmax;
     const int len = step_next + 1, d4 = a.d >> 2;
     for (int i = wv; i < n_all; i += NW) {            // one wave per row
-      const int parent = so[L.parent + i], tk = so[L.tok + i];
+      const int parent = s_par[i], tk = s_tok[i];
       if (parent >= 0)
         for (int p = lane; p < len - 1; p += 64) tab_new[i * a.Lmax + p] = tab_old[parent * a.Lmax + p];
       if (lane == 0) tab_new[i * a.Lmax + len - 1] = step_next * L.S + i;
