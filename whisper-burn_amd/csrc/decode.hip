@@ -578,20 +578,23 @@ __global__ __launch_bounds__(256, 2) void dec_logits_mfma16_kernel(GemvArgs a) {
 #pragma unroll
   for (int c = 0; c < 4; c++) acc[c] = lg_f32x4{0.f, 0.f, 0.f, 0.f};
   const float* ap = xT + (khalf * kh) * MR + lane;
-  // (rolling ring: a slot is refilled for pass + 1 right behind its use -- the stream never drains between passes; loads
-  // return in order, so the wait in front of slot t + 1 leaves the younger refills in flight)
+  // (pass-synchronous: a rolling ring -- slot t refilled right behind its use -- measured 36.7 against 31.0 us per launch,
+  // profiles/r06_j_bench.json)
   for (int t0 = 0; t0 < nld; t0 += LD) {
 #pragma unroll
     for (int t = 0; t < LD; t++) {
       if (t0 + t < nld) {
         const float av = ap[(4 * (t0 + t)) * MR];
-        const float4 w = bw[t];
-        if (t0 + LD + t < nld) bw[t] = *reinterpret_cast<const float4*>(bp + (int64_t)(4 * (t0 + LD + t)) * a.ldw);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w.x, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w.y, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w.z, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w.w, acc[3], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[t].x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[t].y, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[t].z, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[t].w, acc[3], 0, 0, 0);
       }
+    }
+    if (t0 + LD < nld) {
+#pragma unroll
+      for (int t = 0; t < LD; t++)
+        if (t0 + LD + t < nld) bw[t] = *reinterpret_cast<const float4*>(bp + (int64_t)(4 * (t0 + LD + t)) * a.ldw);
     }
   }
   __syncthreads();                                   // everyone is done with the staged rows: reuse them as red[2][MR][CT]
