@@ -353,6 +353,11 @@ def test_bench_main_two_ranks_over_gloo(emu_lib):
     lv = out["large_v2"]                                  # N > 1: the large-v2 leg runs by default (the 8-GPU headline config)
     assert lv["n_gpus"] == 2 and lv["config"]["windows"] >= 2
     assert abs(lv["value"] - 16.0 / (lv["ms_per_step"] * 1e-3)) < 0.05 * lv["value"]
+    # the line is self-checking: the process group as torch.distributed reported it, every rank's (rank, local rank, device);
+    # legs at N > 1 have no committed golden (the N-GPU clip is another signal): tokens_checked null, not true
+    ro = out["config"]["ranks_observed"]
+    assert ro["world_size"] == 2 and ro["backend"] == "gloo" and [r[0] for r in ro["rank_local_rank_device"]] == [0, 1]
+    assert out["config"]["tokens_checked"] is None and lv["config"]["tokens_checked"] is None
 
 
 def test_outputs_are_bitwise_independent_of_the_schedule(emu_lib):
