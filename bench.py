@@ -138,6 +138,8 @@ def check_against_golden(rows, name, world, select=None):
     indices the golden holds (None = all).  A mismatch raises: a fast run that decodes other tokens is not a result.
     The goldens are rows of the 1-GPU audio (synth_audio is not prefix-stable, so the N-GPU clip is another signal): at
     N > 1 the leg reports tokens_checked = null."""
+    if os.environ.get("WHISPER_BENCH_SKIP_TOKEN_CHECK") == "1":      # developer builds that decode garbage on purpose (the "dry" K10)
+        return {"tokens_checked": False, "why": "WHISPER_BENCH_SKIP_TOKEN_CHECK=1: NOT a result"}
     if world != 1:
         return {"tokens_checked": None, "why": "golden rows exist for the 1-GPU clip only (tests/workloads.py)"}
     g = np.load(GOLDEN_NPZ)

@@ -311,7 +311,9 @@ __device__ __forceinline__ bool dec_mlp_body(const MlpFusedArgs& a, const int jb
       // persistent mode: nothing the block streams depends on its predecessor -- the weights are in flight (or landed)
       // while the block waits (pre-wake: the self-attention blocks of every row have finished); the cross-attention
       // planes arrive as tagged granules, re-read until every tag is the producers'
-      load_weights();
+#if !defined(WB_PS_DRY)                             // (developer "dry" build, tools/build_exp.sh dry: every wait and hand-off of
+      load_weights();                               //  a token with no weight / cache loads and no math -- the floor of this partition)
+#endif
       if (!ps_wait(ps)) return false;
 #pragma unroll
       for (int r = 0; r < MR; r++)
@@ -444,6 +446,25 @@ __device__ __forceinline__ bool dec_mlp_body(const MlpFusedArgs& a, const int jb
   WB_STAMP(1);
   __syncthreads();
   if constexpr (PS) { if (!ps_sweeps_ok(ps)) return false; }
+#if defined(WB_PS_DRY)
+  if constexpr (PS) {                                // dry build: publish what the role publishes (zeros), nothing else
+    if (jg == 0) {
+      const Buf16 pgo(a.g_P);
+#pragma unroll
+      for (int r = 0; r < MR; r++)
+        if (r < n_rows && !((deadm >> r) & 1)) st_gran4(pgo, (uint32_t)((jblk * a.S + r) * d + cf * 4), ps.tag_out, make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+    if (jblk == 0) {
+      const Buf16 xgo(a.g_x_out);
+#pragma unroll
+      for (int i = 0; i < EPT; i++) {
+        const int e = tid + NT * i;
+        if (e < n_rows * d && !((deadm >> (e / d)) & 1)) st_gran(xgo, (uint32_t)e, ps.tag_out, xv_fold[i]);
+      }
+    }
+    return true;
+  }
+#endif
   // LayerNorm: every wave takes the statistics of every (live) row itself and normalises the columns its own W1 rows
   // multiply -- no second barrier; the normalised values stay in registers (lane l: column own_col) and reach the
   // thread groups through the LDS crossbar (lane 4 i + q holds row rg + 32 i of group q = lane / 16)
@@ -668,10 +689,12 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
       // persistent mode: the first weight rounds are in flight (or landed) while the block waits; the wait is a PRE-wake
       // (the stage before the producers has finished) -- the planes themselves arrive as tagged granules, re-read until
       // every tag is the producers' (arrival and payload in one round trip)
+#if !defined(WB_PS_DRY)
       if (!ps.known_dead) {
         load_weights();
         load_cache_tile();
       }
+#endif
       if (!ps_wait(ps)) return false;
       dead = ps.known_dead ? 1 : ld_i<true>(ps.dead + r);
       if (r >= n_rows || dead) { ps.saw_dead = true; return true; }
@@ -744,6 +767,13 @@ __device__ __forceinline__ bool dec_attn_body(const AttnFusedArgs& a, const int 
   if constexpr (PS) ps_stamp(ps, 2);
   __syncthreads();
   if constexpr (PS) { if (!ps_sweeps_ok(ps)) return false; }
+#if defined(WB_PS_DRY)
+  if constexpr (PS) {
+    if (tid < d / 4) { const Buf16 pgo(a.g_P); st_gran4(pgo, (uint32_t)((h * a.S + r) * d + tid * 4), ps.tag_out, make_float4(0.f, 0.f, 0.f, 0.f)); }
+    if (h == 0 && tid < d) { const Buf16 xgo(a.g_x_out); st_gran(xgo, (uint32_t)(r * d + tid), ps.tag_out, xfold); }
+    return true;
+  }
+#endif
   // LayerNorm: every wave takes the row's statistics itself and normalises its own KW rows into a register (lane l: row
   // wave KW + l) -- no second barrier; the QKV loop broadcasts them with v_readlane
   float xn_own;
@@ -1022,10 +1052,12 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
       // persistent mode: neither the weights nor the window's cached keys depend on the predecessor -- the Wq slice and
       // the WHOLE K of the head are in flight (or landed) while the block waits (pre-wake); the self-attention planes
       // arrive as tagged granules
+#if !defined(WB_PS_DRY)
       if (!ps.known_dead) {
         load_weights();
         load_keys();
       }
+#endif
       if (!ps_wait(ps)) return false;
       dead = ps.known_dead ? 1 : ld_i<true>(ps.dead + r);
       if (r >= n_live || dead) { ps.saw_dead = true; return true; }
@@ -1089,6 +1121,13 @@ __device__ __forceinline__ bool dec_cross_body(const CrossFusedArgs& a, const in
   if constexpr (PS) ps_stamp(ps, 2);
   __syncthreads();
   if constexpr (PS) { if (!ps_sweeps_ok(ps)) return false; }
+#if defined(WB_PS_DRY)
+  if constexpr (PS) {
+    if (tid < d / 4) { const Buf16 pgo(a.g_P); st_gran4(pgo, (uint32_t)((h * a.S + r) * d + tid * 4), ps.tag_out, make_float4(0.f, 0.f, 0.f, 0.f)); }
+    if (h == 0 && tid < d) { const Buf16 xgo(a.g_x_out); st_gran(xgo, (uint32_t)(r * d + tid), ps.tag_out, xfold); }
+    return true;
+  }
+#endif
   // LayerNorm: statistics per wave, each wave normalises the columns its own Wq rows multiply -- no second barrier
   float xn_own;
   {

@@ -133,8 +133,10 @@ __device__ __forceinline__ bool ps_logits_role(const PersistArgs& a, const int t
   // (profiles/r03_c_ps_timeline_phases.txt).
   float4 w0[NR], w1[TWO ? NR : 1];
   if (!forced) {                                    // (a prompt step chooses nothing: no E^T stream)
+#if !defined(WB_PS_DRY)
     load_tile(w0, tile0);
     if constexpr (TWO) { if (n_t > 1) load_tile(w1, tile0 + 1); }
+#endif
   }
   const int use_mask = (ps.step + 1 <= a.mask_until_len) ? 1 : 0;          // transcribe.rs:271-275
   int deadm = 0;                                    // bit r: row r takes no part (its window has ended)
@@ -182,6 +184,16 @@ __device__ __forceinline__ bool ps_logits_role(const PersistArgs& a, const int t
   // a prompt step: the role has kept its place in the chain (it arrives after the final-LN roles, the merge role after it --
   // the order the reuse of the x rows and planes relies on) and is done
   if (forced) return true;
+#if defined(WB_PS_DRY)
+  // dry build (tools/build_exp.sh dry): the role's tile records without the E^T stream and the GEMV -- token 0-ish every step
+  for (int t = 0; t < n_t; t++)
+    if (wave < MR && !((deadm >> wave) & 1) && lane == 0) {
+      float* ts = a.tstats + ((int64_t)wave * a.n_tiles + tile0 + t) * 2;
+      st_f<true>(ts, 0.f);
+      st_f<true>(ts + 1, __int_as_float((tile0 + t) * CT));
+    }
+  return true;
+#endif
   // one tile: GEMV from the registers, column sums over the eight waves, mask, per-row best (value desc, id asc)
   auto run_tile = [&](const float4 (&w)[NR], int tile) {
     const int n0 = tile * CT;
