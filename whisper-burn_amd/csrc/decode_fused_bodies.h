@@ -72,8 +72,10 @@ __device__ __forceinline__ bool ps_sweeps_ok(const PsStep& ps) { return *ps.lds_
 // matter of load: correctness never depends on it.  (s_sleep 64 ~ 1.7 us)
 template <int UNITS>
 __device__ __forceinline__ void ps_nap() {
+#if !defined(WB_PS_DRY) || defined(WB_PS_DRY_NAPS)    // (dry build: the producers' bodies are empty -- nothing to sleep through)
 #pragma unroll
   for (int i = 0; i < UNITS; i++) __builtin_amdgcn_s_sleep(64);
+#endif
 }
 
 // developer probe: tools/decode_probe.cpp builds this file with -DWB_STAMPS and prints the phase timeline of block 0
