@@ -73,8 +73,11 @@ __device__ __forceinline__ bool ps_sweeps_ok(const PsStep& ps) { return *ps.lds_
 template <int UNITS>
 __device__ __forceinline__ void ps_nap() {
 #if !defined(WB_PS_DRY) || defined(WB_PS_DRY_NAPS)    // (dry build: the producers' bodies are empty -- nothing to sleep through)
+#ifndef WB_PS_NAP_ADJ
+#define WB_PS_NAP_ADJ 0                               // developer A/B: nap units added to every consumer's nap
+#endif
 #pragma unroll
-  for (int i = 0; i < UNITS; i++) __builtin_amdgcn_s_sleep(64);
+  for (int i = 0; i < UNITS + (WB_PS_NAP_ADJ); i++) __builtin_amdgcn_s_sleep(64);
 #endif
 }
 
