@@ -46,7 +46,10 @@ SWITCHES = [{}, {"WHISPER_HIP_FUSE_X": "0"}, {"WHISPER_HIP_FUSE_SUB": "0"}, {"WH
             # beam search driven by the HOST (one synchronisation + the beam.rs bookkeeping on the CPU per step) instead of
             # the device-chained search (decode.hip: dec_beam_update_kernel, the default since round 6) -- alone and over
             # batch mode, so that both row paths see both drivers
-            {"WHISPER_HIP_BEAM_CHAIN": "0"}, {"WHISPER_HIP_BEAM_CHAIN": "0", "WHISPER_HIP_FUSE16": "0"}]
+            {"WHISPER_HIP_BEAM_CHAIN": "0"}, {"WHISPER_HIP_BEAM_CHAIN": "0", "WHISPER_HIP_FUSE16": "0"},
+            # round 6's other defaults switched off one at a time: 9 - 16-row logits on the vector-pipe GEMV / with the fold +
+            # LayerNorm inside every block; encoder activations as f32 between the split-precision GEMMs (bit-identical)
+            {"WHISPER_HIP_LOGITS_MFMA": "0"}, {"WHISPER_HIP_LOGITS_PRELN": "0"}, {"WHISPER_HIP_ENCODER_PIECES": "0"}]
 
 
 _CACHE = {}

@@ -18,6 +18,7 @@ struct wb_session {
   std::vector<int> T, C, row0;  // per window: mel frames (padded), encoder positions, first packed row
   std::vector<wb::MelWindow> wins_host; void* wins_dev_ptr = nullptr;   // what the device window table holds
   std::vector<int> meta_host; void* meta_dev_ptr = nullptr;             // ... and the window meta table
+  std::vector<uint8_t> mask_host; void* mask_dev_ptr = nullptr;         // ... and the special-token mask (set_special_mask)
   int enc_rows = 0, maxC = 0, n_chunks = 0;
   wb::Workspace ws;
   wb::DevMem pcm, mel, wins, gmax, enc_out, ckv, win_meta;
