@@ -499,7 +499,9 @@ __global__ __launch_bounds__(256, 2) void dec_logits_mfma16_kernel(GemvArgs a) {
   const int col0 = strip * 64 + 4 * cq;              // first of this lane's four columns inside the tile
   const bool col_ok = (n0 + col0) < a.ldw && col0 < ct;
   const float* bp = a.W + (int64_t)(khalf * kh + krow) * a.ldw + n0 + (col_ok ? col0 : 0);
-  constexpr int LD = 24;                             // float4 loads a lane keeps in flight (96 K-rows)
+  // float4 loads a lane keeps in flight: with the rows arriving normalised (PRELN) the registers hold a wave's WHOLE K half at
+  // d = 384 (48 loads = 192 K-rows: one round trip, no second pass) and half of it at d = 512; 24 next to the in-kernel prologue
+  constexpr int LD = PRELN ? (DPL <= 6 ? 48 : 32) : 24;
   const int nld = kh >> 2;
   float4 bw[LD];
 #pragma unroll
