@@ -49,7 +49,8 @@ SWITCHES = [{}, {"WHISPER_HIP_FUSE_X": "0"}, {"WHISPER_HIP_FUSE_SUB": "0"}, {"WH
             {"WHISPER_HIP_BEAM_CHAIN": "0"}, {"WHISPER_HIP_BEAM_CHAIN": "0", "WHISPER_HIP_FUSE16": "0"},
             # round 6's other defaults switched off one at a time: 9 - 16-row logits on the vector-pipe GEMV / with the fold +
             # LayerNorm inside every block; encoder activations as f32 between the split-precision GEMMs (bit-identical)
-            {"WHISPER_HIP_LOGITS_MFMA": "0"}, {"WHISPER_HIP_LOGITS_PRELN": "0"}, {"WHISPER_HIP_ENCODER_PIECES": "0"}]
+            {"WHISPER_HIP_LOGITS_MFMA": "0"}, {"WHISPER_HIP_LOGITS_PRELN": "0"}, {"WHISPER_HIP_ENCODER_PIECES": "0"},
+            {"WHISPER_HIP_MLP16_MFMA": "0"}]
 
 
 _CACHE = {}

@@ -499,9 +499,13 @@ __global__ __launch_bounds__(256, 2) void dec_logits_mfma16_kernel(GemvArgs a) {
   const int col0 = strip * 64 + 4 * cq;              // first of this lane's four columns inside the tile
   const bool col_ok = (n0 + col0) < a.ldw && col0 < ct;
   const float* bp = a.W + (int64_t)(khalf * kh + krow) * a.ldw + n0 + (col_ok ? col0 : 0);
-  // float4 loads a lane keeps in flight: with the rows arriving normalised (PRELN) the registers hold a wave's WHOLE K half at
-  // d = 384 (48 loads = 192 K-rows: one round trip, no second pass) and half of it at d = 512; 24 next to the in-kernel prologue
-  constexpr int LD = PRELN ? (DPL <= 6 ? 48 : 32) : 24;
+  // float4 loads a lane keeps in flight per pass.  Measured at tiny.en (profiles/r06_r_bench_logits_ld48.json,
+  // r06_s_ab_logits_ld.txt): the wave's whole K half in one pass (48 loads, 234 VGPRs, two waves per SIMD) 35.8 us; two passes
+  // of 24 (168 VGPRs) 31.0; three of 16 30.0; four of 12 29.5 -- occupancy is worth more than the extra round trips
+#ifndef WB_LOGITS_LD
+#define WB_LOGITS_LD 12
+#endif
+  constexpr int LD = WB_LOGITS_LD;
   const int nld = kh >> 2;
   float4 bw[LD];
 #pragma unroll
