@@ -814,7 +814,7 @@ static int launch_step(wb_session* s, int n_launch, int k, int use_mask, bool fu
   auto mix = [&](uint64_t v) { sig = (sig ^ v) * 1099511628211ull; };
   for (const wb::DevMem* b : {&s->kc, &s->vc, &s->tabs, &s->state, &s->x, &s->h, &s->att, &s->Pqkv, &s->Po, &s->Pq,
                               &s->P1, &s->P2, &s->Pa, &s->Pc, &s->carec, &s->ca, &s->logits, &s->tstats, &s->row_stats, &s->mask, &s->ckv,
-                              &s->win_meta, &s->gctl, &s->gtok, &s->hm, &s->bc_ctl, &s->bc_state, &s->bc_topk})
+                              &s->win_meta, &s->gctl, &s->gtok, &s->hm, &s->bc_ctl, &s->bc_topk})
     mix((uint64_t)(uintptr_t)b->p);
   mix((uint64_t)(uintptr_t)s->host_block_dev);
   for (int v : {s->S, s->W, s->Lmax, s->n_chunks, s->max_beams, m->ln_eps_inside_sqrt, eot, (int)m->dec_split_active()})
@@ -1141,7 +1141,6 @@ int session_beam_chain(wb_session* s, const int32_t* prompt, int P, int k, int e
   }
   const BeamChainLayout bl = make_beam_layout(W, std::max(max_depth, 0));
   WB_TRY(s->bc_ctl.ensure((size_t)bl.total_ints * 4));
-  WB_TRY(s->bc_state.ensure((size_t)L.total * 4));
   WB_TRY(s->bc_topk.ensure((size_t)S * TOPK_MAX * 8));
   std::vector<int> ctl;
   beam_chain_init(ctl, bl, prompt, P, eot);

@@ -39,7 +39,7 @@ struct wb_session {
   int ps_grid = -1;                                                    // co-resident blocks for this model (-1: not asked yet)
   int n_tiles_v = 0, ct_v = 128;
   int ks_qkv = 1, ksl_qkv = 0, ks_o = 1, ksl_o = 0, ks_1 = 1, ksl_1 = 0, ks_2 = 1, ksl_2 = 0, ks_v = 1, ksl_v = 0;
-  wb::DevMem bc_ctl, bc_state, bc_topk;   // device-chained beam search (decode.h: BeamChainArgs): control block, next step's state, top-k rows
+  wb::DevMem bc_ctl, bc_topk;   // device-chained beam search (decode.h: BeamChainArgs): control block, top-k rows of the step
   std::vector<int> prev_len, prev_win;
   int prev_n = 0, step = 0;
   bool has_mask = false, decode_ready = false;
