@@ -27,7 +27,7 @@ def pytest_sessionstart(session):
 # batch-mode sessions at `small` / large-v2 last -- so that one failure in a long test cannot blank the evidence of the
 # ~100 short ones (round 4: the large-v2 file sorted second and `-x` stopped the run after four tests).
 _GPU_ORDER = [
-    "test_gpu_parity.py", "test_gpu_golden.py", "test_gpu_workloads.py", "test_gpu_edge.py", "test_gpu_guard.py", "test_gpu_beam_device.py", "test_gpu_session.py",
+    "test_gpu_parity.py", "test_gpu_golden.py", "test_gpu_workloads.py", "test_gpu_edge.py", "test_gpu_guard.py", "test_gpu_concurrency.py", "test_gpu_beam_device.py", "test_gpu_session.py",
     "test_gpu_switches.py", "test_gpu_budget.py", "test_gpu_e2e.py", "test_resample.py", "test_wav_ingest.py",
     "test_tokenizer_integration.py", "test_legacy_modes.py", "test_burn_record.py", "test_gpu_handoff.py",
     "test_gpu_shard_rccl.py", "test_gpu_scale.py", "test_gpu_batchmode.py",

@@ -1,0 +1,78 @@
+"""GPU: sessions of ONE model on different host threads / streams (round 6: the range-guard words are per session, no model-wide
+lock -- whisper_hip.h documents wb_model as shareable across threads and wb_session as not thread-safe).
+
+Two threads decode different clips through wb_waveform_to_tokens at the same time, several rounds (ctypes drops the GIL, so the
+calls really overlap: pooled sessions, step-graph capture, the deferred encoder guard, the special-mask cache all run
+concurrently); every result must equal the single-threaded one.  A third arm trips the encoder's guard in one thread while the
+other decodes: the tripping call falls back transparently, the bystander's result is unaffected.
+"""
+import threading
+
+import numpy as np
+import pytest
+
+import whisper_burn_amd as wb
+from whisper_burn_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _micro(seed=4242, **kw):
+    dims = synth.micro_dims(n_state=128, n_head=2, n_layer=2, n_vocab=1031)
+    return synth.synth_weights(dims, seed=seed, **kw)
+
+
+def _run_threads(fns):
+    out, err = [None] * len(fns), [None] * len(fns)
+
+    def call(i):
+        try:
+            out[i] = fns[i]()
+        except Exception as e:          # noqa: BLE001  (re-raised below, in the main thread)
+            err[i] = e
+
+    th = [threading.Thread(target=call, args=(i,)) for i in range(len(fns))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+@pytest.mark.parametrize("beam", [1, 3])
+def test_two_threads_decode_with_one_model(beam):
+    eng = wb.Whisper.from_tensors(_micro())
+    st = wb.SpecialTokens.for_vocab(1031)
+    clips = [synth.synth_audio(16000 * 35, 501), synth.synth_audio(16000 * 47, 502)]      # 3 and 4 reference windows
+    ref = [wb.waveform_to_tokens(eng, st, c, 16000, beam, 12) for c in clips]
+    for _ in range(4):
+        got = _run_threads([lambda c=c: wb.waveform_to_tokens(eng, st, c, 16000, beam, 12) for c in clips])
+        assert got == ref
+    # more threads than clips: sessions come and go through the pool
+    got = _run_threads([lambda c=clips[i % 2]: wb.waveform_to_tokens(eng, st, c, 16000, beam, 12) for i in range(4)])
+    assert got == [ref[0], ref[1], ref[0], ref[1]]
+    eng.close()
+
+
+def test_a_guard_trip_in_one_thread_does_not_disturb_the_other():
+    """Thread A's clip makes an encoder activation leave fp16's range (checkpoint with a 1e5 hidden unit, exact result unchanged:
+    tests/test_gpu_guard.py) -- its pass falls back to exact f32 behind the decode; thread B decodes on the SAME model meanwhile.
+    Both must return the tokens of an engine that never used the split kernel."""
+    w = _micro(eot_beta=0.0)
+    p = "encoder/block_1/mlp"
+    j = 4 * 128 - 1
+    w[p + "/mlp1/weight"][:, j] = 0.0
+    w[p + "/mlp1/bias"][j] = 1.0e5
+    w[p + "/mlp2/weight"][j, :] = 0.0
+    st = wb.SpecialTokens.for_vocab(1031)
+    clips = [synth.synth_audio(16000 * 20, 503), synth.synth_audio(16000 * 26, 504)]
+    eng = wb.Whisper.from_tensors(w)
+    assert eng.encoder_gemm() == "f16x3"
+    got = _run_threads([lambda c=c: wb.waveform_to_tokens(eng, st, c, 16000, 1, 10) for c in clips])
+    assert eng.encoder_gemm() == "f32"                       # (one of the two passes tripped the guard; both are valid)
+    ref = [wb.waveform_to_tokens(eng, st, c, 16000, 1, 10) for c in clips]      # exact-f32 encoder from the start
+    assert got == ref
+    eng.close()
