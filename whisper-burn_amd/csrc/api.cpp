@@ -36,13 +36,14 @@ int DevMem::ensure(size_t n) {
   if (n <= bytes && p) return WB_OK;
   return alloc(n + n / 8);
 }
-int DevMem::ensure_zeroed(size_t n) {
+int DevMem::ensure_zeroed(size_t n, hipStream_t st) {
   if (n <= bytes && p) return WB_OK;
   WB_TRY(alloc(n + n / 8));
-  WB_HIP(hipMemset(p, 0, bytes));
-  // the owners' streams are non-blocking (no implicit ordering with the null stream the memset runs on): wait here, once
-  // per (re)allocation, so that no later cache append can be overtaken by the fill
-  WB_HIP(hipStreamSynchronize(nullptr));
+  // on the OWNER's stream (a fill on the legacy stream fails while another session of the process is capturing a step graph:
+  // "would make the legacy stream depend on a capturing ... stream" -- tests/test_gpu_concurrency.py); wait here, once per
+  // (re)allocation, so that no later cache append can be overtaken by the fill
+  WB_HIP(hipMemsetAsync(p, 0, bytes, st));
+  WB_HIP(hipStreamSynchronize(st));
   return WB_OK;
 }
 void DevMem::release() {

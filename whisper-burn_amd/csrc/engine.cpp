@@ -21,7 +21,15 @@ int get_mel_tables(int device, double sample_rate, const MelTables** out_dev) {
   MelTables* dev = nullptr;
   WB_HIP(hipSetDevice(device));
   WB_HIP(hipMalloc(&dev, sizeof(MelTables)));
-  WB_HIP(hipMemcpy(dev, host.get(), sizeof(MelTables), hipMemcpyHostToDevice));
+  {  // (once per (device, rate); on a stream of its own: a legacy-stream copy fails while another thread captures a step graph)
+    hipStream_t ts = nullptr;
+    WB_HIP(hipStreamCreateWithFlags(&ts, hipStreamNonBlocking));
+    const hipError_t e1 = hipMemcpyAsync(dev, host.get(), sizeof(MelTables), hipMemcpyHostToDevice, ts);
+    const hipError_t e2 = hipStreamSynchronize(ts);
+    (void)hipStreamDestroy(ts);
+    WB_HIP(e1);
+    WB_HIP(e2);
+  }
   cache[key] = dev;
   *out_dev = dev;
   return WB_OK;

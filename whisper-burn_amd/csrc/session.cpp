@@ -299,8 +299,8 @@ int session_reserve(wb_session* s, int max_len) {
   max_len = std::max(8, std::min(max_len, std::min(D.n_text_ctx, 448)));
   s->Lmax = max_len;
   const size_t pool = (size_t)max_len * S;
-  WB_TRY(s->kc.ensure_zeroed((size_t)NL * pool * d * 4));
-  WB_TRY(s->vc.ensure_zeroed((size_t)NL * pool * d * 4));
+  WB_TRY(s->kc.ensure_zeroed((size_t)NL * pool * d * 4, s->st));
+  WB_TRY(s->vc.ensure_zeroed((size_t)NL * pool * d * 4, s->st));
   WB_TRY(s->tabs.ensure((size_t)2 * S * max_len * 4));
   s->lay = make_step_layout(S, s->W);
   WB_TRY(s->state.ensure((size_t)s->lay.total * 4));
@@ -876,11 +876,11 @@ static int run_persistent_chain(wb_session* s, int eot, int max_depth, int mask_
   // ---- the hand-off buffers: residual streams and partial planes as {tag, value} granules (zero-filled once: tag 0 is
   // never used; the tags of a launch live above launch_count << 16, so leftovers of earlier decodes never match)
   WB_REQUIRE(NB <= 32 && H <= 8, WB_ERR_SHAPE, "persistent decode: more planes than its folds hold");
-  WB_TRY(s->ps_gx.ensure_zeroed(((size_t)2 * S + 8) * d * 8));
-  WB_TRY(s->ps_gpa.ensure_zeroed(((size_t)H * S + 8) * d * 8));
-  WB_TRY(s->ps_gpc.ensure_zeroed(((size_t)H * S + 8) * d * 8));
-  WB_TRY(s->ps_gp2.ensure_zeroed(((size_t)NB * S + 8) * d * 8));
-  WB_TRY(s->ps_gxn.ensure_zeroed(((size_t)S + 8) * d * 8));
+  WB_TRY(s->ps_gx.ensure_zeroed(((size_t)2 * S + 8) * d * 8, st));
+  WB_TRY(s->ps_gpa.ensure_zeroed(((size_t)H * S + 8) * d * 8, st));
+  WB_TRY(s->ps_gpc.ensure_zeroed(((size_t)H * S + 8) * d * 8, st));
+  WB_TRY(s->ps_gp2.ensure_zeroed(((size_t)NB * S + 8) * d * 8, st));
+  WB_TRY(s->ps_gxn.ensure_zeroed(((size_t)S + 8) * d * 8, st));
   if (((s->ps_launches + 1) & 0xffffu) == 0) {     // the 16-bit launch count wraps: forget every old tag
     for (DevMem* b : {&s->ps_gx, &s->ps_gpa, &s->ps_gpc, &s->ps_gp2, &s->ps_gxn}) WB_HIP(hipMemsetAsync(b->p, 0, b->bytes, st));
     s->ps_launches++;

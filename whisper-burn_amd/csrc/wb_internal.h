@@ -62,7 +62,7 @@ struct DevMem {
   // grow-only, and a fresh allocation is zero-filled: for buffers a kernel may READ before it has written them under
   // a zero weight (cached K/V rows past the current position enter a dot product with probability 0) -- whatever bit
   // patterns hipMalloc hands back, including NaN / Inf, must not reach the arithmetic
-  int ensure_zeroed(size_t n);
+  int ensure_zeroed(size_t n, hipStream_t st = nullptr);   // (st: the owner's stream -- never the legacy stream when sessions run concurrently)
   void release();
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
