@@ -2,9 +2,13 @@
 // short sequence of fused gfx950 launches over packed, ragged window batches.
 #include "engine.h"
 
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include <functional>
 #include <map>
 #include <mutex>
+#include <string>
 
 namespace wb {
 
@@ -34,6 +38,43 @@ int get_mel_tables(int device, double sample_rate, const MelTables** out_dev) {
   *out_dev = dev;
   return WB_OK;
 }
+
+// Developer tool (WHISPER_HIP_ENC_TRACE=<dir>): stream-ordered device copies of every stage of an encoder pass, written to
+// <dir>/enc_trace_<tid>.bin at the end of the pass (one extra synchronisation there, none inside) -- to find the first stage
+// whose result differs between two runs (tools/probe_threads_enc.py).
+namespace {
+struct EncTrace { std::vector<std::string> name; std::vector<DevMem> buf; std::vector<size_t> bytes; size_t n = 0; };
+thread_local EncTrace tl_trace;
+const char* enc_trace_dir() { static const char* d = getenv("WHISPER_HIP_ENC_TRACE"); return d; }
+void trace_stage(hipStream_t st, const std::string& name, const void* p, size_t bytes) {
+  if (!enc_trace_dir()) return;
+  EncTrace& t = tl_trace;
+  if (t.n == t.buf.size()) { t.buf.emplace_back(); t.name.emplace_back(); t.bytes.push_back(0); }
+  if (t.buf[t.n].ensure(bytes) != WB_OK) return;
+  (void)hipMemcpyAsync(t.buf[t.n].p, p, bytes, hipMemcpyDeviceToDevice, st);
+  t.name[t.n] = name; t.bytes[t.n] = bytes; t.n++;
+}
+void trace_flush(hipStream_t st) {
+  if (!enc_trace_dir()) return;
+  EncTrace& t = tl_trace;
+  (void)hipStreamSynchronize(st);
+  char path[512];
+  snprintf(path, sizeof(path), "%s/enc_trace_%ld.bin", enc_trace_dir(), (long)syscall(SYS_gettid));
+  FILE* f = fopen(path, "wb");
+  std::vector<char> host;
+  for (size_t i = 0; f && i < t.n; i++) {
+    host.resize(t.bytes[i]);
+    (void)hipMemcpy(host.data(), t.buf[i].p, t.bytes[i], hipMemcpyDeviceToHost);
+    char nm[32] = {0};
+    snprintf(nm, sizeof(nm), "%s", t.name[i].c_str());
+    const int64_t nb = (int64_t)t.bytes[i];
+    fwrite(nm, 1, 32, f); fwrite(&nb, 8, 1, f); fwrite(host.data(), 1, host.size(), f);
+  }
+  if (f) fclose(f);
+  t.n = 0;
+}
+}  // namespace
+void enc_trace_stage(hipStream_t st, const char* name, const void* p, size_t bytes) { trace_stage(st, name, p, bytes); }
 
 static int upload(hipStream_t st, DevMem& dst, const void* src, size_t bytes) {
   WB_TRY(dst.ensure(bytes));
@@ -221,7 +262,9 @@ int run_encoder_unguarded(wb_model* m, hipStream_t st, Workspace& ws, const MelB
     g.A = mb.mel; g.a_desc = ws.desc1.as<RowDesc>(); g.conv1_tstride = mb.row_stride;
     g.B = m->conv1.w; g.ldb = d; g.C = x1; g.ldc = d; g.bias = m->conv1.b;
     g.M = rows1; g.N = d; g.K = 240; g.act = ACT_GELU;
+    trace_stage(st, "mel", mb.mel, (size_t)nw * mb.win_stride * 4);
     WB_TRY(gemm(m, st, g, nullptr));
+    trace_stage(st, "conv1", x1, (size_t)rows1 * d * 4);
   }
   // conv2 (stride 2) + GELU + transpose + positional add (mod.rs:244-252): rows 2c-1..2c+1 of x1 form one A row
   {
@@ -231,6 +274,7 @@ int run_encoder_unguarded(wb_model* m, hipStream_t st, Workspace& ws, const MelB
     g.M = rows2; g.N = d; g.K = 3 * d; g.act = ACT_GELU;
     g.aux = m->enc_pos; g.aux_idx = ws.auxidx.as<int32_t>(); g.ld_aux = d;
     WB_TRY(gemm(m, st, g, &m->conv2));
+    trace_stage(st, "conv2", x, (size_t)rows2 * d * 4);
   }
   // Activation pieces (round 6): inside a guarded split-precision pass the PRODUCERS of the layer GEMMs' A operands --
   // LayerNorm, the attention kernel, the GELU epilogue of lin1 -- write them as fp16 hi / lo planes once (the same 4 bytes per
@@ -252,16 +296,21 @@ int run_encoder_unguarded(wb_model* m, hipStream_t st, Workspace& ws, const MelB
       launch_layernorm(st, x, h, rows2, d, b.ln1.g, b.ln1.b, b.ln1.eps, m->ln_eps_inside_sqrt);
     }
     g.col_scale = m->qk_scale; g.col_scale_period = 3 * d; g.col_scale_width = 2 * d;   // q*s, k*s (mod.rs:506-514)
+    const std::string L = "L" + std::to_string(i) + ".";
+    trace_stage(st, L + "ln1", h, (size_t)rows2 * d * 4);
     WB_TRY(gemm(m, st, g, &b.qkv));
+    trace_stage(st, L + "qkv", qkv, (size_t)rows2 * 3 * d * 4);
     // (split precision only inside a guarded pass whose out-projection runs on the split GEMM: that GEMM's range guard is
     // what reports an attention operand outside fp16's range -- NaN in, flag raised, the pass repeated in exact f32)
     const bool att_pcs = launch_attention(st, qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, att, d, ws.segs.as<AttnSeg>(), nw, maxC,
                                           H, 1.0f, 0, split_pass && b.out.sh != nullptr, pcs ? att_hi : nullptr,
                                           pcs ? att_lo : nullptr);
+    trace_stage(st, L + "att", att, (size_t)rows2 * d * 4);
     g = linear_args(att, rows2, b.out, x);
     if (att_pcs) { g.Ah = att_hi; g.Al = att_lo; }
     g.residual = x; g.ldr = d;
     WB_TRY(gemm(m, st, g, &b.out));
+    trace_stage(st, L + "out", x, (size_t)rows2 * d * 4);
     g = linear_args(h, rows2, b.mlp1, hm);
     if (pcs) {
       launch_layernorm_pieces(st, x, h_hi, h_lo, rows2, d, b.ln2.g, b.ln2.b, b.ln2.eps, m->ln_eps_inside_sqrt);
@@ -271,10 +320,15 @@ int run_encoder_unguarded(wb_model* m, hipStream_t st, Workspace& ws, const MelB
       launch_layernorm(st, x, h, rows2, d, b.ln2.g, b.ln2.b, b.ln2.eps, m->ln_eps_inside_sqrt);
     }
     g.act = ACT_GELU;
+    trace_stage(st, L + "ln2", h, (size_t)rows2 * d * 4);
     WB_TRY(gemm(m, st, g, &b.mlp1));
+    trace_stage(st, L + "mlp1", hm, (size_t)rows2 * 4 * d * 4);
     WB_TRY(gemm_residual_kblocked(m, st, hm, rows2, b.mlp2, x, pcs ? hm_hi : nullptr, pcs ? hm_lo : nullptr));
+    trace_stage(st, L + "mlp2", x, (size_t)rows2 * d * 4);
   }
   launch_layernorm(st, x, out_dev, rows2, d, m->ln_post.g, m->ln_post.b, m->ln_post.eps, m->ln_eps_inside_sqrt);
+  trace_stage(st, "ln_post", out_dev, (size_t)rows2 * d * 4);
+  trace_flush(st);
   WB_HIP(hipGetLastError());
   return WB_OK;
 }

@@ -45,5 +45,7 @@ int gemm_dispatch(const wb_model* m, hipStream_t st, const GemmArgs& a, int ldwt
 
 // Process-wide mel constant tables for (device, sample_rate).
 int get_mel_tables(int device, double sample_rate, const MelTables** out_dev);
+// developer tool (WHISPER_HIP_ENC_TRACE): a stream-ordered copy of one more stage into this thread's encoder trace
+void enc_trace_stage(hipStream_t st, const char* name, const void* p, size_t bytes);
 
 }  // namespace wb

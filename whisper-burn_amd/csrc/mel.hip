@@ -47,6 +47,13 @@ constexpr int BMAX_OFF = 800;    // the block-maximum scratch (pair 0's region)
 
 struct cpx { float re, im; };
 
+// (developer A/B, WB_MEL_SETTLE: idle cycles between the instruction that produced a value and the LDS store that reads it)
+#if defined(WB_MEL_SETTLE) && !defined(HIPEMU)
+#define WB_SETTLE2(a, b) asm volatile("s_nop 3" : "+v"(a), "+v"(b))
+#else
+#define WB_SETTLE2(a, b) do { } while (0)
+#endif
+
 __device__ __forceinline__ cpx cmul(cpx a, float wr, float wi) {
   return {a.re * wr - a.im * wi, a.re * wi + a.im * wr};
 }
@@ -63,61 +70,76 @@ __device__ __forceinline__ cpx cmul(cpx a, float wr, float wi) {
 // 572 / 54 here.  Measured in round 5 on one box, alternating: 1.14 -> 1.21 G frames/s, with the plain v_fmac filterbank
 // sums below 1.30 -- profiles/r05_a_variants.txt.)
 typedef float f2 __attribute__((ext_vector_type(2)));
+#if defined(HIPEMU) || defined(WB_MEL_NO_ASM)
 #if defined(HIPEMU)
+#define WB_PK static inline
+#else
+#define WB_PK __device__ __forceinline__   // (developer A/B: the arithmetic without the hand-written instructions)
+#endif
 // functional model: the helpers by their arithmetic (mul then fma, as the two-instruction forms below round)
-static inline f2 pk_add(f2 a, f2 b) { return a + b; }
-static inline f2 pk_sub(f2 a, f2 b) { return a - b; }
-static inline f2 pk_add_mi(f2 a, f2 b) { return f2{a.x + b.y, a.y - b.x}; }          // a - i b
-static inline f2 pk_add_pi(f2 a, f2 b) { return f2{a.x - b.y, a.y + b.x}; }          // a + i b
-static inline f2 pk_cmul(f2 a, f2 w) {                                                 // a * (w.x + i w.y)
+#if defined(WB_MEL_NO_PK)   // (developer A/B, with -fno-slp-vectorize: no packed-FP32 instruction at all)
+WB_PK f2 pk_add(f2 a, f2 b) { return f2{a.x + b.x, a.y + b.y}; }
+WB_PK f2 pk_sub(f2 a, f2 b) { return f2{a.x - b.x, a.y - b.y}; }
+#else
+WB_PK f2 pk_add(f2 a, f2 b) { return a + b; }
+WB_PK f2 pk_sub(f2 a, f2 b) { return a - b; }
+#endif
+WB_PK f2 pk_add_mi(f2 a, f2 b) { return f2{a.x + b.y, a.y - b.x}; }          // a - i b
+WB_PK f2 pk_add_pi(f2 a, f2 b) { return f2{a.x - b.y, a.y + b.x}; }          // a + i b
+WB_PK f2 pk_cmul(f2 a, f2 w) {                                                 // a * (w.x + i w.y)
   f2 r = f2{a.x * w.x, a.y * w.x};
   return f2{fmaf(-a.y, w.y, r.x), fmaf(a.x, w.y, r.y)};
 }
-static inline f2 pk_fma_lo(f2 a, f2 c, f2 acc) { return f2{fmaf(a.x, c.x, acc.x), fmaf(a.y, c.x, acc.y)}; }   // acc + a * c.x
-static inline f2 pk_fma_hi(f2 a, f2 c, f2 acc) { return f2{fmaf(a.x, c.y, acc.x), fmaf(a.y, c.y, acc.y)}; }   // acc + a * c.y
-static inline f2 pk_mul_lo(f2 a, f2 c) { return f2{a.x * c.x, a.y * c.x}; }
-static inline f2 pk_mul_hi(f2 a, f2 c) { return f2{a.x * c.y, a.y * c.y}; }
+WB_PK f2 pk_fma_lo(f2 a, f2 c, f2 acc) { return f2{fmaf(a.x, c.x, acc.x), fmaf(a.y, c.x, acc.y)}; }   // acc + a * c.x
+WB_PK f2 pk_fma_hi(f2 a, f2 c, f2 acc) { return f2{fmaf(a.x, c.y, acc.x), fmaf(a.y, c.y, acc.y)}; }   // acc + a * c.y
+WB_PK f2 pk_mul_lo(f2 a, f2 c) { return f2{a.x * c.x, a.y * c.x}; }
+WB_PK f2 pk_mul_hi(f2 a, f2 c) { return f2{a.x * c.y, a.y * c.y}; }
 #else
+#if defined(WB_MEL_EARLYCLOBBER)
+#define WB_PK_OUT "=&v"
+#else
+#define WB_PK_OUT "=v"
+#endif
 __device__ __forceinline__ f2 pk_add(f2 a, f2 b) { return a + b; }
 __device__ __forceinline__ f2 pk_sub(f2 a, f2 b) { return a - b; }
 // a - i b = (a.x + b.y, a.y - b.x): LO = src0.lo + src1.hi, HI = src0.hi - src1.lo
 __device__ __forceinline__ f2 pk_add_mi(f2 a, f2 b) {
   f2 r;
-  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : WB_PK_OUT(r) : "v"(a), "v"(b));
   return r;
 }
 // a + i b = (a.x - b.y, a.y + b.x)
 __device__ __forceinline__ f2 pk_add_pi(f2 a, f2 b) {
   f2 r;
-  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : WB_PK_OUT(r) : "v"(a), "v"(b));
   return r;
 }
 // a * (w.x + i w.y) = (a.x w.x - a.y w.y, a.y w.x + a.x w.y): two instructions, the twiddle one 64-bit constant pair
 __device__ __forceinline__ f2 pk_cmul(f2 a, f2 w) {
   f2 r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(w));                 // (a.x w.x, a.y w.x)
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : WB_PK_OUT(r) : "v"(a), "v"(w));                 // (a.x w.x, a.y w.x)
   asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "+v"(r) : "v"(a), "v"(w));   // LO -= a.y w.y; HI += a.x w.y
   return r;
 }
 // acc + a * c.x / acc + a * c.y (a complex value times one REAL constant of the pair c, both halves)
 __device__ __forceinline__ f2 pk_fma_lo(f2 a, f2 c, f2 acc) {
   f2 r;
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(c), "v"(acc));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : WB_PK_OUT(r) : "v"(a), "v"(c), "v"(acc));
   return r;
 }
 __device__ __forceinline__ f2 pk_fma_hi(f2 a, f2 c, f2 acc) {
   f2 r;
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(a), "v"(c), "v"(acc));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : WB_PK_OUT(r) : "v"(a), "v"(c), "v"(acc));
   return r;
 }
 __device__ __forceinline__ f2 pk_mul_lo(f2 a, f2 c) {
   f2 r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(c));
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : WB_PK_OUT(r) : "v"(a), "v"(c));
   return r;
 }
 __device__ __forceinline__ f2 pk_mul_hi(f2 a, f2 c) {
   f2 r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "v"(c));
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : WB_PK_OUT(r) : "v"(a), "v"(c));
   return r;
 }
 #endif
@@ -263,6 +285,7 @@ __global__ __launch_bounds__(MEL_THREADS, WB_MEL_MIN_BLOCKS) void mel_spectrogra
   for (int k1 = 0; k1 < 20; k1++) {
     const float2 t = twv[k1];
     cpx v = cmul(z[k1], t.x, t.y);
+    WB_SETTLE2(v.re, v.im);
     U[k1 * UROW + q] = make_float2(v.re, v.im);
   }
   __syncthreads();
@@ -276,7 +299,7 @@ __global__ __launch_bounds__(MEL_THREADS, WB_MEL_MIN_BLOCKS) void mel_spectrogra
   __syncthreads();
   float2* Z = reinterpret_cast<float2*>(reg);   // Z[k], k = 0..399
 #pragma unroll
-  for (int k2 = 0; k2 < 20; k2++) Z[q + 20 * k2] = make_float2(z[k2].re, z[k2].im);
+  for (int k2 = 0; k2 < 20; k2++) { WB_SETTLE2(z[k2].re, z[k2].im); Z[q + 20 * k2] = make_float2(z[k2].re, z[k2].im); }
   __syncthreads();
   // ---- stage 3: split the packed transform, power spectrum of both frames ----
   // A[k] = (Z[k] + conj Z[400-k]) / 2,  B[k] = (Z[k] - conj Z[400-k]) / (2i)
@@ -302,7 +325,7 @@ __global__ __launch_bounds__(MEL_THREADS, WB_MEL_MIN_BLOCKS) void mel_spectrogra
 #pragma unroll
   for (int i = 0; i < 11; i++) {
     int k = q + 20 * i;
-    if (k <= 200) { P[k] = pa[i]; P[PB_OFF + k] = pb[i]; }
+    if (k <= 200) { WB_SETTLE2(pa[i], pb[i]); P[k] = pa[i]; P[PB_OFF + k] = pb[i]; }
   }
   {
     const int m = tid >> 2;                     // taps 4 tid .. 4 tid + 3 belong to mel row m
@@ -344,7 +367,7 @@ __global__ __launch_bounds__(MEL_THREADS, WB_MEL_MIN_BLOCKS) void mel_spectrogra
         const float* tw = lds + (m / 5) * 2 * FROW + TAP_OFF + (m % 5) * MEL_MAX_TAPS;
         const float4 w4 = *reinterpret_cast<const float4*>(tw + 4 * c);
         const float* pp = Pf + s0v[r] + 4 * c;
-#if !defined(HIPEMU)
+#if !defined(HIPEMU) && !defined(WB_MEL_NO_ASM)
         // plain v_fmac: left to itself the compiler SLP-packs the sums of two rows into v_pk_fma_f32 and builds each operand
         // pair with two or three v_mov (16 packed + ~40 moves per chunk against 32 scalar FMAs); same operation order
         asm("v_fmac_f32 %0, %1, %2" : "+v"(accv[r]) : "v"(w4.x), "v"(pp[0]));

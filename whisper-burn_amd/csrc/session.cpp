@@ -262,6 +262,18 @@ int session_encode_pcm(wb_session* s, const float* pcm, int64_t n_pcm, const int
   WB_TRY(s->wins.ensure(wins.size() * sizeof(MelWindow)));
   WB_TRY(s->gmax.ensure((size_t)s->W * mel_bmax_stride(maxF) * 2 * 4));
   WB_TRY(s->mel.ensure((size_t)s->W * 80 * Ts * 4));
+  static const bool stage_pcm = []() { const char* e = getenv("WHISPER_HIP_PCM_STAGE"); return e && e[0] == '1'; }();
+  if (!pcm_on_device && stage_pcm) {
+    const size_t nb = (size_t)(hi - lo) * 4;
+    if (s->pcm_stage_bytes < nb) {
+      if (s->pcm_stage) (void)hipHostFree(s->pcm_stage);
+      s->pcm_stage = nullptr; s->pcm_stage_bytes = 0;
+      WB_HIP(hipHostMalloc((void**)&s->pcm_stage, nb, hipHostMallocDefault));
+      s->pcm_stage_bytes = nb;
+    }
+    memcpy(s->pcm_stage, pcm + lo, nb);
+    WB_HIP(hipMemcpyAsync(s->pcm.p, s->pcm_stage, nb, hipMemcpyHostToDevice, s->st));
+  } else
   if (!pcm_on_device) WB_HIP(hipMemcpyAsync(s->pcm.p, pcm + lo, (size_t)(hi - lo) * 4, hipMemcpyHostToDevice, s->st));
   const float* pcm_dev = pcm_on_device ? pcm : s->pcm.as<float>();
   // the window table on the device is re-used when this (pooled) session saw the same windows last time
@@ -275,10 +287,14 @@ int session_encode_pcm(wb_session* s, const float* pcm, int64_t n_pcm, const int
   } else if (!pcm_on_device) {
     WB_HIP(hipStreamSynchronize(s->st));   // the caller's PCM buffer may go away
   }
+  static const int trace_extra = []() { const char* e = getenv("WHISPER_HIP_ENC_TRACE_EXTRA"); return e ? atoi(e) : 0; }();
+  if (!pcm_on_device && (trace_extra & 1)) enc_trace_stage(s->st, "pcm", s->pcm.p, (size_t)(hi - lo) * 4);
   {
     ScopedTimer tm(s->st, 0);
     launch_mel_spectrogram(s->st, pcm_dev, s->wins.as<MelWindow>(), s->W, maxF, tabs, s->mel.as<float>(),
                            (int64_t)80 * Ts, Ts, s->gmax.as<float>(), s->padding, Ts);
+    if (trace_extra & 2) enc_trace_stage(s->st, "mel0", s->mel.p, (size_t)s->W * 80 * Ts * 4);
+    if (trace_extra & 4) enc_trace_stage(s->st, "gmax", s->gmax.p, (size_t)s->W * mel_bmax_stride(maxF) * 2 * 4);
     launch_mel_finalize(s->st, s->wins.as<MelWindow>(), s->W, s->mel.as<float>(), (int64_t)80 * Ts, Ts,
                         s->gmax.as<float>(), maxF);
     tm.stop();
@@ -361,6 +377,7 @@ wb_session::~wb_session() {
   clear_graphs();
   if (host_block) (void)hipHostFree(host_block);
   if (guard_host) (void)hipHostFree(guard_host);
+  if (pcm_stage) (void)hipHostFree(pcm_stage);
   if (ev_seg) (void)hipEventDestroy(ev_seg);
   if (st2) (void)hipStreamDestroy(st2);
   if (st) (void)hipStreamDestroy(st);
@@ -425,7 +442,8 @@ void wb_session_free(wb_session* s) {
       size_t parked = 0;
       for (const wb_session* q : it->second) parked += session_device_bytes(q);
       // keep the allocations (and captured graphs) for the next batch, within a byte budget
-      if (it->second.size() < POOL_MAX_SESSIONS && parked + session_device_bytes(s) <= POOL_MAX_BYTES) {
+      static const bool pool_enabled = []() { const char* e = getenv("WHISPER_HIP_SESSION_POOL"); return !(e && e[0] == '0'); }();   // developer A/B
+      if (pool_enabled && it->second.size() < POOL_MAX_SESSIONS && parked + session_device_bytes(s) <= POOL_MAX_BYTES) {
         it->second.push_back(s);
         return;
       }
@@ -817,8 +835,12 @@ static int launch_step(wb_session* s, int n_launch, int k, int use_mask, bool fu
                               &s->win_meta, &s->gctl, &s->gtok, &s->hm, &s->bc_ctl, &s->bc_topk})
     mix((uint64_t)(uintptr_t)b->p);
   mix((uint64_t)(uintptr_t)s->host_block_dev);
-  for (int v : {s->S, s->W, s->Lmax, s->n_chunks, s->max_beams, m->ln_eps_inside_sqrt, eot, (int)m->dec_split_active()})
-    mix((uint64_t)(int64_t)v);      // (the last one: another session's trip switched the model's decoder GEMM under these graphs)
+  // (enc_rows: the layer-major cross-K/V cache puts layer l at ckv + l * enc_rows * 2d -- ckv_of -- so the per-layer pointers a
+  // graph holds move with the batch's packed encoder rows even when no buffer does; maxC: picks the cross-attention kernel
+  // and its pass count (enqueue_step);
+  // dec_split_active: another session's trip switched the model's decoder GEMM under these graphs)
+  for (int v : {s->S, s->W, s->Lmax, s->n_chunks, s->max_beams, m->ln_eps_inside_sqrt, eot, (int)m->dec_split_active(), s->enc_rows, s->maxC})
+    mix((uint64_t)(int64_t)v);
   mix(m->uid);
   if (sig != s->buf_sig) { s->clear_graphs(); s->buf_sig = sig; }
   // (reps > 1: device-chained steps read their position from the control block, so one graph can hold

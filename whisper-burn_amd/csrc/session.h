@@ -22,6 +22,7 @@ struct wb_session {
   int enc_rows = 0, maxC = 0, n_chunks = 0;
   wb::Workspace ws;
   wb::DevMem pcm, mel, wins, gmax, enc_out, ckv, win_meta;
+  float* pcm_stage = nullptr; size_t pcm_stage_bytes = 0;   // pinned host staging of the caller's PCM (session_encode_pcm)
   wb::DevMem kc, vc, tabs, state;
   wb::StepLayout lay;
   char* host_block = nullptr;           // mapped pinned host memory: step state | top-k ids | top-k log-probs
