@@ -1,5 +1,8 @@
-run() { echo "== $*"; env "$@" 2>&1 | grep -v amdgpu.ids | grep "aggressor\|mismatching" | cut -c1-300; }
-for v in "" SETTLE NOSLP NO_PK; do
-  L=whisper-burn_amd/lib/libwhisper_hip_exp_mel_$v.so; [ -z "$v" ] && L=whisper-burn_amd/lib/libwhisper_hip.so
-  run PROBE_MODE=persistent PROBE_SAME_LEN=1 WHISPER_HIP_LIB=$L python whisper-burn_amd/tools/probe_threads_enc.py 300
-done
+run() { echo "== $*"; env "$@" 2>&1 | grep -v amdgpu.ids | grep "aggressor\|mismatching\|passed\|failed" | cut -c1-300; }
+run PROBE_MODE=persistent PROBE_SAME_LEN=1 python whisper-burn_amd/tools/probe_threads_enc.py 300
+run PROBE_MODE=fresh python whisper-burn_amd/tools/probe_threads_enc.py 300
+run WHISPER_HIP_GPU_TURN=0 PROBE_MODE=persistent PROBE_SAME_LEN=1 python whisper-burn_amd/tools/probe_threads_enc.py 300
+run python whisper-burn_amd/tools/probe_threads.py 1 150
+run python whisper-burn_amd/tools/probe_threads.py 3 150
+run WHISPER_HIP_GPU_TURN=0 python whisper-burn_amd/tools/probe_threads.py 1 150
+for i in 1 2 3 4 5; do run python -m pytest tests/test_gpu_concurrency.py -q -x; done

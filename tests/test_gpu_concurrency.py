@@ -2,9 +2,15 @@
 lock -- whisper_hip.h documents wb_model as shareable across threads and wb_session as not thread-safe).
 
 Two threads decode different clips through wb_waveform_to_tokens at the same time, several rounds (ctypes drops the GIL, so the
-calls really overlap: pooled sessions, step-graph capture, the deferred encoder guard, the special-mask cache all run
-concurrently); every result must equal the single-threaded one.  A third arm trips the encoder's guard in one thread while the
-other decodes: the tripping call falls back transparently, the bystander's result is unaffected.
+calls really overlap on the host: pooled sessions, the special-mask cache, the guard words); every result must equal the
+single-threaded one.  A third arm trips the encoder's guard in one thread while the other decodes: the tripping call falls
+back transparently, the bystander's result is unaffected.
+
+On the GPU the calls take turns (wb_internal.h: GpuTurn).  Without the turn these tests failed about every second run: a wave's
+packed-FP32 instructions return wrong results in lanes 48-63 while another kernel's f16 MFMAs run on the same SIMD
+(tools/pk_mfma_probe.cpp reproduces that without this library; profiles/r06_y_*), which showed up here as a log-mel with a few
+wrong frames in one thread -- the other thread's split-precision encoder GEMM was running next to its mel kernel -- and then
+different tokens.  tools/probe_threads_enc.py with WHISPER_HIP_GPU_TURN=0 shows the unprotected behaviour.
 """
 import threading
 
@@ -48,7 +54,7 @@ def test_two_threads_decode_with_one_model(beam):
     st = wb.SpecialTokens.for_vocab(1031)
     clips = [synth.synth_audio(16000 * 35, 501), synth.synth_audio(16000 * 47, 502)]      # 3 and 4 reference windows
     ref = [wb.waveform_to_tokens(eng, st, c, 16000, beam, 12) for c in clips]
-    for _ in range(4):
+    for _ in range(8):
         got = _run_threads([lambda c=c: wb.waveform_to_tokens(eng, st, c, 16000, beam, 12) for c in clips])
         assert got == ref
     # more threads than clips: sessions come and go through the pool

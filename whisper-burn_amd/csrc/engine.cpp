@@ -12,6 +12,12 @@
 
 namespace wb {
 
+GpuTurn::GpuTurn() {
+  static std::recursive_mutex mu;
+  static const bool enabled = []() { const char* e = getenv("WHISPER_HIP_GPU_TURN"); return !(e && e[0] == '0'); }();
+  if (enabled) lk = std::unique_lock<std::recursive_mutex>(mu);
+}
+
 int get_mel_tables(int device, double sample_rate, const MelTables** out_dev) {
   static std::mutex mu;
   static std::map<std::pair<int, double>, MelTables*> cache;
