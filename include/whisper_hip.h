@@ -17,10 +17,16 @@
  *  - all floating point data is IEEE f32 (the reference runs TchBackend<f32>,
  *    src/bin/transcribe/main.rs:80); token ids are int32.
  *  - a wb_model may be shared by threads: its weights never change after load.  The one
- *    piece of state it carries is the encoder arithmetic (wb_model_encoder_gemm), which
- *    can switch from 1 to 0 once, atomically, when the range guard of the split-precision
- *    kernel trips; passes that use that kernel are serialised per model.  A wb_session is
- *    not thread-safe.
+ *    piece of state it carries is the arithmetic switches (wb_model_encoder_gemm /
+ *    wb_model_decoder_gemm), which can go from 1 to 0 once, atomically, when a range guard of
+ *    the split-precision kernels trips (the guard words themselves are per session).  A
+ *    wb_session is not thread-safe.
+ *  - calls from different threads are safe and give the single-threaded results, but they TAKE
+ *    TURNS on the GPU: every entry point that enqueues kernels holds one process-wide turn
+ *    from its first launch to its last synchronisation.  (On gfx950 a wave's packed-FP32
+ *    instructions return wrong results while another kernel's f16 MFMAs run on the same
+ *    SIMD: kernels of two calls must not share the device.  DESIGN.md section 9,
+ *    tools/pk_mfma_probe.cpp.)  One process per GPU is the scaling model.
  */
 #ifndef WHISPER_HIP_H
 #define WHISPER_HIP_H

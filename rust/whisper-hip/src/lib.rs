@@ -82,6 +82,8 @@ pub struct Whisper {
     dims: ffi::wb_dims,
     device: i32,
 }
+// whisper_hip.h, "Conventions": the model is immutable after load and may be shared by threads; calls from different
+// threads return the single-threaded results and take turns on the GPU (one process-wide turn inside the library).
 unsafe impl Send for Whisper {}
 unsafe impl Sync for Whisper {}
 

@@ -87,6 +87,28 @@ def main(which):
         gen = [len(r) - 4 for r in rw]
         assert wins == rw and got == ref, (wins, rw)
         assert len(set(gen)) >= 3 and all(r[-1] == st.end_of_text for r in rw) and max(gen) < 30, gen
+    elif which == "two_threads":
+        # calls from different host threads on one model: the sessions' calls and a stateless one at the same time, several
+        # rounds; every result equals the single-threaded one (the process-wide GPU turn -- wb_internal.h: GpuTurn -- is
+        # recursive: wb_waveform_to_tokens -> wb_session_decode; tests/test_gpu_concurrency.py is the GPU twin)
+        import threading
+        clips = [synth.synth_audio(16000 * 3, 7), synth.synth_audio(16000 * 4 + 123, 8)]
+        ref = [wb.waveform_to_tokens(eng, st, c, 16000, 1, 6) for c in clips]
+        mel_ref = wb.prep_audio(clips[0][None])[0]
+        for rnd in range(2):
+            out, err = [None] * 3, []
+
+            def call(i):
+                try:
+                    out[i] = wb.waveform_to_tokens(eng, st, clips[i], 16000, 1, 6) if i < 2 else wb.prep_audio(clips[0][None])[0]
+                except Exception as e:      # noqa: BLE001
+                    err.append(e)
+
+            th = [threading.Thread(target=call, args=(i,)) for i in range(3)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+            assert not err, err
+            assert out[0] == ref[0] and out[1] == ref[1] and np.array_equal(out[2], mel_ref), rnd
     elif which == "pool":
         # a session that outlives its model: model A is freed, model B (same architecture, other weights) is loaded --
         # its handle may reuse A's heap address -- then A's leftover session is released and B decodes.  The session

@@ -118,7 +118,7 @@ def _prefetch(request, emu_lib):
     _JOBS.clear()
 
 
-@pytest.mark.parametrize("which", ["mel", "greedy", "beam", "forward", "geometry", "prompted", "pool", "bigpad"])
+@pytest.mark.parametrize("which", ["mel", "greedy", "beam", "forward", "geometry", "prompted", "pool", "bigpad", "two_threads"])
 def test_kernel_sources_reproduce_the_oracle_under_the_functional_model(emu_lib, which):
     p = _run(emu_lib, which)
     assert p.returncode == 0 and f"EMU_CHECK_OK {which}" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]

@@ -80,6 +80,37 @@ __global__ __launch_bounds__(256, 2) void aggressor_kernel(float* sink, int iter
   if (keep == 123456.789f) sink[0] = keep;
 }
 
+// ONE kernel whose even blocks run the f16 MFMA loop and whose odd blocks run the packed-FP32 butterflies (same register
+// allocation for both, as inside a GEMM whose blocks are in different phases): kinds 20 (natural allocation) / 21 (152 VGPRs)
+template <int TOP>
+__global__ __launch_bounds__(320, 2) void mixed_kernel(float* out, int reps, float* sink, int iters) {
+  if constexpr (TOP == 151) asm volatile("v_mov_b32 v151, 0" ::: "v151");
+  if (blockIdx.x & 1) {
+    const int gid = (blockIdx.x >> 1) * blockDim.x + threadIdx.x;
+    cpx z[20];
+#pragma unroll
+    for (int i = 0; i < 20; i++) z[i] = cpx{(float)((gid * 7 + i * 13) % 97) * 0.01f - 0.4f, (float)((gid * 5 + i * 11) % 89) * 0.01f - 0.3f};
+    for (int r = 0; r < reps; r++) {
+      dft20(z);
+#pragma unroll
+      for (int i = 0; i < 20; i++) { z[i].re *= 0.2236068f; z[i].im *= 0.2236068f; }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 20; i++) s += z[i].re * (float)(i + 1) + z[i].im * (float)(21 + i);
+    out[gid] = s;
+  } else {
+    f32x4 acc[4] = {};
+    f16x8 a = {}, b = {};
+    a[0] = (_Float16)(float)threadIdx.x;
+    for (int i = 0; i < iters; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[j], 0, 0, 0);
+    const float keep = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
+    if (keep == 123456.789f) sink[0] = keep;
+  }
+}
+
 int main(int argc, char** argv) {
   const double seconds = argc > 1 ? atof(argv[1]) : 2.0;
   const int kind = argc > 2 ? atoi(argv[2]) : 0;
@@ -112,7 +143,9 @@ int main(int argc, char** argv) {
       else if (kind == 17) hipLaunchKernelGGL((aggressor_kernel<0, 119>), dim3(1024), dim3(256), 0, sa, sink, 200);
       else if (kind == 18) hipLaunchKernelGGL((aggressor_kernel<0, 95>), dim3(1024), dim3(256), 0, sa, sink, 200);
     }
-    hipLaunchKernelGGL(victim_kernel, dim3(blocks), dim3(320), 0, sv, out, reps);
+    if (kind == 20) hipLaunchKernelGGL((mixed_kernel<0>), dim3(2 * blocks), dim3(320), 0, sv, out, reps, sink, 60);
+    else if (kind == 21) hipLaunchKernelGGL((mixed_kernel<151>), dim3(2 * blocks), dim3(320), 0, sv, out, reps, sink, 60);
+    else hipLaunchKernelGGL(victim_kernel, dim3(blocks), dim3(320), 0, sv, out, reps);
     CK(hipStreamSynchronize(sv));
     CK(hipMemcpy(got.data(), out, (size_t)n * 4, hipMemcpyDeviceToHost));
     launches++;
