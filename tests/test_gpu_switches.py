@@ -50,7 +50,9 @@ SWITCHES = [{}, {"WHISPER_HIP_FUSE_X": "0"}, {"WHISPER_HIP_FUSE_SUB": "0"}, {"WH
             # round 6's other defaults switched off one at a time: 9 - 16-row logits on the vector-pipe GEMV / with the fold +
             # LayerNorm inside every block; encoder activations as f32 between the split-precision GEMMs (bit-identical)
             {"WHISPER_HIP_LOGITS_MFMA": "0"}, {"WHISPER_HIP_LOGITS_PRELN": "0"}, {"WHISPER_HIP_ENCODER_PIECES": "0"},
-            {"WHISPER_HIP_MLP16_MFMA": "0"}]
+            {"WHISPER_HIP_MLP16_MFMA": "0"},
+            # round 6: the process-wide GPU turn off (developer switch of the concurrency probes; one thread: nothing changes)
+            {"WHISPER_HIP_GPU_TURN": "0"}, {"WHISPER_HIP_SESSION_POOL": "0"}]
 
 
 _CACHE = {}
