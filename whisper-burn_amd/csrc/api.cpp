@@ -149,7 +149,7 @@ int wb_prep_audio(int device, const float* pcm, int64_t n, double sample_rate, f
   WB_REQUIRE(pcm && mel, WB_ERR_ARG, "wb_prep_audio: null argument");
   WB_REQUIRE(n >= MEL_N_FFT, WB_ERR_SHAPE, "prep_audio: %lld samples < n_fft = 400 (audio.rs:292)", (long long)n);
   WB_REQUIRE(n < ((int64_t)1 << 31), WB_ERR_SHAPE, "prep_audio: window too long");
-  wb::GpuTurn turn;
+  wb::GpuTurn turn(device);
   WB_HIP(hipSetDevice(device));
   const MelTables* tabs;
   WB_TRY(get_mel_tables(device, sample_rate, &tabs));
@@ -196,7 +196,7 @@ int wb_waveform_to_mels_dev(int device, const float* pcm_dev, int64_t n_samples,
   }
   WB_REQUIRE(row_stride >= maxT && row_stride % 4 == 0 && win_stride >= (int64_t)80 * row_stride, WB_ERR_ARG,
              "wb_waveform_to_mels_dev: row_stride %d must be a multiple of 4 and >= %d frames", row_stride, maxT);
-  wb::GpuTurn turn;
+  wb::GpuTurn turn(device);
   WB_HIP(hipSetDevice(device));
   const MelTables* tabs;
   WB_TRY(get_mel_tables(device, sample_rate, &tabs));
@@ -232,7 +232,7 @@ int wb_forward_encoder(wb_model* m, const float* mel, int B, int T, float* out) 
   // mod.rs:236-241
   WB_REQUIRE(T >= 1 && T <= m->max_mel_frames(), WB_ERR_SHAPE, "Audio length %d cannot exceed %d.", T,
              m->max_mel_frames());
-  wb::GpuTurn turn;
+  wb::GpuTurn turn(m->device);
   std::lock_guard<std::mutex> lk(g_stateless_mu);
   WB_HIP(hipSetDevice(m->device));
   wb_model* sc = m;
@@ -274,7 +274,7 @@ static int decoder_common(wb_model* m, wb_model* sc, hipStream_t st, const int32
 
 int wb_forward_decoder(wb_model* m, const int32_t* tokens, int n, int L, const float* enc, int C, float* logits) {
   WB_REQUIRE(m && tokens && enc && logits && n > 0 && C > 0, WB_ERR_ARG, "wb_forward_decoder: bad argument");
-  wb::GpuTurn turn;
+  wb::GpuTurn turn(m->device);
   std::lock_guard<std::mutex> lk(g_stateless_mu);
   WB_HIP(hipSetDevice(m->device));
   wb_model* sc = m;
@@ -289,7 +289,7 @@ int wb_forward(wb_model* m, const float* mel, int B, int T, const int32_t* token
   WB_REQUIRE(m && mel && tokens && logits && B > 0, WB_ERR_ARG, "wb_forward: bad argument");
   WB_REQUIRE(T >= 1 && T <= m->max_mel_frames(), WB_ERR_SHAPE, "Audio length %d cannot exceed %d.", T,
              m->max_mel_frames());
-  wb::GpuTurn turn;
+  wb::GpuTurn turn(m->device);
   std::lock_guard<std::mutex> lk(g_stateless_mu);
   WB_HIP(hipSetDevice(m->device));
   wb_model* sc = m;

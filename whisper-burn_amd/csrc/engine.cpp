@@ -12,10 +12,10 @@
 
 namespace wb {
 
-GpuTurn::GpuTurn() {
-  static std::recursive_mutex mu;
+GpuTurn::GpuTurn(int device) {
+  static std::recursive_mutex mu[64];          // (per device: the fault is a co-execution fault of one GPU's SIMDs)
   static const bool enabled = []() { const char* e = getenv("WHISPER_HIP_GPU_TURN"); return !(e && e[0] == '0'); }();
-  if (enabled) lk = std::unique_lock<std::recursive_mutex>(mu);
+  if (enabled) lk = std::unique_lock<std::recursive_mutex>(mu[device < 0 ? 0 : device & 63]);
 }
 
 int get_mel_tables(int device, double sample_rate, const MelTables** out_dev) {

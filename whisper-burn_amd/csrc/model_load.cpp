@@ -221,7 +221,7 @@ int build_model(TensorMap& tm, int device, int compute_dtype, wb_model** out) {
              "compute_dtype WB_BF16 was retired in round 4: the 16-bit matrix path is the split-precision fp16 kernel of WB_F32 "
              "models (f32-grade results; wb_model_encoder_gemm)");
   WB_REQUIRE(compute_dtype == WB_F32, WB_ERR_ARG, "bad compute_dtype %d", compute_dtype);
-  wb::GpuTurn turn;   // (the weight repacking / splitting kernels)
+  wb::GpuTurn turn(device);   // (the weight repacking / splitting kernels)
   Builder B(tm);
   auto m = std::make_unique<wb_model>();
   wb_dims& D = m->dims;

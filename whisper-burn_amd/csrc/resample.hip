@@ -155,7 +155,7 @@ int wb_resample_dev(int device, const float* src_dev, int64_t n_in, int32_t rate
              (long long)capacity);
   if (n_out) *n_out = n;
   if (n == 0) return WB_OK;
-  wb::GpuTurn turn;
+  wb::GpuTurn turn(device);
   WB_HIP(hipSetDevice(device));
   if (up == 1 && down == 1) {
     WB_HIP(hipMemcpyAsync(dst_dev, src_dev, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, nullptr));

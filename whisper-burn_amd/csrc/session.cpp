@@ -388,7 +388,7 @@ extern "C" {
 int wb_session_begin(wb_model* m, const float* pcm, int64_t n_pcm, const int64_t* starts, const int64_t* lens,
                      int n_windows, int max_beams, int padding, wb_session** out) {
   WB_REQUIRE(m && pcm && starts && lens && out, WB_ERR_ARG, "wb_session_begin: null argument");
-  wb::GpuTurn turn;
+  wb::GpuTurn turn(m->device);
   wb_session* s = nullptr;
   WB_TRY(session_create(m, n_windows, max_beams, padding, &s));
   int rc = session_encode_pcm(s, pcm, n_pcm, starts, lens, false);
@@ -400,7 +400,7 @@ int wb_session_begin(wb_model* m, const float* pcm, int64_t n_pcm, const int64_t
 int wb_session_begin_mel(wb_model* m, const float* mel, const int32_t* T, int n_windows, int max_beams, int padding,
                          wb_session** out) {
   WB_REQUIRE(m && mel && T && out, WB_ERR_ARG, "wb_session_begin_mel: null argument");
-  wb::GpuTurn turn;
+  wb::GpuTurn turn(m->device);
   wb_session* s = nullptr;
   WB_TRY(session_create(m, n_windows, max_beams, padding, &s));
   const int clip = m->max_mel_frames() - padding;
@@ -457,7 +457,7 @@ void wb_session_free(wb_session* s) {
 
 int wb_session_set_special_mask(wb_session* s, const uint8_t* is_special) {
   WB_REQUIRE(s && is_special, WB_ERR_ARG, "wb_session_set_special_mask: null argument");
-  wb::GpuTurn turn;
+  wb::GpuTurn turn(s->device);
   const int V = s->m->dims.n_vocab;
   WB_HIP(hipSetDevice(s->m->device));
   WB_TRY(s->mask.ensure((size_t)V * 4));
@@ -1513,7 +1513,7 @@ extern "C" int wb_beam_search_device(int device, const wb_decode_params* p, int 
   const int W = n_windows, k = p->beam_size, S = W * MAX_BEAMS, P = 4, V = n_vocab, eot = p->tok_end_of_text;
   const int32_t prompt[4] = {p->tok_start_of_transcript, p->tok_language, p->tok_transcribe, p->tok_no_timestamps};
   WB_REQUIRE(row_stride >= P + p->max_depth, WB_ERR_ARG, "row_stride %d < %d", row_stride, P + p->max_depth);
-  wb::GpuTurn turn;
+  wb::GpuTurn turn(device);
   WB_HIP(hipSetDevice(device));
   const StepLayout L = make_step_layout(S, W);
   const BeamChainLayout bl = make_beam_layout(W, p->max_depth);
@@ -1567,7 +1567,7 @@ int wb_session_step(wb_session* s, const int32_t* new_tokens, const int32_t* par
   wb_model* m = s->m;
   const wb_dims& D = m->dims;
   const int V = D.n_vocab, S = s->S;
-  wb::GpuTurn turn;
+  wb::GpuTurn turn(s->device);
   WB_HIP(hipSetDevice(m->device));
   if (!s->decode_ready) WB_TRY(session_reserve(s, D.n_text_ctx));
   WB_REQUIRE(n >= 1 && n <= S, WB_ERR_ARG, "wb_session_step: n = %d outside [1, %d]", n, S);
@@ -1644,7 +1644,7 @@ int wb_session_last_logprobs(wb_session* s, int slot, float* out) {
   WB_REQUIRE(s->last_had_logits && slot >= 0 && slot < s->prev_n, WB_ERR_STATE,
              "wb_session_last_logprobs: no logits for slot %d", slot);
   const int V = s->m->dims.n_vocab;
-  wb::GpuTurn turn;
+  wb::GpuTurn turn(s->device);
   WB_HIP(hipSetDevice(s->m->device));
   launch_dec_logprob_row(s->st, s->logits.as<float>() + (size_t)slot * V, 1, (int64_t)s->S * V, V,
                          s->mask.as<float>(), s->last_use_mask,
@@ -1659,7 +1659,7 @@ int wb_session_encoder_output(wb_session* s, int w, float* out, int32_t* C) {
   const int d = s->m->dims.n_audio_state;
   if (C) *C = s->C[w];
   if (out) {
-    wb::GpuTurn turn;
+    wb::GpuTurn turn(s->device);
     WB_HIP(hipSetDevice(s->m->device));
     WB_HIP(hipMemcpyAsync(out, s->enc_out.as<float>() + (size_t)s->row0[w] * d, (size_t)s->C[w] * d * 4,
                           hipMemcpyDeviceToHost, s->st));

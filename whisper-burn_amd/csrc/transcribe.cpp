@@ -291,7 +291,7 @@ static int session_step_thunk(void* user, const int32_t* new_tokens, const int32
 extern "C" int wb_session_decode(wb_session* s, const wb_decode_params* p, int32_t* out_tokens, int32_t row_stride,
                                  int32_t* out_lens) {
   WB_REQUIRE(s && p && out_tokens && out_lens, WB_ERR_ARG, "wb_session_decode: null argument");
-  wb::GpuTurn turn;
+  wb::GpuTurn turn(s->device);
   WB_REQUIRE(p->beam_size >= 1 && p->beam_size <= s->max_beams, WB_ERR_ARG, "beam_size %d outside [1, %d]",
              p->beam_size, s->max_beams);
   if (!s->decode_ready || s->Lmax < 4 + p->max_depth) WB_TRY(session_reserve(s, 4 + p->max_depth + 1));
@@ -406,7 +406,7 @@ static int waveform_to_tokens_impl(wb_model* m, const float* pcm, bool pcm_on_de
                                    int32_t* win_tokens, int32_t row_stride, int32_t* win_lens, int32_t* stitched,
                                    int64_t stitched_cap, int64_t* n_stitched) {
   WB_REQUIRE(m && pcm && p && is_special && win_tokens && win_lens, WB_ERR_ARG, "wb_waveform_to_tokens: null argument");
-  wb::GpuTurn turn;   // (the sharded entry point calls this for its local windows and exchanges results outside the turn)
+  wb::GpuTurn turn(m->device);   // (the sharded entry point calls this for its local windows and exchanges results outside the turn)
   WB_REQUIRE(p->padding >= 0 && p->padding < m->max_mel_frames(), WB_ERR_ARG, "bad padding");
   // transcribe.rs:32-34
   const int64_t wlen = wb_max_waveform_samples(m->max_mel_frames() - p->padding);

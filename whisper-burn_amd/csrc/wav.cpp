@@ -144,7 +144,7 @@ static int read_wav_f32(const char* path, float* out, int64_t capacity, int64_t*
 int wb_pcm_s16_to_f32_dev(int device, const int16_t* src_dev, int64_t n, float* dst_dev) {
   WB_REQUIRE(n >= 0 && (n == 0 || (src_dev && dst_dev)), WB_ERR_ARG, "wb_pcm_s16_to_f32_dev: bad argument");
   if (n == 0) return WB_OK;
-  wb::GpuTurn turn;
+  wb::GpuTurn turn(device);
   WB_HIP(hipSetDevice(device));
   launch_pcm_s16_to_f32(nullptr, src_dev, n, dst_dev);
   WB_HIP(hipGetLastError());

@@ -15,8 +15,8 @@
 
 namespace wb {
 
-// One GPU "turn" per process.  Every entry point that enqueues kernels holds it from its first launch to its last
-// synchronisation, so kernels of different sessions / streams of this process never run on the GPU at the same time.
+// One GPU "turn" per device and process.  Every entry point that enqueues kernels holds its device's turn from its first launch
+// to its last synchronisation, so kernels of different sessions / streams of this process never run on one GPU at the same time.
 // Why (round 6, profiles/r06_y_*): on gfx950 a wave's packed-FP32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32)
 // return wrong results in lanes 48-63 while a wave of ANOTHER kernel executes f16 MFMAs (v_mfma_f32_32x32x16_f16,
 // v_mfma_f32_16x16x32_f16) on the same SIMD -- tools/pk_mfma_probe.cpp reproduces it without this library.  Two threads
@@ -26,7 +26,7 @@ namespace wb {
 // WHISPER_HIP_GPU_TURN=0 (developer switch: the probes that demonstrate the fault) makes it a no-op.
 struct GpuTurn {
   std::unique_lock<std::recursive_mutex> lk;
-  GpuTurn();
+  explicit GpuTurn(int device);
 };
 
 // ---- errors -------------------------------------------------------------------
