@@ -63,6 +63,31 @@ def test_two_threads_decode_with_one_model(beam):
     eng.close()
 
 
+def test_two_threads_encode_bit_identical_outputs():
+    """The sensitive form of the test above: Session.begin (mel + encoder + cross-K/V) from two threads at once, 60 rounds, every
+    window's encoder output compared BIT FOR BIT with the single-threaded one -- token equality can hide a few wrong log-mel
+    frames, this cannot.  Without the GPU turn 5 - 25 % of the rounds differ (profiles/r06_y_threads_enc*.txt)."""
+    from whisper_burn_amd.model import max_waveform_samples
+    eng = wb.Whisper.from_tensors(_micro())
+    clips = [synth.synth_audio(16000 * 47, 501), synth.synth_audio(16000 * 47, 502)]
+    win = max_waveform_samples(eng.max_mel_frames() - 12)
+
+    def enc(c):
+        starts, lens = wb.window_extents(len(c), 16000, win)
+        s = wb.Session.begin(eng, c, starts, lens, 1, 12)
+        out = [s.encoder_output(w).copy() for w in range(len(starts))]
+        s.close()
+        return out
+
+    ref = [enc(c) for c in clips]
+    bad = 0
+    for _ in range(60):
+        got = _run_threads([lambda c=c: enc(c) for c in clips])
+        bad += sum(not np.array_equal(g, r) for gi, ri in zip(got, ref) for g, r in zip(gi, ri))
+    assert bad == 0, f"{bad} of {60 * 2 * len(ref[0])} encoder outputs differ from the single-threaded bits"
+    eng.close()
+
+
 def test_a_guard_trip_in_one_thread_does_not_disturb_the_other():
     """Thread A's clip makes an encoder activation leave fp16's range (checkpoint with a 1e5 hidden unit, exact result unchanged:
     tests/test_gpu_guard.py) -- its pass falls back to exact f32 behind the decode; thread B decodes on the SAME model meanwhile.
