@@ -3,7 +3,8 @@
 // another stream?  Victim: every thread runs dft20 R times on a thread-private sequence and stores a checksum; the result of a
 // quiet run is the reference.  Aggressor (argv[2]): 0 = v_mfma_f32_32x32x16_f16 loop, 1 = v_mfma_f32_32x32x2_f32 loop,
 // 2 = v_mfma_f32_16x16x32_f16 loop, 3 = plain VALU loop, 4 = none; 10 / 11 / 12 = as 0 with a register allocation of 152 / 144 / 136
-// VGPRs, 13 = as 3 with 152; 14 / 15 = as 1 / 2 with 152; 16 / 17 / 18 = as 0 with 128 / 120 / 96.
+// VGPRs, 13 = as 3 with 152; 14 / 15 = as 1 / 2 with 152; 16 / 17 / 18 = as 0 with 128 / 120 / 96;
+// 30 / 31 / 32 = aggressor 15 against a victim whose own allocation is 152 / 128 / 96 VGPRs (default victim: 64).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../csrc -o pk_mfma_probe pk_mfma_probe.cpp && ./pk_mfma_probe [seconds] [aggressor]
 #include "../csrc/mel.hip"   // (the anonymous-namespace helpers: dft20, cpx)
 
@@ -15,6 +16,27 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 using namespace wb;
+
+template <int TOPV>
+__global__ __launch_bounds__(320, 2) void victim_kernel_t(float* out, int reps) {
+  // (kinds 30 - 32: the victim with a register allocation of its own choosing: 152 / 128 / 96)
+  if constexpr (TOPV == 151) asm volatile("v_mov_b32 v151, 0" ::: "v151");
+  if constexpr (TOPV == 127) asm volatile("v_mov_b32 v127, 0" ::: "v127");
+  if constexpr (TOPV == 95) asm volatile("v_mov_b32 v95, 0" ::: "v95");
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  cpx z[20];
+#pragma unroll
+  for (int i = 0; i < 20; i++) z[i] = cpx{(float)((gid * 7 + i * 13) % 97) * 0.01f - 0.4f, (float)((gid * 5 + i * 11) % 89) * 0.01f - 0.3f};
+  for (int r = 0; r < reps; r++) {
+    dft20(z);
+#pragma unroll
+    for (int i = 0; i < 20; i++) { z[i].re *= 0.2236068f; z[i].im *= 0.2236068f; }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 20; i++) s += z[i].re * (float)(i + 1) + z[i].im * (float)(21 + i);
+  out[gid] = s;
+}
 
 __global__ __launch_bounds__(320, 4) void victim_kernel(float* out, int reps) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -137,6 +159,7 @@ int main(int argc, char** argv) {
       else if (kind == 11) hipLaunchKernelGGL((aggressor_kernel<0, 143>), dim3(1024), dim3(256), 0, sa, sink, 200);
       else if (kind == 12) hipLaunchKernelGGL((aggressor_kernel<0, 135>), dim3(1024), dim3(256), 0, sa, sink, 200);
       else if (kind == 13) hipLaunchKernelGGL((aggressor_kernel<3, 151>), dim3(1024), dim3(256), 0, sa, sink, 200);
+      else if (kind >= 30 && kind <= 32) hipLaunchKernelGGL((aggressor_kernel<2, 151>), dim3(1024), dim3(256), 0, sa, sink, 200);
       else if (kind == 14) hipLaunchKernelGGL((aggressor_kernel<1, 151>), dim3(1024), dim3(256), 0, sa, sink, 200);
       else if (kind == 15) hipLaunchKernelGGL((aggressor_kernel<2, 151>), dim3(1024), dim3(256), 0, sa, sink, 200);
       else if (kind == 16) hipLaunchKernelGGL((aggressor_kernel<0, 127>), dim3(1024), dim3(256), 0, sa, sink, 200);
@@ -145,6 +168,9 @@ int main(int argc, char** argv) {
     }
     if (kind == 20) hipLaunchKernelGGL((mixed_kernel<0>), dim3(2 * blocks), dim3(320), 0, sv, out, reps, sink, 60);
     else if (kind == 21) hipLaunchKernelGGL((mixed_kernel<151>), dim3(2 * blocks), dim3(320), 0, sv, out, reps, sink, 60);
+    else if (kind == 30) hipLaunchKernelGGL((victim_kernel_t<151>), dim3(blocks), dim3(320), 0, sv, out, reps);
+    else if (kind == 31) hipLaunchKernelGGL((victim_kernel_t<127>), dim3(blocks), dim3(320), 0, sv, out, reps);
+    else if (kind == 32) hipLaunchKernelGGL((victim_kernel_t<95>), dim3(blocks), dim3(320), 0, sv, out, reps);
     else hipLaunchKernelGGL(victim_kernel, dim3(blocks), dim3(320), 0, sv, out, reps);
     CK(hipStreamSynchronize(sv));
     CK(hipMemcpy(got.data(), out, (size_t)n * 4, hipMemcpyDeviceToHost));
