@@ -4,7 +4,8 @@
 // quiet run is the reference.  Aggressor (argv[2]): 0 = v_mfma_f32_32x32x16_f16 loop, 1 = v_mfma_f32_32x32x2_f32 loop,
 // 2 = v_mfma_f32_16x16x32_f16 loop, 3 = plain VALU loop, 4 = none; 10 / 11 / 12 = as 0 with a register allocation of 152 / 144 / 136
 // VGPRs, 13 = as 3 with 152; 14 / 15 = as 1 / 2 with 152; 16 / 17 / 18 = as 0 with 128 / 120 / 96;
-// 30 / 31 / 32 = aggressor 15 against a victim whose own allocation is 152 / 128 / 96 VGPRs (default victim: 64).
+// 30 / 31 / 32 = aggressor 15 against a victim whose own allocation is 152 / 128 / 96 VGPRs (default victim: 64);
+// 40 = the 152-VGPR f16 aggressor and the 152-VGPR victim back to back on ONE stream.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../csrc -o pk_mfma_probe pk_mfma_probe.cpp && ./pk_mfma_probe [seconds] [aggressor]
 #include "../csrc/mel.hip"   // (the anonymous-namespace helpers: dft20, cpx)
 
@@ -168,6 +169,13 @@ int main(int argc, char** argv) {
     }
     if (kind == 20) hipLaunchKernelGGL((mixed_kernel<0>), dim3(2 * blocks), dim3(320), 0, sv, out, reps, sink, 60);
     else if (kind == 21) hipLaunchKernelGGL((mixed_kernel<151>), dim3(2 * blocks), dim3(320), 0, sv, out, reps, sink, 60);
+    else if (kind == 40) {
+      // ONE stream: f16-MFMA kernel, packed-FP32 kernel, f16-MFMA kernel, back to back (what a single-threaded caller of the
+      // library does all the time) -- in-order execution must keep them apart
+      hipLaunchKernelGGL((aggressor_kernel<2, 151>), dim3(1024), dim3(256), 0, sv, sink, 50);
+      hipLaunchKernelGGL((victim_kernel_t<151>), dim3(blocks), dim3(320), 0, sv, out, reps);
+      hipLaunchKernelGGL((aggressor_kernel<2, 151>), dim3(1024), dim3(256), 0, sv, sink, 50);
+    }
     else if (kind == 30) hipLaunchKernelGGL((victim_kernel_t<151>), dim3(blocks), dim3(320), 0, sv, out, reps);
     else if (kind == 31) hipLaunchKernelGGL((victim_kernel_t<127>), dim3(blocks), dim3(320), 0, sv, out, reps);
     else if (kind == 32) hipLaunchKernelGGL((victim_kernel_t<95>), dim3(blocks), dim3(320), 0, sv, out, reps);
